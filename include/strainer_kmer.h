@@ -1,0 +1,187 @@
+/* strainer_kmer.h -- C-ABI of libstrainer_kmer.so: the MI355X (gfx950) k-mer scrub/count path.
+ *
+ * This is the drop-in boundary.  The reference (jeremiahfaith/strainer2, a plain C program)
+ * has no FFI: its seam for this path is the internal call chain
+ *
+ *     GEN_hash_sequences_set_count_vec()   src/genome_compare.c:967-1030   (build the strain table)
+ *     GEN_all_kmer_counts[_skip_file]()    src/genome_compare.c:149-177,115-146 (walk a file list)
+ *     GEN_calculate_kmer_count()           src/genome_compare.c:179-236     (THE hot loop)
+ *     BIO_searchHash()/BIO_getHashKeys()   src/BIO_hash.c:161-172,174-188   (lookup / row order)
+ *     print_hash_counts()                  src/kmer_scrub_count.c:134-156   (TSV)
+ *
+ * The entry points below replace those calls one for one (each cites what it replaces).
+ * Plain pointers and sizes only; no C++ or torch types.  Two layers:
+ *
+ *   sk_*   device layer  -- context, table residency, batch scan, counters, collective.
+ *   skh_*  host layer    -- the reference's file/list/record semantics in C (kseq grammar,
+ *                           canonical 2-bit packing, BIO_hash slot-order replay, TSV print),
+ *                           driving the device layer.  kmer_scrub_count's main() is ~100 lines
+ *                           on top of it.
+ *
+ * There is NO CPU compute fallback: every window lookup runs in a HIP kernel.  Without a
+ * usable GPU sk_ctx_create() fails with SK_E_NODEVICE and callers must stop.
+ *
+ * Stream layout ("record stream") used by the scan entry points: the sequence bytes of the
+ * records, verbatim as decoded (any case), records separated by one '\n'.  Bytes that are not
+ * A/C/G/T (any case) break windows; '\n', 'N'/'n' and NUL never take part in any window.
+ *
+ * Thread-safety: one caller per sk_ctx at a time; distinct contexts are independent.
+ */
+#ifndef STRAINER_KMER_H
+#define STRAINER_KMER_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_K                 31            /* seed length: src/kmer_scrub_count.c:39, src/strain_detect.c:78 */
+#define SK_REF_TABLE_SLOTS   8000000u      /* DEFAULT_GENOME_HASH_SIZE: src/genome_compare.h:20 */
+#define SK_KEY_NONE          UINT64_MAX    /* "no packed key for this row" (row is a wide key) */
+
+/* error codes (0 = success) */
+#define SK_OK            0
+#define SK_E_NODEVICE   -1   /* no HIP device / HIP runtime failure at init                  */
+#define SK_E_HIP        -2   /* a HIP call failed; sk_last_error() has the text              */
+#define SK_E_ARG        -3   /* bad argument                                                 */
+#define SK_E_NOMEM      -4
+#define SK_E_OPEN       -5   /* file could not be opened (host layer)                        */
+#define SK_E_DUPKEY     -6   /* duplicate key passed to sk_table_load                        */
+#define SK_E_STATE      -7   /* call out of order (e.g. scan before table load)              */
+#define SK_E_RCCL       -8
+
+typedef struct sk_ctx sk_ctx;
+
+/* ----------------------------------------------------------------------------------------
+ * device layer
+ * -------------------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` (0-based).  Replaces BIO_initHash(): src/BIO_hash.c:14-37. */
+int  sk_ctx_create(sk_ctx **out, int device);
+/* Replaces BIO_destroyHashD(): src/BIO_hash.c:77-92. */
+void sk_ctx_destroy(sk_ctx *ctx);
+const char *sk_last_error(const sk_ctx *ctx);
+const char *sk_strerror(int code);
+
+/* Make a strain's key set resident in HBM and allocate ncols zeroed u32 counters per row.
+ * keys[r] is the canonical 31-mer of row r packed 2 bits/base, A=0 C=1 G=2 T=3, first base in
+ * the most significant position (bits 61..60), i.e. canonical = max(forward, revcomp) as
+ * integers == the reference's orient_string() choice (src/genome_compare.c:1100-1141).
+ * Rows whose key is not pure ACGT carry SK_KEY_NONE here and are supplied through
+ * sk_table_load_wide().  Row order is the caller's (the host layer passes BIO_hash slot order).
+ * Replaces the insert half of GEN_hash_sequences_set_count_vec(): src/genome_compare.c:1007-1019. */
+int sk_table_load(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t ncols);
+
+/* Wide keys: rows whose 31-byte upper-cased oriented key contains bytes other than ACGT
+ * (IUPAC letters in the strain: SURVEY 8(a) a3/a6).  keys31 = nwide * 32 bytes, each key
+ * 31 bytes + NUL; rows[i] = row index of key i. */
+int sk_table_load_wide(sk_ctx *ctx, const char *keys31, const uint32_t *rows, uint32_t nwide);
+
+/* Scan one batch of the record stream held in HOST memory: copy to HBM and count, both
+ * asynchronous on the context's stream (the call returns once the batch is staged; the
+ * caller may reuse `stream` immediately).  Adds 1 to counter column `col` of every row whose
+ * key equals the canonical form of a window.  Replaces the window loop of
+ * GEN_calculate_kmer_count(): src/genome_compare.c:213-229 + BIO_searchHash(). */
+int sk_scan_stream(sk_ctx *ctx, const uint8_t *stream, uint64_t nbytes, uint32_t col);
+
+/* Same, for a batch already resident in HBM (device pointer). */
+int sk_scan_device(sk_ctx *ctx, const void *dev_stream, uint64_t nbytes, uint32_t col);
+
+/* Wait for all queued work of the context. */
+int sk_sync(sk_ctx *ctx);
+
+/* Counter access.  Layout on the device: counts[col * nrows + row], u32, wrapping.
+ * fetch/set replace reads/writes of the reference's per-key count vectors
+ * (src/kmer_scrub_count.c:144-151; src/genome_compare.c:1011-1016). */
+int sk_counts_fetch(sk_ctx *ctx, uint32_t col, uint32_t *out /* nrows */);
+int sk_counts_set(sk_ctx *ctx, uint32_t col, const uint32_t *in /* nrows */);
+int sk_counts_zero(sk_ctx *ctx, uint32_t col);
+/* Device address of the whole counter block (ncols * nrows u32) for a caller-run collective
+ * (torch.distributed / RCCL all-reduce over xGMI).  New: the reference is single-process. */
+void    *sk_counts_device_ptr(sk_ctx *ctx);
+uint32_t sk_table_rows(const sk_ctx *ctx);
+uint32_t sk_table_cols(const sk_ctx *ctx);
+/* In-library sum all-reduce (u32, wrapping) of the counter block over an RCCL communicator
+ * (ncclComm_t passed as void*).  New: SURVEY 8(e). */
+int sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);
+
+/* Device-side timing of the scan kernel, from HIP events recorded on the context's stream
+ * around every scan kernel since the last reset: total milliseconds and launch count. */
+int sk_scan_timing(sk_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
+
+/* Tunables (before sk_table_load).  name: "bloom_bits_log2" (0 = no prefilter),
+ * "table_load_pct" (max load factor in percent). Unknown name -> SK_E_ARG. */
+int sk_set_option(sk_ctx *ctx, const char *name, long value);
+
+/* Device buffer helpers so that FFI callers need no HIP binding of their own. */
+int sk_dev_alloc(sk_ctx *ctx, void **dev, uint64_t nbytes);
+int sk_dev_free(sk_ctx *ctx, void *dev);
+int sk_dev_upload(sk_ctx *ctx, void *dev, const void *host, uint64_t nbytes);
+int sk_dev_download(sk_ctx *ctx, void *host, const void *dev, uint64_t nbytes);
+
+/* ----------------------------------------------------------------------------------------
+ * host layer (C): the reference's file semantics around the device layer
+ * -------------------------------------------------------------------------------------- */
+
+typedef struct skh_keyset {
+    uint32_t  nrows;        /* distinct oriented keys, in OUTPUT (BIO_hash slot) order          */
+    uint32_t  nwide;        /* how many of them are wide (non-ACGT bytes)                       */
+    uint64_t *packed;       /* [nrows] canonical packed key or SK_KEY_NONE                      */
+    uint32_t *first_count;  /* [nrows] column-0 value after the build phase                     */
+    char     *wide_keys;    /* [nwide*32]                                                       */
+    uint32_t *wide_rows;    /* [nwide]                                                          */
+    uint32_t  final_slots;  /* M of the replayed reference table                                */
+    uint64_t  short_records;/* records skipped because shorter than k-1 (reference crashes)     */
+} skh_keyset;
+
+/* Build phase.  Reads a FASTA/FASTQ(.gz) strain file with the reference parser's grammar
+ * (src/kseq.h:166-211), upper-cases, extracts every window's oriented key that contains no
+ * 'N', de-duplicates in first-occurrence order with column 0 = default_val + incr*(repeats)
+ * and replays BIO_hash's insertion/doubling (src/BIO_hash.c:39-61,129-139,208-216) from
+ * `initial_slots` to put the rows in the reference's output order.
+ * Replaces GEN_hash_sequences_set_count_vec(): src/genome_compare.c:967-1030. */
+int  skh_keyset_from_file(skh_keyset *ks, const char *path, uint32_t initial_slots,
+                          uint32_t default_val, uint32_t incr);
+int  skh_keyset_from_stream(skh_keyset *ks, const char *stream, size_t nbytes,
+                            uint32_t initial_slots, uint32_t default_val, uint32_t incr);
+void skh_keyset_free(skh_keyset *ks);
+/* Decode row r's key to 31 ASCII bytes + NUL. */
+void skh_keyset_key(const skh_keyset *ks, uint32_t row, char out[32]);
+/* Load a keyset into a context (sk_table_load + sk_table_load_wide + column 0). */
+int  skh_keyset_load(sk_ctx *ctx, const skh_keyset *ks, uint32_t ncols);
+
+/* Scan one FASTA/FASTQ(.gz) file into column `col`; *bases (may be NULL) accumulates the
+ * sequence bytes seen.  Replaces GEN_calculate_kmer_count(): src/genome_compare.c:179-236. */
+int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases);
+
+/* Walk a newline-separated file list.  `skip` (may be NULL): a line equal to it is not
+ * scanned and "skipping %s (identical match)" goes to `err`.  `progress` (may be NULL) gets
+ * "<line>\t<asctime>".  On an unreadable list or file the reference's message is written to
+ * `err` and SK_E_OPEN returned.  Lines with index % world != rank are logged but left to
+ * other ranks (world=1, rank=0 for the single-GPU program).
+ * Replaces GEN_all_kmer_counts(): src/genome_compare.c:149-177 and
+ * GEN_all_kmer_counts_skip_file(): src/genome_compare.c:115-146. */
+int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col,
+                  FILE *progress, FILE *err, uint32_t rank, uint32_t world, uint64_t *bases);
+
+/* Print the TSV: src/kmer_scrub_count.c:134-156 (5 header names always; 4 or 5 fields). */
+int skh_print_counts(sk_ctx *ctx, const skh_keyset *ks, FILE *out, int with_drug_column);
+
+/* The whole program with the reference's argv contract (src/kmer_scrub_count.c:29-131).
+ * Extra environment: SK_DEVICE (default 0).  Returns the process exit status. */
+int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err);
+
+/* Record reader exposed for tests: decode `path` into the record stream, calling `sink` with
+ * successive chunks (records separated by '\n'; a long record may be cut with a k-1 overlap).
+ * Returns number of records, or SK_E_OPEN. */
+typedef int (*skh_sink_fn)(void *user, const uint8_t *chunk, uint64_t nbytes);
+int64_t skh_decode_file(const char *path, uint64_t chunk_bytes, skh_sink_fn sink, void *user,
+                        uint64_t *bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRAINER_KMER_H */

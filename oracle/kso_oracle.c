@@ -408,6 +408,29 @@ int kso_scan_file(kso_table *t, const char *path, int k, int col, uint64_t *base
     return KSO_OK;
 }
 
+char *kso_decode_file(const char *path, size_t *out_len, long *nrecords, int *status)
+{
+    kso_reader *r = rd_open_file(path);
+    kso_buf out = { NULL, 0, 0 };
+    long l, n = 0;
+    if (!r) return NULL;
+    buf_reserve(&out, 0);
+    while ((l = rd_record(r)) >= 0) {
+        buf_reserve(&out, (size_t)l + 1);
+        memcpy(out.p + out.len, r->seq.p, (size_t)l);
+        out.len += (size_t)l;
+        out.p[out.len++] = '\n';
+        n++;
+    }
+    if (status) *status = (int)l;
+    if (nrecords) *nrecords = n;
+    if (out_len) *out_len = out.len;
+    rd_close(r);
+    return out.p;
+}
+
+void kso_free(void *p) { free(p); }
+
 /* a2: src/genome_compare.c:115-146 (skip variant) and :149-177 */
 int kso_scan_list(kso_table *t, const char *list_path, const char *skip, int k, int col,
                   FILE *progress, FILE *err, uint64_t *bases_seen)
@@ -450,6 +473,7 @@ void kso_scan_stream(kso_table *t, const char *stream, size_t len, int k, int co
     while (pos <= len) {
         const char *nl = (pos < len) ? (const char *)memchr(stream + pos, '\n', len - pos) : NULL;
         size_t n = nl ? (size_t)(nl - (stream + pos)) : len - pos;
+        if (!nl && n == 0 && pos > 0) break;            /* nothing after the final separator */
         rec.len = 0;
         buf_reserve(&rec, n);
         memcpy(rec.p, stream + pos, n);
@@ -474,6 +498,7 @@ int kso_build_from_stream(kso_table *t, const char *stream, size_t len, int k,
     while (pos <= len) {
         const char *nl = (pos < len) ? (const char *)memchr(stream + pos, '\n', len - pos) : NULL;
         size_t n = nl ? (size_t)(nl - (stream + pos)) : len - pos;
+        if (!nl && n == 0 && pos > 0) break;            /* nothing after the final separator */
         rec.len = 0;
         buf_reserve(&rec, n);
         memcpy(rec.p, stream + pos, n);

@@ -69,6 +69,12 @@ void kso_table_rows(const kso_table *t, int k, char *keys_out, unsigned *counts_
 /* a9: print the TSV exactly as the reference's print_hash_counts does. */
 void kso_print(const kso_table *t, FILE *out, int with_drug_column);
 
+/* Test helper: decode a FASTA/FASTQ(.gz) file with the reference parser's grammar and return
+ * every record's sequence, each followed by '\n', in one malloc'd buffer (free with
+ * kso_free).  *status = last parser return (-1 end of file, -2 truncated quality). */
+char *kso_decode_file(const char *path, size_t *out_len, long *nrecords, int *status);
+void  kso_free(void *p);
+
 /* Whole-program restatement: argv as the reference's kmer_scrub_count. Returns exit status. */
 int kso_main(int argc, char **argv, FILE *out, FILE *err);
 

@@ -1,0 +1,89 @@
+/* sk_common.h -- definitions shared by the host (C) and device (HIP) halves of libstrainer_kmer.
+ *
+ * Packed key convention (include/strainer_kmer.h): 31 bases, 2 bits each, A=0 C=1 G=2 T=3,
+ * first base in bits 61..60.  With that code the integer order of packed keys equals the
+ * signed-char ASCII order the reference compares in (A<C<G<T), so the reference's
+ * "lexicographically larger of window and reverse complement, forward on ties"
+ * (src/genome_compare.c:1100-1141) is max(fwd, rc) on integers.
+ */
+#ifndef SK_COMMON_H
+#define SK_COMMON_H
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SK_HD __host__ __device__ __forceinline__
+#else
+#define SK_HD static inline
+#endif
+
+#define SK_KMASK62   0x3FFFFFFFFFFFFFFFull
+#define SK_EMPTY64   0xFFFFFFFFFFFFFFFFull
+#define SK_OVERLAP   30u                 /* k-1 bytes shared by consecutive pieces of a cut record */
+
+/* 2-bit code of an (any-case) base byte; garbage for other bytes (callers gate on sk_is_acgt) */
+SK_HD uint32_t sk_code(uint32_t b)
+{
+    uint32_t x = (b >> 1) & 3u;          /* A0 C1 T2 G3 */
+    return x ^ (x >> 1);                 /* A0 C1 G2 T3 */
+}
+
+SK_HD int sk_is_acgt(uint32_t b)
+{
+    uint32_t u = b & 0xDFu;
+    return (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+}
+
+/* bytes that can never be inside a counted window: N (src/genome_compare.c:210,219,1007),
+ * the record separator, and NUL (C-string end in the reference) */
+SK_HD int sk_is_hard_break(uint32_t b)
+{
+    return ((b & 0xDFu) == 'N') | (b == '\n') | (b == 0u);
+}
+
+/* slot hash of a packed canonical key (device table; not the reference's djb2, which only
+ * matters for row ORDER and is replayed on the host) */
+SK_HD uint32_t sk_hash62(uint64_t key)
+{
+    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t h = lo ^ (hi * 0x9E3779B1u);
+    h ^= h >> 16; h *= 0x7FEB352Du;
+    h ^= h >> 15; h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+
+/* second, independent hash for the prefilter */
+SK_HD uint32_t sk_hash62b(uint64_t key)
+{
+    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t h = (lo * 0x85EBCA6Bu) ^ hi;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+/* FNV-1a over the 31 bytes of a wide key */
+SK_HD uint32_t sk_hash_wide(const char *k31)
+{
+    uint32_t h = 2166136261u;
+    for (int i = 0; i < 31; i++) { h ^= (uint8_t)k31[i]; h *= 16777619u; }
+    return h;
+}
+
+/* C-locale toupper, the only case mapping the reference applies (src/BIO_sequence.c:228-234) */
+SK_HD uint32_t sk_upper(uint32_t b) { return (b >= 'a' && b <= 'z') ? b - 32u : b; }
+
+/* The reference's nucleotide complement map (src/BIO_sequence.c:203-213), as data: every byte
+ * maps to (char)-1 except the IUPAC letters and a few symbols.  Reproduced quirks: upper-case
+ * K maps to '.', U maps to A.  Bytes >= 0x80 (negative subscript in the reference: undefined)
+ * map to -1 here. */
+static inline void sk_fill_complement(signed char t[256])
+{
+    static const char from[] = "-.^ATCGBVDHKMNRYSUWXatcgbvdhkmnrysuwx";
+    static const char to[]   = "-.^TAGCVBHD.KNYRSAWXtagcvbhdmknyrsawx";
+    int i;
+    for (i = 0; i < 256; i++) t[i] = -1;
+    for (i = 0; from[i]; i++) t[(unsigned char)from[i]] = (signed char)to[i];
+}
+
+#endif

@@ -1,0 +1,753 @@
+/* sk_host.c -- host layer (plain C) of libstrainer_kmer.so.
+ *
+ * Keeps the reference's FILE semantics around the device layer:
+ *   - FASTA/FASTQ(.gz) record grammar of the reference's parser (src/kseq.h:166-211), here as a
+ *     push-style state machine over inflated blocks;
+ *   - build phase (src/genome_compare.c:967-1030): oriented keys of the strain, first-occurrence
+ *     order, column-0 multiplicity -- keys are 62-bit packed integers, wide (non-ACGT) keys are
+ *     kept as bytes;
+ *   - BIO_hash slot-order replay (src/BIO_hash.c:39-61,129-139,208-216) so that rows come out in
+ *     exactly the reference's order;
+ *   - file-list walk, progress log, skip rule, error texts (src/genome_compare.c:115-177);
+ *   - TSV printing (src/kmer_scrub_count.c:134-156) and the program's argv contract (:29-131).
+ *
+ * No window is ever looked up on the CPU here: lookups happen in sk_scan_main / sk_scan_wide.
+ */
+#define _GNU_SOURCE
+#include <ctype.h>
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "../../include/strainer_kmer.h"
+#include "sk_common.h"
+
+/* =========================================================================================
+ * record parser
+ * ======================================================================================= */
+
+enum { P_SEEK, P_NAME, P_COMMENT, P_LINE_START, P_SEQ, P_PLUS, P_QUAL, P_STOP };
+
+typedef int (*rec_fn)(void *user, char *seq, size_t len);
+
+typedef struct {
+    int     state;
+    int     name_any, line_any, qual_any;
+    char   *seq;  size_t seq_len, seq_cap;
+    char   *qual; size_t qual_len, qual_cap;
+    rec_fn  on_record;
+    void   *user;
+    int64_t nrecords;
+    int     sink_rc;
+} parser;
+
+static void grow(char **p, size_t *cap, size_t need)
+{
+    if (need + 1 > *cap) {
+        size_t nc = *cap ? *cap : 4096;
+        while (nc < need + 1) nc *= 2;
+        *p = (char *)realloc(*p, nc);
+        *cap = nc;
+    }
+}
+
+static void parser_init(parser *ps, rec_fn fn, void *user)
+{
+    memset(ps, 0, sizeof *ps);
+    ps->state = P_SEEK;
+    ps->on_record = fn;
+    ps->user = user;
+}
+
+static void parser_free(parser *ps) { free(ps->seq); free(ps->qual); }
+
+static void emit(parser *ps)
+{
+    grow(&ps->seq, &ps->seq_cap, ps->seq_len);
+    ps->seq[ps->seq_len] = '\0';
+    ps->nrecords++;
+    if (ps->on_record) {
+        int rc = ps->on_record(ps->user, ps->seq, ps->seq_len);
+        if (rc) { ps->sink_rc = rc; ps->state = P_STOP; }
+    }
+}
+
+static void begin_header(parser *ps)
+{
+    ps->state = P_NAME;
+    ps->name_any = 0;
+    ps->seq_len = 0;
+    ps->qual_len = 0;
+}
+
+/* a trailing CR is dropped once the accumulated text is longer than one byte (src/kseq.h:136) */
+static void strip_cr(char *p, size_t *len) { if (*len > 1 && p[*len - 1] == '\r') (*len)--; }
+
+static void finish_fastq(parser *ps)
+{
+    if (ps->qual_len == ps->seq_len) { emit(ps); if (ps->state != P_STOP) ps->state = P_SEEK; }
+    else ps->state = P_STOP;                 /* -2: this record and the rest of the file are dropped */
+}
+
+static void parser_feed(parser *ps, const unsigned char *b, size_t n)
+{
+    size_t i = 0;
+    while (i < n && ps->state != P_STOP) {
+        switch (ps->state) {
+        case P_SEEK:
+            while (i < n && b[i] != '>' && b[i] != '@') i++;
+            if (i < n) { i++; begin_header(ps); }
+            break;
+        case P_NAME:
+            while (i < n) {
+                int c = b[i++];
+                ps->name_any = 1;
+                if (isspace(c)) { ps->state = (c == '\n') ? P_LINE_START : P_COMMENT; break; }
+            }
+            break;
+        case P_COMMENT: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            if (nl) { i = (size_t)(nl - b) + 1; ps->state = P_LINE_START; } else i = n;
+            break; }
+        case P_LINE_START: {
+            int c = b[i++];
+            if (c == '\n') break;
+            if (c == '>' || c == '@') { emit(ps); if (ps->state != P_STOP) begin_header(ps); break; }
+            if (c == '+') { ps->state = P_PLUS; break; }
+            grow(&ps->seq, &ps->seq_cap, ps->seq_len + 1);
+            ps->seq[ps->seq_len++] = (char)c;
+            ps->line_any = 0;
+            ps->state = P_SEQ;
+            break; }
+        case P_SEQ: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            size_t take = nl ? (size_t)(nl - (b + i)) : n - i;
+            ps->line_any = 1;
+            grow(&ps->seq, &ps->seq_cap, ps->seq_len + take);
+            memcpy(ps->seq + ps->seq_len, b + i, take);
+            ps->seq_len += take;
+            i += take;
+            if (nl) { i++; strip_cr(ps->seq, &ps->seq_len); ps->state = P_LINE_START; }
+            break; }
+        case P_PLUS: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            if (nl) { i = (size_t)(nl - b) + 1; ps->state = P_QUAL; ps->qual_len = 0; ps->qual_any = 0; } else i = n;
+            break; }
+        case P_QUAL: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            size_t take = nl ? (size_t)(nl - (b + i)) : n - i;
+            ps->qual_any = 1;
+            grow(&ps->qual, &ps->qual_cap, ps->qual_len + take);
+            memcpy(ps->qual + ps->qual_len, b + i, take);
+            ps->qual_len += take;
+            i += take;
+            if (nl) {
+                i++;
+                strip_cr(ps->qual, &ps->qual_len);
+                ps->qual_any = 0;
+                if (ps->qual_len >= ps->seq_len) finish_fastq(ps);
+            }
+            break; }
+        default: i = n; break;
+        }
+    }
+}
+
+static void parser_eof(parser *ps)
+{
+    switch (ps->state) {
+    case P_NAME:       if (ps->name_any) emit(ps); break;     /* header cut by EOF: empty record */
+    case P_COMMENT:    emit(ps); break;
+    case P_LINE_START: emit(ps); break;
+    case P_SEQ:        if (ps->line_any) strip_cr(ps->seq, &ps->seq_len); emit(ps); break;
+    case P_QUAL:       if (ps->qual_any) strip_cr(ps->qual, &ps->qual_len); finish_fastq(ps); break;
+    default: break;                                           /* P_SEEK, P_PLUS (-2), P_STOP */
+    }
+    ps->state = P_STOP;
+}
+
+/* run a whole (possibly gzipped) file through the parser */
+static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords, int *sink_rc)
+{
+    enum { BLK = 1 << 20 };
+    gzFile g = gzopen(path, "r");
+    unsigned char *blk;
+    parser ps;
+    int got;
+    if (!g) return SK_E_OPEN;
+    gzbuffer(g, 1 << 18);
+    blk = (unsigned char *)malloc(BLK);
+    parser_init(&ps, fn, user);
+    while (ps.state != P_STOP && (got = gzread(g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
+    if (ps.state != P_STOP) parser_eof(&ps);
+    if (nrecords) *nrecords = ps.nrecords;
+    if (sink_rc) *sink_rc = ps.sink_rc;
+    parser_free(&ps);
+    free(blk);
+    gzclose(g);
+    return SK_OK;
+}
+
+static int parse_memory(const char *text, size_t n, rec_fn fn, void *user)
+{
+    /* "stream" form: every '\n'-separated line is one decoded record */
+    size_t pos = 0;
+    char *tmp = NULL; size_t cap = 0;
+    int rc = 0;
+    while (pos <= n) {
+        const char *nl = pos < n ? (const char *)memchr(text + pos, '\n', n - pos) : NULL;
+        size_t len = nl ? (size_t)(nl - (text + pos)) : n - pos;
+        if (!nl && len == 0 && pos > 0) break;          /* nothing after the final separator */
+        grow(&tmp, &cap, len);
+        memcpy(tmp, text + pos, len);
+        tmp[len] = '\0';
+        rc = fn(user, tmp, len);
+        if (rc || !nl) break;
+        pos += len + 1;
+    }
+    free(tmp);
+    return rc;
+}
+
+/* =========================================================================================
+ * record stream writer: packs decoded records into '\n'-separated chunks for the device
+ * ======================================================================================= */
+
+typedef struct {
+    uint8_t    *buf;
+    uint64_t    cap, len;
+    skh_sink_fn sink;
+    void       *user;
+    uint64_t    bases;
+    int         rc;
+} stream_writer;
+
+static int writer_flush(stream_writer *w)
+{
+    if (w->len && !w->rc) w->rc = w->sink(w->user, w->buf, w->len);
+    w->len = 0;
+    return w->rc;
+}
+
+static int writer_record(void *user, char *seq, size_t len)
+{
+    stream_writer *w = (stream_writer *)user;
+    size_t off = 0;
+    w->bases += len;
+    if (len < SK_K) return 0;                        /* src/genome_compare.c:204: no window fits */
+    while (off < len) {
+        uint64_t room, take;
+        if (w->cap - w->len < 2 * SK_K + 2 && writer_flush(w)) return w->rc;
+        room = w->cap - w->len - 1;
+        take = len - off;
+        if (take > room) take = room;
+        memcpy(w->buf + w->len, seq + off, take);
+        w->len += take;
+        w->buf[w->len++] = '\n';
+        off += take;
+        if (off < len) off -= SK_OVERLAP;            /* cut record: next piece re-reads k-1 bytes */
+    }
+    return 0;
+}
+
+int64_t skh_decode_file(const char *path, uint64_t chunk_bytes, skh_sink_fn sink, void *user, uint64_t *bases)
+{
+    stream_writer w;
+    int64_t nrec = 0;
+    int rc;
+    if (chunk_bytes < 4096) chunk_bytes = 4096;
+    memset(&w, 0, sizeof w);
+    w.buf = (uint8_t *)malloc(chunk_bytes);
+    w.cap = chunk_bytes;
+    w.sink = sink;
+    w.user = user;
+    rc = parse_file(path, writer_record, &w, &nrec, NULL);
+    if (rc == SK_OK) writer_flush(&w);
+    if (bases) *bases += w.bases;
+    free(w.buf);
+    if (rc != SK_OK) return rc;
+    if (w.rc) return w.rc;
+    return nrec;
+}
+
+/* =========================================================================================
+ * build phase: oriented keys in first-occurrence order
+ * ======================================================================================= */
+
+#define WIDE_FLAG 0x8000000000000000ull     /* order-list entry refers to wide key (index in low bits) */
+
+typedef struct {
+    /* packed-key set: open addressing on u64 -> order index */
+    uint64_t *pk; uint32_t *pv; uint64_t pmask; uint64_t pcount;
+    /* wide-key set */
+    char *wkeys; uint32_t *wv; uint32_t wn, wcap; uint32_t *windex; uint32_t wmask;
+    /* insertion order */
+    uint64_t *order; uint32_t *count; uint32_t n, cap;
+    uint32_t default_val, incr;
+    uint64_t short_records;
+    signed char comp[256];
+} builder;
+
+static void builder_init(builder *b, uint32_t default_val, uint32_t incr)
+{
+    memset(b, 0, sizeof *b);
+    b->pmask = (1u << 16) - 1;
+    b->pk = (uint64_t *)malloc((b->pmask + 1) * sizeof(uint64_t));
+    b->pv = (uint32_t *)malloc((b->pmask + 1) * sizeof(uint32_t));
+    memset(b->pk, 0xFF, (b->pmask + 1) * sizeof(uint64_t));
+    b->wmask = 63;
+    b->windex = (uint32_t *)calloc(b->wmask + 1, sizeof(uint32_t));
+    b->default_val = default_val;
+    b->incr = incr;
+    sk_fill_complement(b->comp);
+}
+
+static void builder_free(builder *b)
+{
+    free(b->pk); free(b->pv); free(b->wkeys); free(b->wv); free(b->windex);
+    free(b->order); free(b->count);
+}
+
+static uint32_t builder_append(builder *b, uint64_t entry)
+{
+    if (b->n == b->cap) {
+        b->cap = b->cap ? b->cap * 2 : 1 << 16;
+        b->order = (uint64_t *)realloc(b->order, (size_t)b->cap * sizeof(uint64_t));
+        b->count = (uint32_t *)realloc(b->count, (size_t)b->cap * sizeof(uint32_t));
+    }
+    b->order[b->n] = entry;
+    b->count[b->n] = b->default_val;
+    return b->n++;
+}
+
+static void builder_grow_packed(builder *b)
+{
+    uint64_t oldn = b->pmask + 1, i, nm = oldn * 2 - 1;
+    uint64_t *ok = b->pk; uint32_t *ov = b->pv;
+    b->pk = (uint64_t *)malloc((nm + 1) * sizeof(uint64_t));
+    b->pv = (uint32_t *)malloc((nm + 1) * sizeof(uint32_t));
+    memset(b->pk, 0xFF, (nm + 1) * sizeof(uint64_t));
+    for (i = 0; i < oldn; i++) {
+        uint64_t s;
+        if (ok[i] == SK_EMPTY64) continue;
+        s = sk_hash62(ok[i]) & nm;
+        while (b->pk[s] != SK_EMPTY64) s = (s + 1) & nm;
+        b->pk[s] = ok[i]; b->pv[s] = ov[i];
+    }
+    b->pmask = nm;
+    free(ok); free(ov);
+}
+
+static void builder_add_packed(builder *b, uint64_t key)
+{
+    uint64_t s = sk_hash62(key) & b->pmask;
+    while (b->pk[s] != SK_EMPTY64) {
+        if (b->pk[s] == key) { b->count[b->pv[s]] += b->incr; return; }
+        s = (s + 1) & b->pmask;
+    }
+    b->pk[s] = key;
+    b->pv[s] = builder_append(b, key);
+    if (++b->pcount * 2 > b->pmask) builder_grow_packed(b);
+}
+
+static void builder_add_wide(builder *b, const char *key31)
+{
+    uint32_t s = sk_hash_wide(key31) & b->wmask, i;
+    while (b->windex[s]) {
+        uint32_t e = b->windex[s] - 1;
+        if (memcmp(b->wkeys + (size_t)e * 32, key31, SK_K) == 0) { b->count[b->wv[e]] += b->incr; return; }
+        s = (s + 1) & b->wmask;
+    }
+    if (b->wn == b->wcap) {
+        b->wcap = b->wcap ? b->wcap * 2 : 64;
+        b->wkeys = (char *)realloc(b->wkeys, (size_t)b->wcap * 32);
+        b->wv = (uint32_t *)realloc(b->wv, (size_t)b->wcap * sizeof(uint32_t));
+    }
+    memcpy(b->wkeys + (size_t)b->wn * 32, key31, SK_K);
+    b->wkeys[(size_t)b->wn * 32 + SK_K] = '\0';
+    b->wv[b->wn] = builder_append(b, WIDE_FLAG | b->wn);
+    b->windex[s] = ++b->wn;
+    if (b->wn * 2 > b->wmask) {                      /* rebuild the small index */
+        uint32_t nm = b->wmask * 2 + 1;
+        free(b->windex);
+        b->windex = (uint32_t *)calloc((size_t)nm + 1, sizeof(uint32_t));
+        for (i = 0; i < b->wn; i++) {
+            uint32_t t = sk_hash_wide(b->wkeys + (size_t)i * 32) & nm;
+            while (b->windex[t]) t = (t + 1) & nm;
+            b->windex[t] = i + 1;
+        }
+        b->wmask = nm;
+    }
+}
+
+/* one strain record: every window, rolling 2-bit pack; windows with a non-ACGT byte that is
+ * not a hard breaker take the byte-string route (src/genome_compare.c:1000-1024) */
+static int builder_record(void *user, char *seq, size_t len)
+{
+    builder *b = (builder *)user;
+    uint64_t fwd = 0, rc = 0;
+    uint32_t run = 0, soft = 0;
+    size_t i;
+    if (len + 1 < SK_K) { b->short_records++; return 0; }   /* reference: size_t underflow, crash */
+    for (i = 0; i < len; i++) {
+        uint32_t c = (uint8_t)seq[i], code = sk_code(c);
+        fwd = ((fwd << 2) | code) & SK_KMASK62;
+        rc = (rc >> 2) | ((uint64_t)(3u - code) << 60);
+        run = sk_is_acgt(c) ? run + 1 : 0;
+        soft = sk_is_hard_break(c) ? 0 : soft + 1;
+        if (run >= SK_K) {
+            builder_add_packed(b, fwd > rc ? fwd : rc);
+        } else if (soft >= SK_K) {
+            char u[SK_K], o[SK_K + 1];
+            const char *w = seq + i - (SK_K - 1);
+            int j, sign = 0, pure = 1;
+            for (j = 0; j < SK_K; j++) u[j] = (char)sk_upper((uint8_t)w[j]);
+            for (j = 0; j < SK_K && !sign; j++) {
+                signed char f = (signed char)u[j], r = b->comp[(uint8_t)u[SK_K - 1 - j]];
+                sign = (f > r) - (r > f);
+            }
+            if (sign >= 0) memcpy(o, u, SK_K);
+            else for (j = 0; j < SK_K; j++) o[SK_K - 1 - j] = (char)b->comp[(uint8_t)u[j]];
+            o[SK_K] = '\0';
+            for (j = 0; j < SK_K; j++) pure &= (o[j] == 'A') | (o[j] == 'C') | (o[j] == 'G') | (o[j] == 'T');
+            if (pure) {                              /* e.g. U in the strain whose revcomp wins */
+                uint64_t key = 0;
+                for (j = 0; j < SK_K; j++) key = (key << 2) | sk_code((uint8_t)o[j]);
+                builder_add_packed(b, key);
+            } else {
+                builder_add_wide(b, o);
+            }
+        }
+    }
+    return 0;
+}
+
+/* ---- BIO_hash order replay ------------------------------------------------------------- */
+
+static void decode_key(uint64_t key, char out[32])
+{
+    int i;
+    for (i = 0; i < SK_K; i++) out[i] = "ACGT"[(key >> (2 * (SK_K - 1 - i))) & 3];
+    out[SK_K] = '\0';
+}
+
+static uint32_t djb2_bytes(const char *s)           /* src/BIO_hash.c:208-216, signed bytes */
+{
+    uint32_t h = 5381u;
+    for (; *s; s++) h = h * 33u + (uint32_t)(int32_t)(signed char)*s;
+    return h;
+}
+
+/* Replays insert-with-doubling and returns entries in ascending slot order of the final table. */
+static uint32_t *replay_slot_order(const builder *b, uint32_t initial_slots, uint32_t *final_slots)
+{
+    uint32_t M = initial_slots, N = 0, e, i;
+    uint32_t *h32 = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
+    int32_t *slot;
+    uint32_t *rows;
+    char tmp[32];
+    if (M == 0) M = 1000; else if (M < 10) M = 10;       /* src/BIO_hash.c:18-21 */
+    for (e = 0; e < b->n; e++) {
+        if (b->order[e] & WIDE_FLAG) h32[e] = djb2_bytes(b->wkeys + (size_t)(b->order[e] & 0xFFFFFFFFu) * 32);
+        else { decode_key(b->order[e], tmp); h32[e] = djb2_bytes(tmp); }
+    }
+    slot = (int32_t *)malloc((size_t)M * sizeof(int32_t));
+    memset(slot, 0xFF, (size_t)M * sizeof(int32_t));
+    for (e = 0; e < b->n; e++) {
+        uint32_t s = h32[e] % M;
+        while (slot[s] >= 0) s = (s + 1) % M;
+        slot[s] = (int32_t)e;
+        if (N++ >= M / 2) {                              /* post-increment test: src/BIO_hash.c:138 */
+            uint32_t M2 = M + M;
+            int32_t *ns = (int32_t *)malloc((size_t)M2 * sizeof(int32_t));
+            memset(ns, 0xFF, (size_t)M2 * sizeof(int32_t));
+            N = 0;
+            for (i = 0; i < M; i++) {                    /* old slot order: src/BIO_hash.c:54-58 */
+                uint32_t t;
+                if (slot[i] < 0) continue;
+                t = h32[slot[i]] % M2;
+                while (ns[t] >= 0) t = (t + 1) % M2;
+                ns[t] = slot[i];
+                N++;
+            }
+            free(slot);
+            slot = ns;
+            M = M2;
+        }
+    }
+    rows = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
+    for (i = 0, e = 0; i < M; i++) if (slot[i] >= 0) rows[e++] = (uint32_t)slot[i];
+    free(slot);
+    free(h32);
+    *final_slots = M;
+    return rows;
+}
+
+static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
+{
+    uint32_t r, *rows = replay_slot_order(b, initial_slots, &ks->final_slots);
+    uint32_t *wide_newrow = (uint32_t *)calloc(b->wn ? b->wn : 1, sizeof(uint32_t));
+    ks->nrows = b->n;
+    ks->nwide = b->wn;
+    ks->short_records = b->short_records;
+    ks->packed = (uint64_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint64_t));
+    ks->first_count = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
+    ks->wide_keys = (char *)malloc((size_t)(b->wn ? b->wn : 1) * 32);
+    ks->wide_rows = (uint32_t *)malloc((size_t)(b->wn ? b->wn : 1) * sizeof(uint32_t));
+    for (r = 0; r < b->n; r++) {
+        uint64_t ent = b->order[rows[r]];
+        ks->first_count[r] = b->count[rows[r]];
+        if (ent & WIDE_FLAG) { ks->packed[r] = SK_KEY_NONE; wide_newrow[ent & 0xFFFFFFFFu] = r; }
+        else ks->packed[r] = ent;
+    }
+    for (r = 0; r < b->wn; r++) {
+        memcpy(ks->wide_keys + (size_t)r * 32, b->wkeys + (size_t)r * 32, 32);
+        ks->wide_rows[r] = wide_newrow[r];
+    }
+    free(wide_newrow);
+    free(rows);
+    return SK_OK;
+}
+
+int skh_keyset_from_file(skh_keyset *ks, const char *path, uint32_t initial_slots, uint32_t default_val, uint32_t incr)
+{
+    builder b;
+    int rc;
+    if (!ks || !path) return SK_E_ARG;
+    memset(ks, 0, sizeof *ks);
+    builder_init(&b, default_val, incr);
+    rc = parse_file(path, builder_record, &b, NULL, NULL);
+    if (rc == SK_OK) rc = keyset_finish(ks, &b, initial_slots);
+    builder_free(&b);
+    return rc;
+}
+
+int skh_keyset_from_stream(skh_keyset *ks, const char *stream, size_t nbytes, uint32_t initial_slots,
+                           uint32_t default_val, uint32_t incr)
+{
+    builder b;
+    int rc;
+    if (!ks || (!stream && nbytes)) return SK_E_ARG;
+    memset(ks, 0, sizeof *ks);
+    builder_init(&b, default_val, incr);
+    parse_memory(stream, nbytes, builder_record, &b);
+    rc = keyset_finish(ks, &b, initial_slots);
+    builder_free(&b);
+    return rc;
+}
+
+void skh_keyset_free(skh_keyset *ks)
+{
+    if (!ks) return;
+    free(ks->packed); free(ks->first_count); free(ks->wide_keys); free(ks->wide_rows);
+    memset(ks, 0, sizeof *ks);
+}
+
+void skh_keyset_key(const skh_keyset *ks, uint32_t row, char out[32])
+{
+    uint32_t i;
+    if (ks->packed[row] != SK_KEY_NONE) { decode_key(ks->packed[row], out); return; }
+    for (i = 0; i < ks->nwide; i++)
+        if (ks->wide_rows[i] == row) { memcpy(out, ks->wide_keys + (size_t)i * 32, 32); return; }
+    out[0] = '\0';
+}
+
+int skh_keyset_load(sk_ctx *ctx, const skh_keyset *ks, uint32_t ncols)
+{
+    int rc = sk_table_load(ctx, ks->packed, ks->nrows, ncols);
+    if (rc) return rc;
+    rc = sk_table_load_wide(ctx, ks->wide_keys, ks->wide_rows, ks->nwide);
+    if (rc) return rc;
+    if (ks->nrows) rc = sk_counts_set(ctx, 0, ks->first_count);
+    return rc;
+}
+
+/* =========================================================================================
+ * scan phase
+ * ======================================================================================= */
+
+typedef struct { sk_ctx *ctx; uint32_t col; } scan_sink;
+
+static int scan_sink_fn(void *user, const uint8_t *chunk, uint64_t nbytes)
+{
+    scan_sink *s = (scan_sink *)user;
+    return sk_scan_stream(s->ctx, chunk, nbytes, s->col);
+}
+
+int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases)
+{
+    scan_sink s;
+    int64_t rc;
+    s.ctx = ctx; s.col = col;
+    rc = skh_decode_file(path, 32u << 20, scan_sink_fn, &s, bases);
+    return rc < 0 ? (int)rc : SK_OK;
+}
+
+int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
+                  FILE *err, uint32_t rank, uint32_t world, uint64_t *bases)
+{
+    FILE *fp = fopen(list_path, "r");
+    char *line = NULL, *nl;
+    size_t cap = 0;
+    uint32_t idx = 0;
+    int rc = SK_OK;
+    if (!fp) {
+        if (err) fprintf(err, "could not read file %s in GEN_all_kmer_counts()\n", list_path);
+        return SK_E_OPEN;
+    }
+    if (world == 0) world = 1;
+    while (getline(&line, &cap, fp) != -1) {
+        if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
+        if (progress && rank == 0) {
+            time_t now = time(NULL);
+            fprintf(progress, "%s\t%s", line, asctime(localtime(&now)));
+        }
+        if (skip && strcmp(skip, line) == 0) {
+            if (err && rank == 0) fprintf(err, "skipping %s (identical match)\n", line);
+            idx++;
+            continue;
+        }
+        if (idx++ % world != rank) continue;
+        rc = skh_scan_file(ctx, line, col, bases);
+        if (rc == SK_E_OPEN) {
+            if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", line);
+            break;
+        }
+        if (rc != SK_OK) {
+            if (err) fprintf(err, "kmer_scrub_count: device error while scanning %s: %s (%s)\n", line,
+                             sk_strerror(rc), sk_last_error(ctx));
+            break;
+        }
+    }
+    free(line);
+    fclose(fp);
+    return rc;
+}
+
+/* =========================================================================================
+ * output
+ * ======================================================================================= */
+
+static char *put_i32(char *p, int32_t v)             /* "%d" of an unsigned counter */
+{
+    char tmp[12];
+    int n = 0;
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    if (v < 0) *p++ = '-';
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+int skh_print_counts(sk_ctx *ctx, const skh_keyset *ks, FILE *out, int with_drug_column)
+{
+    const uint32_t ncols = with_drug_column ? 4 : 3, n = ks->nrows;
+    uint32_t *cols[4] = {NULL, NULL, NULL, NULL};
+    uint32_t c, r, w = 0, *worder;
+    char *buf, *p;
+    int rc = SK_OK;
+    const size_t BUF = 1 << 20;
+    if (sk_table_cols(ctx) < ncols || sk_table_rows(ctx) != n) return SK_E_STATE;
+    for (c = 0; c < ncols && rc == SK_OK; c++) {
+        cols[c] = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+        rc = sk_counts_fetch(ctx, c, cols[c]);
+    }
+    /* wide keys in ascending row order (there are few of them) */
+    worder = (uint32_t *)malloc((size_t)(ks->nwide ? ks->nwide : 1) * sizeof(uint32_t));
+    for (c = 0; c < ks->nwide; c++) {
+        uint32_t j = c;
+        while (j > 0 && ks->wide_rows[worder[j - 1]] > ks->wide_rows[c]) { worder[j] = worder[j - 1]; j--; }
+        worder[j] = c;
+    }
+    if (rc == SK_OK) {
+        buf = (char *)malloc(BUF + 256);
+        p = buf;
+        fputs("#kmer\treference_count\tpangenome_count\tmetagenome_count\tdrug_count\n", out);
+        for (r = 0; r < n; r++) {
+            if (ks->packed[r] != SK_KEY_NONE) { decode_key(ks->packed[r], p); p += SK_K; }
+            else {
+                const char *wk = ks->wide_keys + (size_t)worder[w++] * 32;
+                size_t l = strlen(wk);
+                memcpy(p, wk, l);
+                p += l;
+            }
+            for (c = 0; c < ncols; c++) { *p++ = '\t'; p = put_i32(p, (int32_t)cols[c][r]); }
+            *p++ = '\n';
+            if ((size_t)(p - buf) >= BUF) { fwrite(buf, 1, (size_t)(p - buf), out); p = buf; }
+        }
+        fwrite(buf, 1, (size_t)(p - buf), out);
+        free(buf);
+    }
+    for (c = 0; c < 4; c++) free(cols[c]);
+    free(worder);
+    return rc;
+}
+
+/* =========================================================================================
+ * the program
+ * ======================================================================================= */
+
+static void usage(FILE *err)
+{
+    fputs("Usage: kmer_scrub_count -r <reference genome>  -A <file with multiple genome filenames> "
+          "-B <file with multiple metagenome filenames> -C <(optional) file with multiple genome "
+          "filenames of drug strains> -p [progress output file, optional]\n", err);
+}
+
+int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
+{
+    const char *A = NULL, *B = NULL, *C = NULL, *R = NULL, *P = NULL, *env;
+    FILE *progress = NULL;
+    skh_keyset ks;
+    sk_ctx *ctx = NULL;
+    int c, rc, status = 1, device = 0;
+
+    optind = 1;
+    while ((c = getopt(argc, argv, "A:B:C:r:p:Hhud")) != -1) {
+        switch (c) {
+        case 'A': A = optarg; break;
+        case 'B': B = optarg; break;
+        case 'C': C = optarg; break;
+        case 'r': R = optarg; break;
+        case 'p': P = optarg; break;
+        case 'd': break;
+        default:  usage(err); break;                 /* -h/-u/-H/unknown: print and carry on */
+        }
+    }
+    if (!R || !A || !B) { usage(err); return 1; }
+    if (P) {
+        progress = fopen(P, "w");
+        if (!progress) { fprintf(err, "could not open progress file %s\n", P); return 1; }
+        fputs("adding kmer counts for:\n", progress);
+    }
+    if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
+
+    memset(&ks, 0, sizeof ks);
+    rc = skh_keyset_from_file(&ks, R, SK_REF_TABLE_SLOTS, 1, 1);
+    if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", R); goto done; }
+    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s\n", sk_strerror(rc)); goto done; }
+    if (ks.short_records)
+        fprintf(err, "kmer_scrub_count: skipped %llu reference record(s) shorter than %d bases "
+                     "(the original program crashes on these)\n", (unsigned long long)ks.short_records, SK_K - 1);
+
+    rc = sk_ctx_create(&ctx, device);
+    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); goto done; }
+    rc = skh_keyset_load(ctx, &ks, 4);
+    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+
+    if (skh_scan_list(ctx, A, NULL, 1, progress, err, 0, 1, NULL) != SK_OK) goto done;
+    if (skh_scan_list(ctx, B, NULL, 2, progress, err, 0, 1, NULL) != SK_OK) goto done;
+    if (C && skh_scan_list(ctx, C, R, 3, progress, err, 0, 1, NULL) != SK_OK) goto done;
+    rc = skh_print_counts(ctx, &ks, out, C != NULL);
+    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+    status = 0;
+done:
+    if (ctx) sk_ctx_destroy(ctx);
+    skh_keyset_free(&ks);
+    if (progress) fclose(progress);
+    return status;
+}

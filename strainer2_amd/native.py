@@ -1,0 +1,323 @@
+"""ctypes binding of include/strainer_kmer.h (see that header for the contract of each call).
+
+Fails loudly when the native library is absent: there is no fallback implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libstrainer_kmer.so")
+
+
+def cli_path():
+    return os.path.join(_HERE, "bin", "kmer_scrub_count")
+
+
+def _load():
+    p = library_path()
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C strainer2_amd/csrc` (there is no non-native fallback)")
+    return C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+SK_K = 31
+SK_REF_TABLE_SLOTS = 8000000
+SK_KEY_NONE = 0xFFFFFFFFFFFFFFFF
+SK_OK = 0
+SK_E_NODEVICE = -1
+SK_E_OPEN = -5
+
+# every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load",
+    "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_sync", "sk_counts_fetch",
+    "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
+    "sk_counts_allreduce", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
+    "sk_dev_upload", "sk_dev_download",
+    "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
+    "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
+    "skh_kmer_scrub_count_main", "skh_decode_file",
+]
+
+
+class _KeysetStruct(C.Structure):
+    _fields_ = [("nrows", C.c_uint32), ("nwide", C.c_uint32),
+                ("packed", C.POINTER(C.c_uint64)), ("first_count", C.POINTER(C.c_uint32)),
+                ("wide_keys", C.POINTER(C.c_char)), ("wide_rows", C.POINTER(C.c_uint32)),
+                ("final_slots", C.c_uint32), ("short_records", C.c_uint64)]
+
+
+_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
+
+lib.sk_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+lib.sk_ctx_destroy.argtypes = [C.c_void_p]
+lib.sk_ctx_destroy.restype = None
+lib.sk_last_error.argtypes = [C.c_void_p]
+lib.sk_last_error.restype = C.c_char_p
+lib.sk_strerror.argtypes = [C.c_int]
+lib.sk_strerror.restype = C.c_char_p
+lib.sk_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+lib.sk_table_load_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+lib.sk_scan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+lib.sk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+lib.sk_sync.argtypes = [C.c_void_p]
+lib.sk_counts_fetch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+lib.sk_counts_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+lib.sk_counts_zero.argtypes = [C.c_void_p, C.c_uint32]
+lib.sk_counts_device_ptr.argtypes = [C.c_void_p]
+lib.sk_counts_device_ptr.restype = C.c_void_p
+lib.sk_table_rows.argtypes = [C.c_void_p]
+lib.sk_table_rows.restype = C.c_uint32
+lib.sk_table_cols.argtypes = [C.c_void_p]
+lib.sk_table_cols.restype = C.c_uint32
+lib.sk_counts_allreduce.argtypes = [C.c_void_p, C.c_void_p]
+lib.sk_scan_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+lib.sk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+lib.sk_dev_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64]
+lib.sk_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+lib.sk_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+lib.sk_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+lib.skh_keyset_from_file.argtypes = [C.POINTER(_KeysetStruct), C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32]
+lib.skh_keyset_from_stream.argtypes = [C.POINTER(_KeysetStruct), C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]
+lib.skh_keyset_free.argtypes = [C.POINTER(_KeysetStruct)]
+lib.skh_keyset_free.restype = None
+lib.skh_keyset_key.argtypes = [C.POINTER(_KeysetStruct), C.c_uint32, C.c_char_p]
+lib.skh_keyset_key.restype = None
+lib.skh_keyset_load.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_uint32]
+lib.skh_scan_file.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.skh_scan_list.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                              C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.skh_print_counts.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_void_p, C.c_int]
+lib.skh_kmer_scrub_count_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
+lib.skh_decode_file.argtypes = [C.c_char_p, C.c_uint64, _SINK, C.c_void_p, C.POINTER(C.c_uint64)]
+lib.skh_decode_file.restype = C.c_int64
+
+_libc = C.CDLL(None)
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fopen.restype = C.c_void_p
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+class SKError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib.sk_strerror(code).decode()
+        super().__init__(f"libstrainer_kmer error {code}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+class Keyset:
+    """Strain key set in reference output order (host layer: skh_keyset_*)."""
+
+    def __init__(self):
+        self._s = _KeysetStruct()
+        self._live = False
+
+    @classmethod
+    def from_file(cls, path, initial_slots=SK_REF_TABLE_SLOTS, default_val=1, incr=1):
+        ks = cls()
+        rc = lib.skh_keyset_from_file(C.byref(ks._s), os.fsencode(path), initial_slots, default_val, incr)
+        if rc:
+            raise SKError(rc, path)
+        ks._live = True
+        return ks
+
+    @classmethod
+    def from_stream(cls, stream: bytes, initial_slots=SK_REF_TABLE_SLOTS, default_val=1, incr=1):
+        ks = cls()
+        rc = lib.skh_keyset_from_stream(C.byref(ks._s), stream, len(stream), initial_slots, default_val, incr)
+        if rc:
+            raise SKError(rc)
+        ks._live = True
+        return ks
+
+    nrows = property(lambda self: self._s.nrows)
+    nwide = property(lambda self: self._s.nwide)
+    final_slots = property(lambda self: self._s.final_slots)
+    short_records = property(lambda self: self._s.short_records)
+
+    def packed(self):
+        return np.ctypeslib.as_array(self._s.packed, shape=(max(self.nrows, 1),))[: self.nrows].copy()
+
+    def first_count(self):
+        return np.ctypeslib.as_array(self._s.first_count, shape=(max(self.nrows, 1),))[: self.nrows].copy()
+
+    def key(self, row):
+        buf = C.create_string_buffer(32)
+        lib.skh_keyset_key(C.byref(self._s), row, buf)
+        return buf.value
+
+    def keys(self):
+        """All keys as bytes, in row order (vectorised decode of the packed ones)."""
+        pk = self.packed()
+        out = np.empty((self.nrows, SK_K), dtype=np.uint8)
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        for i in range(SK_K):
+            out[:, i] = lut[((pk >> np.uint64(2 * (SK_K - 1 - i))) & np.uint64(3)).astype(np.int64)]
+        keys = [bytes(r) for r in out]
+        for r in np.nonzero(pk == np.uint64(SK_KEY_NONE))[0]:
+            keys[int(r)] = self.key(int(r))
+        return keys
+
+    def close(self):
+        if self._live:
+            lib.skh_keyset_free(C.byref(self._s))
+            self._live = False
+
+    def __del__(self):
+        self.close()
+
+
+class KmerContext:
+    """One device context (device layer: sk_*)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib.sk_ctx_create(C.byref(self._h), device)
+        if rc:
+            self._h = None
+            raise SKError(rc, "sk_ctx_create: this library needs an MI355X-class GPU; there is no CPU path")
+        self._bufs = []
+
+    def _ck(self, rc):
+        if rc:
+            raise SKError(rc, lib.sk_last_error(self._h).decode())
+
+    def set_option(self, name, value):
+        self._ck(lib.sk_set_option(self._h, name.encode(), value))
+
+    def load_keyset(self, ks: Keyset, ncols=4):
+        self._ck(lib.skh_keyset_load(self._h, C.byref(ks._s), ncols))
+
+    def load_table(self, keys: np.ndarray, ncols=4):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        self._ck(lib.sk_table_load(self._h, keys.ctypes.data, len(keys), ncols))
+
+    def scan_stream(self, stream, col):
+        if isinstance(stream, np.ndarray):
+            stream = np.ascontiguousarray(stream, dtype=np.uint8)
+            self._ck(lib.sk_scan_stream(self._h, stream.ctypes.data, stream.size, col))
+        else:
+            self._ck(lib.sk_scan_stream(self._h, stream, len(stream), col))
+
+    def scan_device(self, dev_ptr, nbytes, col):
+        self._ck(lib.sk_scan_device(self._h, dev_ptr, nbytes, col))
+
+    def scan_file(self, path, col):
+        bases = C.c_uint64(0)
+        self._ck(lib.skh_scan_file(self._h, os.fsencode(path), col, C.byref(bases)))
+        return bases.value
+
+    def scan_list(self, list_path, col, skip=None, rank=0, world=1):
+        bases = C.c_uint64(0)
+        self._ck(lib.skh_scan_list(self._h, os.fsencode(list_path), None if skip is None else os.fsencode(skip),
+                                   col, None, None, rank, world, C.byref(bases)))
+        return bases.value
+
+    def sync(self):
+        self._ck(lib.sk_sync(self._h))
+
+    def counts(self, col):
+        out = np.empty(self.nrows, dtype=np.uint32)
+        if self.nrows:
+            self._ck(lib.sk_counts_fetch(self._h, col, out.ctypes.data))
+        return out
+
+    def set_counts(self, col, values):
+        values = np.ascontiguousarray(values, dtype=np.uint32)
+        assert values.size == self.nrows
+        self._ck(lib.sk_counts_set(self._h, col, values.ctypes.data))
+
+    def zero_counts(self, col):
+        self._ck(lib.sk_counts_zero(self._h, col))
+
+    nrows = property(lambda self: lib.sk_table_rows(self._h))
+    ncols = property(lambda self: lib.sk_table_cols(self._h))
+
+    def counts_device_ptr(self):
+        return lib.sk_counts_device_ptr(self._h)
+
+    def scan_timing(self, reset=False):
+        ms = C.c_double(0)
+        n = C.c_uint64(0)
+        self._ck(lib.sk_scan_timing(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._ck(lib.sk_dev_alloc(self._h, C.byref(p), nbytes))
+        self._bufs.append(p.value)
+        return p.value
+
+    def dev_free(self, ptr):
+        self._ck(lib.sk_dev_free(self._h, ptr))
+        self._bufs.remove(ptr)
+
+    def dev_upload(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._ck(lib.sk_dev_upload(self._h, ptr, arr.ctypes.data, arr.nbytes))
+
+    def dev_download(self, ptr, nbytes):
+        out = np.empty(nbytes, dtype=np.uint8)
+        self._ck(lib.sk_dev_download(self._h, out.ctypes.data, ptr, nbytes))
+        return out
+
+    def print_counts(self, ks: Keyset, path, with_drug_column=False):
+        fp = _libc.fopen(os.fsencode(path), b"w")
+        try:
+            self._ck(lib.skh_print_counts(self._h, C.byref(ks._s), fp, int(with_drug_column)))
+        finally:
+            _libc.fclose(fp)
+
+    def close(self):
+        if self._h:
+            for p in list(self._bufs):
+                lib.sk_dev_free(self._h, p)
+            self._bufs = []
+            lib.sk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def decode_file(path, chunk_bytes=1 << 26):
+    """Host reader only (no GPU): the record stream the scan would be fed, as a list of chunks."""
+    chunks = []
+
+    def sink(_user, ptr, n):
+        chunks.append(C.string_at(ptr, n))
+        return 0
+
+    bases = C.c_uint64(0)
+    nrec = lib.skh_decode_file(os.fsencode(path), chunk_bytes, _SINK(sink), None, C.byref(bases))
+    if nrec < 0:
+        raise SKError(int(nrec), path)
+    return chunks, int(nrec), bases.value
+
+
+def run_cli_inprocess(argv, stdout_path, stderr_path):
+    """Call the program's main() in this process (the bin/ program is the same function)."""
+    args = [b"kmer_scrub_count"] + [os.fsencode(a) for a in argv]
+    arr = (C.c_char_p * (len(args) + 1))(*args, None)
+    fo = _libc.fopen(os.fsencode(stdout_path), b"w")
+    fe = _libc.fopen(os.fsencode(stderr_path), b"w")
+    try:
+        return lib.skh_kmer_scrub_count_main(len(args), arr, fo, fe)
+    finally:
+        _libc.fclose(fo)
+        _libc.fclose(fe)
