@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- the k-mer scrub/count hot path on N MI355X, one process per GPU.
+
+Metric (BASELINE.json): metagenome bases/sec scanned at k=31, bit-exact k-mer counts.
+Workload at every N (weak scaling): BASELINE configs[1] per GPU -- one 5 Mbp synthetic strain
+(-r) resident as the key table, 10 M x 150 bp synthetic reads (-B; 1.5 Gbase, SURVEY 8(d)
+recipe, seed 0x5EED31 + rank) resident in HBM as a record stream.  A "step" = one pass of the
+scan over that batch (sk_scan_device -> sk_scan_main [+ sk_scan_wide early-exit]).  After the
+K timed steps the per-k-mer count vectors are summed across ranks with one RCCL all-reduce
+(inside the timed region when N > 1).  value = bases all ranks scanned / max-over-ranks time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ALG_BYTES_PER_BASE = 7.4          # 1 B base + 8 B key probe x 0.8 windows/base (p_hit -> 0)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+_ORACLE_TABLE = None
+
+
+def _cpu_worker(args):
+    shard, col = args
+    t0 = time.perf_counter()
+    _ORACLE_TABLE.scan_stream(shard, col)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(sstream, reads, read_len, target_seconds=12.0):
+    """The oracle ("port": same string-keyed work per window as the reference) timed on this host's
+    cores on a bounded sample of the same reads.  P forked workers share one built table."""
+    global _ORACLE_TABLE
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import _oracle
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    t = _oracle.OracleTable()
+    tb = time.perf_counter()
+    assert t.build_stream(sstream) == 0
+    build_s = time.perf_counter() - tb
+    _ORACLE_TABLE = t
+    rec = read_len + 1
+    # calibrate on 20 k reads, then size the sample for ~target_seconds per core
+    cal = reads[: 20_000 * rec].tobytes()
+    t0 = time.perf_counter()
+    t.scan_stream(cal, 3)
+    rate1 = 20_000 * read_len / (time.perf_counter() - t0)
+    per_core_reads = int(min(max(rate1 * target_seconds / read_len, 20_000), (reads.size // rec) // cores))
+    shards = [(reads[i * per_core_reads * rec:(i + 1) * per_core_reads * rec].tobytes(), 3) for i in range(cores)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, shards)
+    wall = time.perf_counter() - t0
+    bases = cores * per_core_reads * read_len
+    _ORACLE_TABLE = None
+    t.close()
+    return {"value": bases / wall, "unit": "bases/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} forked workers x {per_core_reads} reads of the same synthetic stream "
+                      f"({bases / 1e6:.0f} Mbase, {wall:.1f} s wall); 1-core rate {rate1 / 1e6:.2f} Mbase/s; "
+                      f"oracle string-table build {build_s:.1f} s (not counted)"}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (cfg 2: 10 M)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--bloom-bits-log2", type=int, default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    from strainer2_amd import synth
+    contigs = synth.make_strain()
+    sstream = synth.strain_stream(contigs)
+    reads, nbases = synth.make_reads(contigs, args.reads, args.read_len, seed=synth.SEED + 1 + rank)
+
+    # CPU baseline first: it forks, and must do so before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(sstream, reads, args.read_len)
+
+    import torch
+    import torch.distributed as dist
+    import strainer2_amd as sk
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    ks = sk.Keyset.from_stream(sstream)
+    ctx = sk.KmerContext(local_rank)
+    if args.bloom_bits_log2 is not None:
+        ctx.set_option("bloom_bits_log2", args.bloom_bits_log2)
+    ctx.load_keyset(ks, 4)
+    dev = ctx.dev_alloc(reads.size)
+    ctx.dev_upload(dev, reads)
+    nbytes = int(reads.size)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from strainer2_amd.dist import allreduce_counts
+
+    for _ in range(args.warmup):
+        ctx.scan_device(dev, nbytes, 2)
+    if world > 1:
+        allreduce_counts(ctx)               # warm the communicator up
+    ctx.zero_counts(2)
+    barrier()
+    ctx.scan_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.scan_device(dev, nbytes, 2)
+    if world > 1:
+        allreduce_counts(ctx)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = ctx.scan_timing(reset=True)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # bit-exactness inside the same run: K passes over one batch => counts == K x one pass (and,
+    # for N > 1 after the all-reduce, the sum over ranks); one pass is checked against the oracle
+    # in tests/ and smoke().  Here: every count is a multiple of K and the total is sane.
+    counts = ctx.counts(2)
+    assert int(counts.sum()) % args.steps == 0 and np.all(counts % args.steps == 0), "counts not K x one pass"
+    hits_per_pass = int(counts.sum()) // args.steps
+
+    if rank == 0:
+        total_bases = nbases * args.steps * world
+        value = total_bases / elapsed
+        avg_ms = kern_ms / max(launches, 1)
+        achieved = ALG_BYTES_PER_BASE * nbases / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("reads") == args.reads and tj.get("kernel") == "sk_scan_main":
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "metagenome bases/sec scanned at k=31", "value": value, "unit": "bases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: 5 Mbp synthetic strain (-r) vs %d x %d bp synthetic reads (-B) per GPU, k=31, "
+                                   "reads resident in HBM as a record stream" % (args.reads, args.read_len),
+                       "strain_keys": int(ks.nrows), "reads_per_gpu": args.reads, "read_len": args.read_len,
+                       "bases_per_step_per_gpu": nbases, "hits_per_pass_rank0_or_sum": hits_per_pass,
+                       "sharding": "reads sharded by rank, table replicated, one RCCL all-reduce of counts" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "sk_scan_main", "avg_launch_ms": avg_ms, "launches": int(launches),
+                         "alg_bytes_per_base": ALG_BYTES_PER_BASE},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""Multi-GPU plumbing: one process per GPU, table replicated, inputs sharded, and ONE sum
+all-reduce of the per-k-mer count block at the end (RCCL over xGMI via torch.distributed;
+gloo on CPU for tests).  New relative to the reference, which is single-process.
+"""
+import numpy as np
+
+
+class _DevBlock:
+    """Expose a raw HIP device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def shard_of(index: int, rank: int, world: int) -> bool:
+    """List line `index` belongs to `rank` (round-robin; same rule as skh_scan_list)."""
+    return index % world == rank
+
+
+def allreduce_counts(ctx):
+    """In-place sum of ctx's whole counter block over the default process group.
+    u32 wrap-around == i32 two's-complement sum, so the block is reduced as int32."""
+    import torch
+    import torch.distributed as dist
+    ctx.sync()
+    n = ctx.nrows * ctx.ncols
+    t = torch.as_tensor(_DevBlock(ctx.counts_device_ptr(), n), device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+
+
+def allreduce_count_array(counts: np.ndarray):
+    """Host-array variant (gloo): used by the CPU tests of the sharding identity."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(counts.view(np.int32).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy().view(np.uint32)

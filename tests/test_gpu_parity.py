@@ -1,0 +1,191 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle and the
+golden vectors.  Bit-exact (integer work): every comparison is equality."""
+import hashlib
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle
+import _synth
+import strainer2_amd as sk
+from strainer2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["mixed", "drug", "iupac_strain", "truncated_fastq", "missing_in_list", "missing_flag", "contig30"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sk.KmerContext(0)
+    yield c
+    c.close()
+
+
+def _golden_case(golden, name):
+    d = os.path.join(golden, "cases", name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    return d, meta, open(os.path.join(d, "expected.stdout"), "rb").read(), open(os.path.join(d, "expected.stderr"), "rb").read()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_program_matches_reference_golden(golden, name, tmp_path):
+    """bin/kmer_scrub_count vs the bytes the unmodified reference printed (stdout, stderr, status, progress)."""
+    d, meta, out, err = _golden_case(golden, name)
+    argv = list(meta["argv"])
+    if "-p" in argv:
+        argv[argv.index("-p") + 1] = str(tmp_path / "progress")
+    p = subprocess.run([sk.cli_path()] + argv, cwd=d, capture_output=True)
+    assert p.returncode == meta["returncode"]
+    assert p.stdout == out
+    assert p.stderr == err
+    if meta["progress_col1"] is not None:
+        with open(tmp_path / "progress") as f:
+            assert [ln.split("\t")[0].rstrip("\n") for ln in f] == meta["progress_col1"]
+
+
+def test_program_short_contig_divergence(golden):
+    """The reference crashes (SIGSEGV) on a strain record shorter than k-1; we skip it, say so on
+    stderr, and otherwise produce what the oracle produces with the record skipped."""
+    d, meta, _out, _err = _golden_case(golden, "short_contig")
+    assert meta["returncode"] == -11
+    p = subprocess.run([sk.cli_path()] + meta["argv"], cwd=d, capture_output=True)
+    assert p.returncode == 0
+    assert b"skipped 1 reference record(s) shorter than 30 bases" in p.stderr
+    t = _oracle.OracleTable()
+    assert t.build_file(os.path.join(d, "strain.fa"), short_policy=1) == 0
+    t.scan_file(os.path.join(d, "strain.fa"), 1)
+    t.scan_file(os.path.join(d, "strain.fa"), 2)
+    keys, counts = t.rows()
+    want = b"#kmer\treference_count\tpangenome_count\tmetagenome_count\tdrug_count\n" + b"".join(
+        k + b"\t%d\t%d\t%d\n" % tuple(int(x) for x in c[:3]) for k, c in zip(keys, counts))
+    assert p.stdout == want
+
+
+def test_program_bundled_example_md5(golden, tmp_path):
+    """cfg 1 through the GPU path: reference test/example.sh step 1, md5 of the 254 MB TSV."""
+    b = os.path.join(golden, "bundled")
+    facts = json.load(open(os.path.join(b, "step1_facts.json")))
+    out = tmp_path / "step1.tsv"
+    with open(out, "wb") as f:
+        p = subprocess.run([sk.cli_path()] + facts["argv"] + ["-p", str(tmp_path / "prog")], cwd=b, stdout=f,
+                           stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stderr == b""
+    h = hashlib.md5()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert os.path.getsize(out) == facts["stdout_bytes"]
+    assert h.hexdigest() == facts["stdout_md5"] == "75989a9bc31ef0b6f53a5112a60920bd"
+
+
+@pytest.mark.parametrize("seed,junk", [(1, 0.0), (2, 0.01), (3, 0.05)])
+def test_scan_stream_fuzz_vs_oracle(ctx, seed, junk):
+    """Random streams with junk bytes / case / N / U / IUPAC, strain with IUPAC letters too."""
+    rng = random.Random(seed)
+    strain = bytearray(_synth.rand_dna(rng, 6000))
+    if junk:
+        for ch in b"RYKMSWU":
+            strain[rng.randrange(len(strain))] = ch
+    sstream = bytes(strain[:3000]) + b"\n" + bytes(strain[3000:]).lower() + b"\n"
+    ks = sk.Keyset.from_stream(sstream)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    ctx.load_keyset(ks, 4)
+    for col in (1, 2, 3):
+        data = _synth.fuzz_stream(rng, bytes(strain), 400, p_junk=junk, min_len=0, max_len=260)
+        ctx.scan_stream(data, col)
+        t.scan_stream(data, col)
+    okeys, ocounts = t.rows()
+    assert ks.keys() == okeys
+    for col in range(4):
+        assert np.array_equal(ctx.counts(col), ocounts[:, col]), col
+    assert ocounts[:, 1:].sum() > 1000          # the test is not vacuous
+
+
+def test_scan_device_equals_scan_stream_and_tile_edges(ctx):
+    """Device-resident entry point; stream lengths around tile (32768) and chunk (16) edges."""
+    rng = random.Random(7)
+    strain = _synth.rand_dna(rng, 50000)
+    ks = sk.Keyset.from_stream(strain + b"\n")
+    ctx.load_keyset(ks, 4)
+    t = _oracle.OracleTable()
+    t.build_stream(strain + b"\n")
+    base = (strain * 3)[:140000]
+    for n in (0, 1, 30, 31, 32, 47, 32767, 32768, 32769, 32768 + 31, 65536 + 15, 98304, 140000):
+        data = base[:n]
+        ctx.zero_counts(1)
+        ctx.zero_counts(2)
+        ctx.scan_stream(data, 1)
+        buf = ctx.dev_alloc(max(n, 16))
+        if n:
+            ctx.dev_upload(buf, np.frombuffer(data, dtype=np.uint8))
+        ctx.scan_device(buf, n, 2)
+        ctx.sync()
+        ctx.dev_free(buf)
+        t2 = _oracle.OracleTable()
+        t2.build_stream(strain + b"\n")
+        t2.scan_stream(data, 1)
+        want = t2.rows()[1][:, 1]
+        assert np.array_equal(ctx.counts(1), want), n
+        assert np.array_equal(ctx.counts(2), want), n
+
+
+def test_file_scan_and_list_sharding_identity(ctx, golden, tmp_path):
+    """Counts are additive: scanning a list as 2 shards (rank/world) sums to the unsharded scan."""
+    d = os.path.join(golden, "cases", "mixed")
+    ks = sk.Keyset.from_file(os.path.join(d, "strain.fna.gz"))
+    ctx.load_keyset(ks, 4)
+    lst = tmp_path / "L.txt"
+    lst.write_text("\n".join(os.path.join(d, f) for f in ["m1.fasta", "m2.fq.gz", "m3_crlf.fa", "g1.fa", "g2.fa.gz"]) + "\n")
+    ctx.scan_list(str(lst), 1)
+    ctx.scan_list(str(lst), 2, rank=0, world=2)
+    ctx.scan_list(str(lst), 3, rank=1, world=2)
+    whole, a, b = ctx.counts(1), ctx.counts(2), ctx.counts(3)
+    assert whole.sum() > 0 and a.sum() > 0 and b.sum() > 0
+    assert np.array_equal(whole, a + b)
+
+
+def test_full_size_properties_cfg2(ctx):
+    """BASELINE cfg 2 scale (5 Mbp strain; here 1 M reads of it to bound host memory/time) through
+    size-independent properties: oracle equality on a sample, linearity, strand symmetry, shard sums."""
+    contigs = synth.make_strain()
+    sstream = synth.strain_stream(contigs)
+    ks = sk.Keyset.from_stream(sstream)
+    assert 4_990_000 < ks.nrows <= 5_000_000
+    ctx.load_keyset(ks, 4)
+    reads, nbases = synth.make_reads(contigs, 1_000_000)
+    assert nbases == 150_000_000
+    ctx.scan_stream(reads, 1)
+    c1 = ctx.counts(1)
+    # (a) oracle on the first 20 k reads
+    sample = reads[: 20_000 * 151].tobytes()
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    t.scan_stream(sample, 1)
+    okeys, ocounts = t.rows()
+    ctx.scan_stream(sample, 2)
+    assert np.array_equal(ctx.counts(2), ocounts[:, 1])
+    assert np.array_equal(ks.first_count(), ocounts[:, 0])
+    # (b) linearity: scanning the stream again doubles every count
+    ctx.scan_stream(reads, 1)
+    assert np.array_equal(ctx.counts(1), 2 * c1)
+    # (c) strand symmetry: reverse-complemented reads give the same table
+    rc = reads.reshape(-1, 151).copy()
+    rc[:, :150] = synth._COMP[rc[:, :150]][:, ::-1]
+    ctx.zero_counts(3)
+    ctx.scan_stream(rc.reshape(-1), 3)
+    assert np.array_equal(ctx.counts(3), c1)
+    # (d) shard sums: two halves add up
+    ctx.zero_counts(2)
+    ctx.zero_counts(3)
+    half = 500_000 * 151
+    ctx.scan_stream(reads[:half], 2)
+    ctx.scan_stream(reads[half:], 3)
+    assert np.array_equal(ctx.counts(2) + ctx.counts(3), c1)
+    # (e) planted hits are found: ~2 % of reads x up to 120 windows
+    assert 1_500_000 < int(c1.sum()) < 2_600_000
