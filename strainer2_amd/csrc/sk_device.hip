@@ -50,7 +50,19 @@ struct sk_table_view {
     const uint64_t *keys;
     const uint32_t *rowid;
     uint32_t        mask;
+    // L2-resident prefilter: split-block Bloom, 64-bit blocks, 2 bits in each 32-bit half
+    const uint2    *bloom;
+    uint32_t        bloom_mask;      // number of 64-bit blocks - 1
 };
+
+// bit masks of a key inside its Bloom block (low / high word), from the slot hash
+__device__ __forceinline__ uint2 sk_bloom_bits(uint32_t h1)
+{
+    uint2 m;
+    m.x = (1u << (h1 & 31u)) | (1u << ((h1 >> 5) & 31u));
+    m.y = (1u << ((h1 >> 10) & 31u)) | (1u << ((h1 >> 15) & 31u));
+    return m;
+}
 
 __device__ __forceinline__ void sk_resolve(uint64_t canon, uint32_t slot, uint64_t key,
                                            const sk_table_view &t, uint32_t *counts)
@@ -79,6 +91,7 @@ __device__ __forceinline__ void sk_step(sk_roll &s, uint32_t b)
     s.soft = sk_is_hard_break(b) ? 0u : s.soft + 1u;
 }
 
+template <bool BLOOM>
 __global__ __launch_bounds__(SK_THREADS)
 void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, uint32_t *__restrict__ counts, uint32_t *__restrict__ flags)
@@ -131,7 +144,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint64_t canon[4];
-            uint32_t slot[4];
+            uint32_t h1[4];
             bool     live[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -141,14 +154,29 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 canon[i] = s.fwd > s.rc ? s.fwd : s.rc;
                 live[i] = in_range & (s.run >= (uint32_t)SK_K);
                 wide_seen |= (uint32_t)(in_range & (s.run < (uint32_t)SK_K) & (s.soft >= (uint32_t)SK_K));
-                slot[i] = sk_hash62(canon[i]) & table.mask;
+                h1[i] = sk_hash62(canon[i]);
             }
+            if (BLOOM) {
+                // stage 1: one 8-byte load from the L2-resident filter per window
+                uint2 blk[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    blk[i] = make_uint2(0u, 0u);
+                    if (live[i]) blk[i] = table.bloom[sk_hash62b(canon[i]) & table.bloom_mask];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint2 m = sk_bloom_bits(h1[i]);
+                    live[i] = ((blk[i].x & m.x) == m.x) & ((blk[i].y & m.y) == m.y);   // blk == 0 when !live
+                }
+            }
+            // stage 2: the table itself (HBM / Infinity Cache), only for windows that passed
             uint64_t key[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) key[i] = live[i] ? table.keys[slot[i]] : SK_EMPTY64;
+            for (int i = 0; i < 4; i++) key[i] = live[i] ? table.keys[h1[i] & table.mask] : SK_EMPTY64;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (key[i] != SK_EMPTY64) sk_resolve(canon[i], slot[i], key[i], table, counts);
+                if (key[i] != SK_EMPTY64) sk_resolve(canon[i], h1[i] & table.mask, key[i], table, counts);
         }
     }
     if (wide_seen) atomicAdd(&flags[0], 1u);
@@ -252,6 +280,18 @@ __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, uin
     }
 }
 
+__global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *bloom_words, uint32_t bloom_mask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = in[i];
+    if (k == SK_EMPTY64) return;
+    const uint2 m = sk_bloom_bits(sk_hash62(k));
+    const uint32_t b = sk_hash62b(k) & bloom_mask;
+    atomicOr(&bloom_words[2u * b], m.x);
+    atomicOr(&bloom_words[2u * b + 1u], m.y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
@@ -265,6 +305,8 @@ struct sk_ctx {
     uint64_t    *d_keys;
     uint32_t    *d_rowid;
     uint32_t     slots_log2;
+    uint2       *d_bloom;
+    uint32_t     bloom_blocks_log2;       // 0 = no prefilter
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
     // wide keys
@@ -338,7 +380,7 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     if (!c) return SK_E_NOMEM;
     c->device = device;
     c->table_load_pct = 50;
-    c->bloom_bits_log2 = 0;
+    c->bloom_bits_log2 = -1;          // -1 = automatic (sized for the L2), 0 = off
     c->err[0] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SK_E_NODEVICE; }
     if (hipMalloc((void **)&c->d_flags, 16 * sizeof(uint32_t)) != hipSuccess) { delete c; return SK_E_NOMEM; }
@@ -354,6 +396,7 @@ static void sk_table_release(sk_ctx *c)
 {
     hipFree(c->d_keys); c->d_keys = NULL;
     hipFree(c->d_rowid); c->d_rowid = NULL;
+    hipFree(c->d_bloom); c->d_bloom = NULL;
     hipFree(c->d_counts); c->d_counts = NULL;
     hipFree(c->d_wide_keys); c->d_wide_keys = NULL;
     hipFree(c->d_wide_rows); c->d_wide_rows = NULL;
@@ -382,7 +425,7 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
 {
     if (!c || !name) return SK_E_ARG;
     if (!strcmp(name, "table_load_pct")) { if (value < 5 || value > 90) return SK_E_ARG; c->table_load_pct = value; return SK_OK; }
-    if (!strcmp(name, "bloom_bits_log2")) { if (value < 0 || value > 34) return SK_E_ARG; c->bloom_bits_log2 = value; return SK_OK; }
+    if (!strcmp(name, "bloom_bits_log2")) { if (value < -1 || value > 34 || (value > 0 && value < 10)) return SK_E_ARG; c->bloom_bits_log2 = value; return SK_OK; }
     return sk_fail(c, SK_E_ARG, "unknown option %s", name);
 }
 
@@ -411,6 +454,19 @@ extern "C" int sk_table_load(sk_ctx *c, const uint64_t *keys, uint32_t nrows, ui
         SK_HIP(c, hipMemcpyAsync(d_in, keys, (size_t)nrows * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(sk_table_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
                            d_in, nrows, c->d_keys, c->d_rowid, (uint32_t)(slots - 1), c->d_flags);
+        // prefilter: automatic size = 2^25 bits (4 MiB, one XCD L2) unless the key set is tiny
+        long bb = c->bloom_bits_log2;
+        if (bb < 0) { bb = 25; while (bb > 12 && ((uint64_t)1 << bb) > (uint64_t)nrows * 64ull) bb--; }
+        c->bloom_blocks_log2 = 0;
+        if (bb > 0) {
+            const uint32_t blocks_log2 = (uint32_t)bb - 6u;
+            const size_t bbytes = ((size_t)1 << blocks_log2) * sizeof(uint2);
+            SK_HIP(c, hipMalloc((void **)&c->d_bloom, bbytes));
+            SK_HIP(c, hipMemsetAsync(c->d_bloom, 0, bbytes, c->stream));
+            hipLaunchKernelGGL(sk_bloom_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
+                               d_in, nrows, (uint32_t *)c->d_bloom, (uint32_t)(((uint64_t)1 << blocks_log2) - 1));
+            c->bloom_blocks_log2 = blocks_log2;
+        }
         uint32_t flags[2] = {0, 0};
         SK_HIP(c, hipMemcpyAsync(flags, c->d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
         SK_HIP(c, hipStreamSynchronize(c->stream));
@@ -459,6 +515,8 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     if (ntiles > 0x7FFFFFFFull) return sk_fail(c, SK_E_ARG, "batch too large");
     sk_table_view tv;
     tv.keys = c->d_keys; tv.rowid = c->d_rowid; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
+    tv.bloom = c->d_bloom;
+    tv.bloom_mask = c->bloom_blocks_log2 ? (uint32_t)(((uint64_t)1 << c->bloom_blocks_log2) - 1) : 0u;
     sk_wide_view wv;
     wv.keys31 = c->d_wide_keys; wv.rows = c->d_wide_rows; wv.index = c->d_wide_index;
     wv.wmask = c->wide_mask; wv.nwide = c->nwide;
@@ -472,8 +530,12 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         SK_HIP(c, hipEventCreate(&e1));
         SK_HIP(c, hipEventRecord(e0, c->stream));
     }
-    hipLaunchKernelGGL(sk_scan_main, dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
-                       d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
+    if (c->bloom_blocks_log2)
+        hipLaunchKernelGGL(sk_scan_main<true>, dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
+    else
+        hipLaunchKernelGGL(sk_scan_main<false>, dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
     if (timed) {
         SK_HIP(c, hipEventRecord(e1, c->stream));
         c->ev.push_back(e0);
