@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--bloom-bits-log2", type=int, default=None)
+    ap.add_argument("--stats", action="store_true", help="debug counters (slower kernel variant)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,6 +115,8 @@ def main():
     ctx = sk.KmerContext(local_rank)
     if args.bloom_bits_log2 is not None:
         ctx.set_option("bloom_bits_log2", args.bloom_bits_log2)
+    if args.stats:
+        ctx.set_option("stats", 1)
     ctx.load_keyset(ks, 4)
     dev = ctx.dev_alloc(reads.size)
     ctx.dev_upload(dev, reads)
@@ -156,6 +159,10 @@ def main():
     assert int(counts.sum()) % args.steps == 0 and np.all(counts % args.steps == 0), "counts not K x one pass"
     hits_per_pass = int(counts.sum()) // args.steps
 
+    if args.stats and rank == 0:
+        st = ctx.scan_stats()
+        n = args.steps + args.warmup
+        print("stats per pass:", {k: v / n for k, v in st.items()}, file=sys.stderr)
     if rank == 0:
         total_bases = nbases * args.steps * world
         value = total_bases / elapsed

@@ -112,9 +112,14 @@ int sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);
  * around every scan kernel since the last reset: total milliseconds and launch count. */
 int sk_scan_timing(sk_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
 
-/* Tunables (before sk_table_load).  name: "bloom_bits_log2" (0 = no prefilter),
- * "table_load_pct" (max load factor in percent). Unknown name -> SK_E_ARG. */
+/* Tunables (before sk_table_load).  name: "bloom_bits_log2" (size of the prefilter in bits,
+ * log2; -1 = automatic, 0 = no prefilter), "table_load_pct" (max load factor in percent),
+ * "stats" (1 = count windows / prefilter loads / table probes, see sk_scan_stats).
+ * Unknown name -> SK_E_ARG. */
 int sk_set_option(sk_ctx *ctx, const char *name, long value);
+/* Debug counters of the scan kernel since the last table load (needs option "stats"=1):
+ * out[0] windows looked up, out[1] prefilter block loads, out[2] table probes. */
+int sk_scan_stats(sk_ctx *ctx, uint64_t out[3]);
 
 /* Device buffer helpers so that FFI callers need no HIP binding of their own. */
 int sk_dev_alloc(sk_ctx *ctx, void **dev, uint64_t nbytes);

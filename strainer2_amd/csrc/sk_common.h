@@ -52,6 +52,58 @@ SK_HD uint32_t sk_hash62(uint64_t key)
     return h;
 }
 
+/* ---- minimizer-keyed placement (device table + prefilter) --------------------------------
+ * Every 31-mer window contains w = 16 overlapping 16-mers (m = 16, 32 bits packed).  Its
+ * "minimizer hash" mz is the minimum over those of sk_mhash(canonical 16-mer), canonical =
+ * min(16-mer, its reverse complement): orientation-independent, so a window and the strain
+ * key it equals get the same mz.  Consecutive windows mostly share their minimizer, so
+ * everything placed by mz (the prefilter block, the table line) is re-used ~w/2 times in a
+ * row by the scanning lane.  sk_khash is a cheap per-k-mer hash for bits inside those. */
+SK_HD uint32_t sk_mhash(uint32_t c16)
+{
+    uint32_t h = c16 * 0x9E3779B1u;
+    return h ^ (h >> 16);
+}
+
+SK_HD uint32_t sk_khash(uint64_t key)
+{
+    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t x = lo ^ (hi * 0x85EBCA77u);
+    x ^= x >> 15;
+    return x * 0x9E3779B1u;                 /* use the HIGH bits */
+}
+
+/* reverse complement of a packed 31-mer */
+SK_HD uint64_t sk_revcomp62(uint64_t key)
+{
+    uint64_t r = 0;
+    for (int i = 0; i < 31; i++) { r = (r << 2) | (3u - (key & 3u)); key >>= 2; }
+    return r;
+}
+
+/* minimizer hash of a packed 31-mer (build side; the scan kernel rolls it) */
+SK_HD uint32_t sk_minimizer62(uint64_t key)
+{
+    const uint64_t rc = sk_revcomp62(key);
+    uint32_t mz = 0xFFFFFFFFu;
+    for (int i = 0; i < 16; i++) {
+        const uint32_t f = (uint32_t)(key >> (2 * (15 - i)));
+        const uint32_t r = (uint32_t)(rc >> (2 * i));
+        const uint32_t h = sk_mhash(f < r ? f : r);
+        mz = h < mz ? h : mz;
+    }
+    return mz;
+}
+
+/* first table slot of a key: uniform over the table (bits 8..31 of the k-mer hash); linear
+ * probing from there.  (Placing table lines by minimizer was tried and rejected: keys arrive in
+ * clumps of ~8 per minimizer and linear-probe runs get long: 3.7x slower end to end.) */
+SK_HD uint32_t sk_slot0(uint32_t mz, uint32_t kh, uint32_t mask)
+{
+    (void)mz;
+    return (kh >> 8) & mask;
+}
+
 /* second, independent hash for the prefilter */
 SK_HD uint32_t sk_hash62b(uint64_t key)
 {

@@ -50,30 +50,30 @@ struct sk_table_view {
     const uint64_t *keys;
     const uint32_t *rowid;
     uint32_t        mask;
-    // L2-resident prefilter: split-block Bloom, 64-bit blocks, 2 bits in each 32-bit half
-    const uint2    *bloom;
-    uint32_t        bloom_mask;      // number of 64-bit blocks - 1
+    // L2-resident prefilter: 128-bit blocks chosen by the window's minimizer hash; a key sets
+    // one bit in each of the block's four 32-bit words (positions from sk_khash)
+    const sk_u4    *bloom;
+    uint32_t        bloom_mask;      // number of 128-bit blocks - 1
 };
 
-// bit masks of a key inside its Bloom block (low / high word), from the slot hash
-__device__ __forceinline__ uint2 sk_bloom_bits(uint32_t h1)
-{
-    uint2 m;
-    m.x = (1u << (h1 & 31u)) | (1u << ((h1 >> 5) & 31u));
-    m.y = (1u << ((h1 >> 10) & 31u)) | (1u << ((h1 >> 15) & 31u));
-    return m;
-}
-
+// follow the probe sequence of `canon` from `slot` (first key already loaded)
 __device__ __forceinline__ void sk_resolve(uint64_t canon, uint32_t slot, uint64_t key,
                                            const sk_table_view &t, uint32_t *counts)
 {
-    // first probe already loaded; follow the cluster only while slots are occupied
     for (;;) {
         if (key == canon) { atomicAdd(&counts[t.rowid[slot]], 1u); return; }
         if (key == SK_EMPTY64) return;
         slot = (slot + 1u) & t.mask;
         key = t.keys[slot];
     }
+}
+
+__device__ __forceinline__ bool sk_bloom_test(const sk_u4 blk, uint32_t kh)
+{
+    // bit (kh>>27) of word 0, (kh>>22)&31 of word 1, (kh>>17)&31 of word 2, (kh>>12)&31 of word 3
+    const uint32_t t = (blk.x >> (kh >> 27)) & (blk.y >> ((kh >> 22) & 31u)) &
+                       (blk.z >> ((kh >> 17) & 31u)) & (blk.w >> ((kh >> 12) & 31u));
+    return (t & 1u) != 0u;
 }
 
 struct sk_roll {
@@ -91,7 +91,24 @@ __device__ __forceinline__ void sk_step(sk_roll &s, uint32_t b)
     s.soft = sk_is_hard_break(b) ? 0u : s.soft + 1u;
 }
 
-template <bool BLOOM>
+// hash of the canonical 16-mer that ends at the current base
+__device__ __forceinline__ uint32_t sk_mmer_hash(const sk_roll &s)
+{
+    const uint32_t f16 = (uint32_t)s.fwd;
+    const uint32_t r16 = (uint32_t)(s.rc >> 30);
+    return sk_mhash(f16 < r16 ? f16 : r16);
+}
+
+// THE hot kernel.  One thread owns SK_SPAN consecutive window-end positions and rolls over
+// them in 16-base chunks held in registers (bytes staged through LDS, coalesced 16 B loads):
+//   roll      fwd/rc 2-bit packing, ACGT run length                      (registers)
+//   minimizer sliding minimum of the 16-mer hashes over the window        (registers;
+//             block-decomposed: prefix minima of this chunk + suffix minima of the last)
+//   stage 1   prefilter block chosen by the minimizer; re-loaded from L2 only when the
+//             minimizer changes (about once per 8 windows), else kept in registers
+//   stage 2   table line chosen by the minimizer, slot by the k-mer hash (HBM/Infinity Cache),
+//             only for windows that pass stage 1; full 62-bit compare; atomicAdd on a hit
+template <bool BLOOM, bool STATS>
 __global__ __launch_bounds__(SK_THREADS)
 void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, uint32_t *__restrict__ counts, uint32_t *__restrict__ flags)
@@ -121,65 +138,108 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     }
     __syncthreads();
 
-    // ---- each thread rolls over its span: 2 warm-up chunks + SPAN_CH emitting chunks ---------
     sk_roll s;
     s.fwd = 0; s.rc = 0; s.run = 0; s.soft = 0;
     uint32_t wide_seen = 0;
+    uint32_t n_live = 0, n_load = 0, n_probe = 0;             // STATS only
     const uint32_t chunk0 = tid * SK_SPAN_CH;
     const uint64_t pos0 = tile0 + (uint64_t)tid * SK_SPAN;       // window-end position of span byte 0
 
+    uint32_t S[17];                     // suffix minima of the previous chunk's 16-mer hashes
+#pragma unroll
+    for (int i = 0; i < 17; i++) S[i] = 0xFFFFFFFFu;
+    sk_u4    blk = (sk_u4){0u, 0u, 0u, 0u};
+    uint32_t blk_id = 0xFFFFFFFFu;      // which prefilter block `blk` holds
+
+    // ---- warm-up chunk 0: rolling state only ---------------------------------------------
+    {
+        const sk_u4 v = lds[sk_lds_slot(chunk0)];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int o = 0; o < 16; o++) sk_step(s, (w[o >> 2] >> (8 * (o & 3))) & 0xFFu);
+    }
+
 #pragma unroll 1
-    for (uint32_t j = 0; j < SK_SPAN_CH + 2; j++) {
+    for (uint32_t j = 1; j < SK_SPAN_CH + 2; j++) {
         const sk_u4 v = lds[sk_lds_slot(chunk0 + j)];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        if (j < 2) {                                            // warm-up: state only
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) sk_step(s, (w[q] >> (8 * i)) & 0xFFu);
-            }
-            continue;
-        }
+        uint32_t H[16];
+        const bool emit_chunk = j >= 2;                        // chunk 1 only warms the minima up
         const uint64_t pbase = pos0 + (uint64_t)(j - 2) * SK_CH;
+        uint32_t P = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint64_t canon[4];
-            uint32_t h1[4];
+            uint32_t mz[4];
             bool     live[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
+                const int o = q * 4 + i;
                 sk_step(s, (w[q] >> (8 * i)) & 0xFFu);
-                const uint64_t p = pbase + (uint64_t)(q * 4 + i);
-                const bool in_range = (p >= emit_begin) & (p < nbytes);
+                const uint32_t h = sk_mmer_hash(s);
+                H[o] = h;
+                P = h < P ? h : P;
+                mz[i] = S[o + 1] < P ? S[o + 1] : P;
+                const uint64_t p = pbase + (uint64_t)o;
+                const bool in_range = emit_chunk & (p >= emit_begin) & (p < nbytes);
                 canon[i] = s.fwd > s.rc ? s.fwd : s.rc;
                 live[i] = in_range & (s.run >= (uint32_t)SK_K);
                 wide_seen |= (uint32_t)(in_range & (s.run < (uint32_t)SK_K) & (s.soft >= (uint32_t)SK_K));
-                h1[i] = sk_hash62(canon[i]);
             }
+            if (!emit_chunk) continue;
+            uint32_t kh[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) kh[i] = sk_khash(canon[i]);
             if (BLOOM) {
-                // stage 1: one 8-byte load from the L2-resident filter per window
-                uint2 blk[4];
+                // stage 1: block id per window; load only where it differs from the one held
+                uint32_t id[4];
+                bool     need[4];
+                uint32_t prev = blk_id;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    blk[i] = make_uint2(0u, 0u);
-                    if (live[i]) blk[i] = table.bloom[sk_hash62b(canon[i]) & table.bloom_mask];
+                    id[i] = live[i] ? (mz[i] & table.bloom_mask) : prev;
+                    need[i] = id[i] != prev;
+                    prev = id[i];
+                }
+                sk_u4 b[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    b[i] = (sk_u4){0u, 0u, 0u, 0u};
+                    if (need[i]) b[i] = table.bloom[id[i]];
+                    if (STATS) { n_live += live[i]; n_load += need[i]; }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint2 m = sk_bloom_bits(h1[i]);
-                    live[i] = ((blk[i].x & m.x) == m.x) & ((blk[i].y & m.y) == m.y);   // blk == 0 when !live
+                    if (!need[i]) b[i] = (i == 0) ? blk : b[i - 1];
+                    live[i] = live[i] & sk_bloom_test(b[i], kh[i]);
                 }
+                blk = b[3];
+                blk_id = prev;
             }
-            // stage 2: the table itself (HBM / Infinity Cache), only for windows that passed
+            // stage 2: the table, only for windows that passed
             uint64_t key[4];
+            uint32_t slot[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) key[i] = live[i] ? table.keys[h1[i] & table.mask] : SK_EMPTY64;
+            for (int i = 0; i < 4; i++) {
+                slot[i] = sk_slot0(mz[i], kh[i], table.mask);
+                key[i] = live[i] ? table.keys[slot[i]] : SK_EMPTY64;
+                if (STATS) n_probe += live[i];
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (key[i] != SK_EMPTY64) sk_resolve(canon[i], h1[i] & table.mask, key[i], table, counts);
+                if (key[i] != SK_EMPTY64) sk_resolve(canon[i], slot[i], key[i], table, counts);
         }
+        // suffix minima of this chunk for the next one
+        S[15] = H[15];
+#pragma unroll
+        for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
     }
     if (wide_seen) atomicAdd(&flags[0], 1u);
+    if (STATS) {
+        atomicAdd((unsigned long long *)&flags[4], (unsigned long long)n_live);
+        atomicAdd((unsigned long long *)&flags[6], (unsigned long long)n_load);
+        atomicAdd((unsigned long long *)&flags[8], (unsigned long long)n_probe);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,7 +295,7 @@ void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         if (opure) {                                   // e.g. a window with U whose revcomp wins
             uint64_t key = 0;
             for (int i = 0; i < SK_K; i++) key = (key << 2) | sk_code((uint8_t)o[i]);
-            uint32_t slot = sk_hash62(key) & table.mask;
+            const uint32_t slot = sk_slot0(sk_minimizer62(key), sk_khash(key), table.mask);
             const uint64_t first = table.keys[slot];
             if (first != SK_EMPTY64) sk_resolve(key, slot, first, table, counts);
         } else if (wide.nwide) {
@@ -270,7 +330,7 @@ __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, uin
     const uint64_t k = in[i];
     if (k == SK_EMPTY64) return;                       // wide row: not in this table
     if (k > SK_KMASK62) { atomicAdd(&flags[1], 1u); return; }
-    uint32_t slot = sk_hash62(k) & mask;
+    uint32_t slot = sk_slot0(sk_minimizer62(k), sk_khash(k), mask);
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long *)&keys[slot],
                                                 (unsigned long long)SK_EMPTY64, (unsigned long long)k);
@@ -286,10 +346,12 @@ __global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uin
     if (i >= n) return;
     const uint64_t k = in[i];
     if (k == SK_EMPTY64) return;
-    const uint2 m = sk_bloom_bits(sk_hash62(k));
-    const uint32_t b = sk_hash62b(k) & bloom_mask;
-    atomicOr(&bloom_words[2u * b], m.x);
-    atomicOr(&bloom_words[2u * b + 1u], m.y);
+    const uint32_t kh = sk_khash(k);
+    uint32_t *blk = bloom_words + 4u * (size_t)(sk_minimizer62(k) & bloom_mask);
+    atomicOr(&blk[0], 1u << (kh >> 27));
+    atomicOr(&blk[1], 1u << ((kh >> 22) & 31u));
+    atomicOr(&blk[2], 1u << ((kh >> 17) & 31u));
+    atomicOr(&blk[3], 1u << ((kh >> 12) & 31u));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -305,7 +367,7 @@ struct sk_ctx {
     uint64_t    *d_keys;
     uint32_t    *d_rowid;
     uint32_t     slots_log2;
-    uint2       *d_bloom;
+    sk_u4       *d_bloom;
     uint32_t     bloom_blocks_log2;       // 0 = no prefilter
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
@@ -328,6 +390,7 @@ struct sk_ctx {
     // options
     long         table_load_pct;
     long         bloom_bits_log2;
+    long         stats;               // debug: count live windows / filter loads / table probes
     char         err[512];
 };
 
@@ -426,6 +489,7 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
     if (!c || !name) return SK_E_ARG;
     if (!strcmp(name, "table_load_pct")) { if (value < 5 || value > 90) return SK_E_ARG; c->table_load_pct = value; return SK_OK; }
     if (!strcmp(name, "bloom_bits_log2")) { if (value < -1 || value > 34 || (value > 0 && value < 10)) return SK_E_ARG; c->bloom_bits_log2 = value; return SK_OK; }
+    if (!strcmp(name, "stats")) { c->stats = value != 0; return SK_OK; }
     return sk_fail(c, SK_E_ARG, "unknown option %s", name);
 }
 
@@ -459,8 +523,8 @@ extern "C" int sk_table_load(sk_ctx *c, const uint64_t *keys, uint32_t nrows, ui
         if (bb < 0) { bb = 25; while (bb > 12 && ((uint64_t)1 << bb) > (uint64_t)nrows * 64ull) bb--; }
         c->bloom_blocks_log2 = 0;
         if (bb > 0) {
-            const uint32_t blocks_log2 = (uint32_t)bb - 6u;
-            const size_t bbytes = ((size_t)1 << blocks_log2) * sizeof(uint2);
+            const uint32_t blocks_log2 = (uint32_t)bb - 7u;
+            const size_t bbytes = ((size_t)1 << blocks_log2) * sizeof(sk_u4);
             SK_HIP(c, hipMalloc((void **)&c->d_bloom, bbytes));
             SK_HIP(c, hipMemsetAsync(c->d_bloom, 0, bbytes, c->stream));
             hipLaunchKernelGGL(sk_bloom_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
@@ -530,11 +594,14 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         SK_HIP(c, hipEventCreate(&e1));
         SK_HIP(c, hipEventRecord(e0, c->stream));
     }
-    if (c->bloom_blocks_log2)
-        hipLaunchKernelGGL(sk_scan_main<true>, dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+    if (c->stats && c->bloom_blocks_log2)
+        hipLaunchKernelGGL((sk_scan_main<true, true>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
+    else if (c->bloom_blocks_log2)
+        hipLaunchKernelGGL((sk_scan_main<true, false>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
                            d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
     else
-        hipLaunchKernelGGL(sk_scan_main<false>, dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+        hipLaunchKernelGGL((sk_scan_main<false, false>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
                            d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
     if (timed) {
         SK_HIP(c, hipEventRecord(e1, c->stream));
@@ -655,6 +722,19 @@ extern "C" int sk_scan_timing(sk_ctx *c, double *total_ms, uint64_t *launches, i
     if (total_ms) *total_ms = c->timed_ms;
     if (launches) *launches = c->timed_launches;
     if (reset) { c->timed_ms = 0; c->timed_launches = 0; }
+    return SK_OK;
+}
+
+// debug statistics accumulated by sk_scan_main<.., STATS=true> since the table was loaded:
+// out[0] = windows looked up, out[1] = prefilter block loads, out[2] = table probes
+extern "C" int sk_scan_stats(sk_ctx *c, uint64_t out[3])
+{
+    if (!c || !out) return SK_E_ARG;
+    uint64_t raw[4];
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    SK_HIP(c, hipMemcpy(raw, c->d_flags + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    out[0] = raw[0]; out[1] = raw[1]; out[2] = raw[2];
     return SK_OK;
 }
 

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load",
     "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
-    "sk_counts_allreduce", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
+    "sk_counts_allreduce", "sk_scan_timing", "sk_set_option", "sk_scan_stats", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
     "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
@@ -82,6 +82,7 @@ lib.sk_table_cols.restype = C.c_uint32
 lib.sk_counts_allreduce.argtypes = [C.c_void_p, C.c_void_p]
 lib.sk_scan_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
 lib.sk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+lib.sk_scan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 lib.sk_dev_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64]
 lib.sk_dev_free.argtypes = [C.c_void_p, C.c_void_p]
 lib.sk_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -250,6 +251,11 @@ class KmerContext:
         n = C.c_uint64(0)
         self._ck(lib.sk_scan_timing(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+    def scan_stats(self):
+        out = (C.c_uint64 * 3)()
+        self._ck(lib.sk_scan_stats(self._h, out))
+        return {"windows": out[0], "filter_loads": out[1], "table_probes": out[2]}
 
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
