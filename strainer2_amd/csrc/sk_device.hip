@@ -44,16 +44,21 @@
 
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
 
+// per-wave queue of windows that passed stage 1 and still need their table probe
+#define SK_WAVES        (SK_THREADS / 64)
+#define SK_QCAP         (64 + 4 * 64)       // drained below 64 before every group of 4 windows
+
 __device__ __forceinline__ uint32_t sk_lds_slot(uint32_t chunk) { return chunk + chunk / SK_SPAN_CH; }
 
 struct sk_table_view {
     const uint64_t *keys;
     const uint32_t *rowid;
     uint32_t        mask;
-    // L2-resident prefilter: 128-bit blocks chosen by the window's minimizer hash; a key sets
-    // one bit in each of the block's four 32-bit words (positions from sk_khash)
-    const sk_u4    *bloom;
-    uint32_t        bloom_mask;      // number of 128-bit blocks - 1
+    // L2-resident prefilter: a Bloom set of the MINIMIZER hashes that occur in the strain
+    // (about nrows/8 items).  64-bit blocks chosen by the low bits of the minimizer hash,
+    // two bits in each 32-bit half.
+    const uint2    *bloom;
+    uint32_t        bloom_mask;      // number of 64-bit blocks - 1
 };
 
 // follow the probe sequence of `canon` from `slot` (first key already loaded)
@@ -68,11 +73,20 @@ __device__ __forceinline__ void sk_resolve(uint64_t canon, uint32_t slot, uint64
     }
 }
 
-__device__ __forceinline__ bool sk_bloom_test(const sk_u4 blk, uint32_t kh)
+// is minimizer hash `mz` (possibly) one of the strain's?  blk = its filter block
+// stage 2 for one queued window: slot from the k-mer hash, 62-bit compare, atomicAdd on a hit
+__device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, uint32_t *counts)
 {
-    // bit (kh>>27) of word 0, (kh>>22)&31 of word 1, (kh>>17)&31 of word 2, (kh>>12)&31 of word 3
-    const uint32_t t = (blk.x >> (kh >> 27)) & (blk.y >> ((kh >> 22) & 31u)) &
-                       (blk.z >> ((kh >> 17) & 31u)) & (blk.w >> ((kh >> 12) & 31u));
+    const uint32_t slot = sk_slot0(0u, sk_khash(canon), t.mask);
+    const uint64_t key = t.keys[slot];
+    if (key != SK_EMPTY64) sk_resolve(canon, slot, key, t, counts);
+}
+
+__device__ __forceinline__ bool sk_filter_test(const uint2 blk, uint32_t mz)
+{
+    const uint32_t g = mz * 0x9E3779B1u;
+    const uint32_t t = (blk.x >> (g >> 27)) & (blk.x >> ((g >> 22) & 31u)) &
+                       (blk.y >> ((g >> 17) & 31u)) & (blk.y >> ((g >> 12) & 31u));
     return (t & 1u) != 0u;
 }
 
@@ -104,19 +118,25 @@ __device__ __forceinline__ uint32_t sk_mmer_hash(const sk_roll &s)
 //   roll      fwd/rc 2-bit packing, ACGT run length                      (registers)
 //   minimizer sliding minimum of the 16-mer hashes over the window        (registers;
 //             block-decomposed: prefix minima of this chunk + suffix minima of the last)
-//   stage 1   prefilter block chosen by the minimizer; re-loaded from L2 only when the
-//             minimizer changes (about once per 8 windows), else kept in registers
-//   stage 2   table line chosen by the minimizer, slot by the k-mer hash (HBM/Infinity Cache),
-//             only for windows that pass stage 1; full 62-bit compare; atomicAdd on a hit
-template <bool BLOOM, bool STATS>
-__global__ __launch_bounds__(SK_THREADS)
+//   stage 1   "does the strain contain this minimizer at all?"  One 8-byte load from the
+//             L2-resident minimizer filter, only when the lane's minimizer changes (about once
+//             per 8 windows); the verdict is kept in a register until it changes again.
+//             Windows of reads unrelated to the strain stop here (false positives ~0.1 %).
+//   stage 2   table probe (HBM / Infinity Cache), only for windows whose minimizer passed:
+//             slot from the k-mer hash, full 62-bit compare, atomicAdd on a hit
+template <bool BLOOM, bool STATS, int ABLATE>      // ABLATE (timing experiments only; wrong counts):
+__global__ __launch_bounds__(SK_THREADS)           // 1 = no filter/table memory at all, 2 = no table probes
 void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, uint32_t *__restrict__ counts, uint32_t *__restrict__ flags)
 {
     __shared__ sk_u4 lds[SK_LDS_CH];
+    __shared__ uint64_t queue[SK_WAVES][SK_QCAP];
 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // first window-end position
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    uint64_t *const wq = queue[tid >> 6];
+    uint32_t qn = 0;                                              // queued windows (wave-uniform)
 
     // ---- stage bytes [tile0 - LEAD, tile0 + TILE) into LDS, 16 B per lane, coalesced --------
     for (uint32_t c = tid; c < SK_TILE_CH; c += SK_THREADS) {
@@ -148,8 +168,8 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     uint32_t S[17];                     // suffix minima of the previous chunk's 16-mer hashes
 #pragma unroll
     for (int i = 0; i < 17; i++) S[i] = 0xFFFFFFFFu;
-    sk_u4    blk = (sk_u4){0u, 0u, 0u, 0u};
-    uint32_t blk_id = 0xFFFFFFFFu;      // which prefilter block `blk` holds
+    uint32_t cur_mz = 0xFFFFFFFFu;      // minimizer hash the verdict below belongs to
+    bool     cur_pass = false;          // stage-1 verdict for cur_mz
 
     // ---- warm-up chunk 0: rolling state only ---------------------------------------------
     {
@@ -187,53 +207,66 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 wide_seen |= (uint32_t)(in_range & (s.run < (uint32_t)SK_K) & (s.soft >= (uint32_t)SK_K));
             }
             if (!emit_chunk) continue;
-            uint32_t kh[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) kh[i] = sk_khash(canon[i]);
             if (BLOOM) {
-                // stage 1: block id per window; load only where it differs from the one held
-                uint32_t id[4];
+                // stage 1: look the minimizer up only where it differs from the one already judged
+                uint32_t m[4];
                 bool     need[4];
-                uint32_t prev = blk_id;
+                uint32_t prev = cur_mz;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    id[i] = live[i] ? (mz[i] & table.bloom_mask) : prev;
-                    need[i] = id[i] != prev;
-                    prev = id[i];
+                    m[i] = live[i] ? mz[i] : prev;
+                    need[i] = m[i] != prev;
+                    prev = m[i];
                 }
-                sk_u4 b[4];
+                uint2 b[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    b[i] = (sk_u4){0u, 0u, 0u, 0u};
-                    if (need[i]) b[i] = table.bloom[id[i]];
+                    b[i] = make_uint2(0u, 0u);
+                    if (need[i] && ABLATE != 1) b[i] = table.bloom[m[i] & table.bloom_mask];
                     if (STATS) { n_live += live[i]; n_load += need[i]; }
                 }
+                bool pass = cur_pass;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    if (!need[i]) b[i] = (i == 0) ? blk : b[i - 1];
-                    live[i] = live[i] & sk_bloom_test(b[i], kh[i]);
+                    if (need[i]) pass = sk_filter_test(b[i], m[i]) || (ABLATE == 1 && m[i] == 0x12345u);
+                    live[i] = live[i] & pass;
                 }
-                blk = b[3];
-                blk_id = prev;
+                cur_pass = pass;
+                cur_mz = prev;
             }
-            // stage 2: the table, only for windows that passed
-            uint64_t key[4];
-            uint32_t slot[4];
+            if (ABLATE == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) live[i] = live[i] & (canon[i] == 0x123456789ull);
+            }
+            // queue the windows that passed; stage 2 runs on full waves when 64 are waiting
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                slot[i] = sk_slot0(mz[i], kh[i], table.mask);
-                key[i] = live[i] ? table.keys[slot[i]] : SK_EMPTY64;
-                if (STATS) n_probe += live[i];
+                const unsigned long long mask = __ballot(live[i]);
+                if (mask) {
+                    if (live[i]) wq[qn + __popcll(mask & ((1ull << lane) - 1ull))] = canon[i];
+                    qn += (uint32_t)__popcll(mask);
+                    if (STATS) n_probe += live[i];
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (key[i] != SK_EMPTY64) sk_resolve(canon[i], slot[i], key[i], table, counts);
+            if (qn >= 64u) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                do {
+                    qn -= 64u;
+                    sk_probe(wq[qn + lane], table, counts);
+                } while (qn >= 64u);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         // suffix minima of this chunk for the next one
         S[15] = H[15];
 #pragma unroll
         for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
     }
+    // drain what is left in the queue
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < qn) sk_probe(wq[lane], table, counts);
     if (wide_seen) atomicAdd(&flags[0], 1u);
     if (STATS) {
         atomicAdd((unsigned long long *)&flags[4], (unsigned long long)n_live);
@@ -346,12 +379,11 @@ __global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uin
     if (i >= n) return;
     const uint64_t k = in[i];
     if (k == SK_EMPTY64) return;
-    const uint32_t kh = sk_khash(k);
-    uint32_t *blk = bloom_words + 4u * (size_t)(sk_minimizer62(k) & bloom_mask);
-    atomicOr(&blk[0], 1u << (kh >> 27));
-    atomicOr(&blk[1], 1u << ((kh >> 22) & 31u));
-    atomicOr(&blk[2], 1u << ((kh >> 17) & 31u));
-    atomicOr(&blk[3], 1u << ((kh >> 12) & 31u));
+    const uint32_t mz = sk_minimizer62(k);
+    const uint32_t g = mz * 0x9E3779B1u;
+    uint32_t *blk = bloom_words + 2u * (size_t)(mz & bloom_mask);
+    atomicOr(&blk[0], (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)));
+    atomicOr(&blk[1], (1u << ((g >> 17) & 31u)) | (1u << ((g >> 12) & 31u)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,7 +399,7 @@ struct sk_ctx {
     uint64_t    *d_keys;
     uint32_t    *d_rowid;
     uint32_t     slots_log2;
-    sk_u4       *d_bloom;
+    uint2       *d_bloom;
     uint32_t     bloom_blocks_log2;       // 0 = no prefilter
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
@@ -391,6 +423,7 @@ struct sk_ctx {
     long         table_load_pct;
     long         bloom_bits_log2;
     long         stats;               // debug: count live windows / filter loads / table probes
+    long         ablate;              // timing experiments: kernel variants that skip memory stages
     char         err[512];
 };
 
@@ -490,6 +523,7 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
     if (!strcmp(name, "table_load_pct")) { if (value < 5 || value > 90) return SK_E_ARG; c->table_load_pct = value; return SK_OK; }
     if (!strcmp(name, "bloom_bits_log2")) { if (value < -1 || value > 34 || (value > 0 && value < 10)) return SK_E_ARG; c->bloom_bits_log2 = value; return SK_OK; }
     if (!strcmp(name, "stats")) { c->stats = value != 0; return SK_OK; }
+    if (!strcmp(name, "ablate")) { c->ablate = value; return SK_OK; }
     return sk_fail(c, SK_E_ARG, "unknown option %s", name);
 }
 
@@ -518,13 +552,14 @@ extern "C" int sk_table_load(sk_ctx *c, const uint64_t *keys, uint32_t nrows, ui
         SK_HIP(c, hipMemcpyAsync(d_in, keys, (size_t)nrows * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(sk_table_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
                            d_in, nrows, c->d_keys, c->d_rowid, (uint32_t)(slots - 1), c->d_flags);
-        // prefilter: automatic size = 2^25 bits (4 MiB, one XCD L2) unless the key set is tiny
+        // minimizer filter: automatic size = smallest power of two >= 4 bits per key (the set holds
+        // ~nrows/8 minimizers, i.e. ~32 bits each: false positives ~0.1 %); 2 MiB for a 5 Mbp strain
         long bb = c->bloom_bits_log2;
-        if (bb < 0) { bb = 25; while (bb > 12 && ((uint64_t)1 << bb) > (uint64_t)nrows * 64ull) bb--; }
+        if (bb < 0) { bb = 12; while (bb < 30 && ((uint64_t)1 << bb) < (uint64_t)nrows * 4ull) bb++; }
         c->bloom_blocks_log2 = 0;
         if (bb > 0) {
-            const uint32_t blocks_log2 = (uint32_t)bb - 7u;
-            const size_t bbytes = ((size_t)1 << blocks_log2) * sizeof(sk_u4);
+            const uint32_t blocks_log2 = (uint32_t)bb - 6u;
+            const size_t bbytes = ((size_t)1 << blocks_log2) * sizeof(uint2);
             SK_HIP(c, hipMalloc((void **)&c->d_bloom, bbytes));
             SK_HIP(c, hipMemsetAsync(c->d_bloom, 0, bbytes, c->stream));
             hipLaunchKernelGGL(sk_bloom_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
@@ -594,14 +629,20 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         SK_HIP(c, hipEventCreate(&e1));
         SK_HIP(c, hipEventRecord(e0, c->stream));
     }
-    if (c->stats && c->bloom_blocks_log2)
-        hipLaunchKernelGGL((sk_scan_main<true, true>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+    if (c->ablate == 1 && c->bloom_blocks_log2)
+        hipLaunchKernelGGL((sk_scan_main<true, false, 1>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
+    else if (c->ablate == 2 && c->bloom_blocks_log2)
+        hipLaunchKernelGGL((sk_scan_main<true, false, 2>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
+    else if (c->stats && c->bloom_blocks_log2)
+        hipLaunchKernelGGL((sk_scan_main<true, true, 0>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
                            d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
     else if (c->bloom_blocks_log2)
-        hipLaunchKernelGGL((sk_scan_main<true, false>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+        hipLaunchKernelGGL((sk_scan_main<true, false, 0>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
                            d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
     else
-        hipLaunchKernelGGL((sk_scan_main<false, false>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
+        hipLaunchKernelGGL((sk_scan_main<false, false, 0>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
                            d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
     if (timed) {
         SK_HIP(c, hipEventRecord(e1, c->stream));
