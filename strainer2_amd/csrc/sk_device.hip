@@ -33,22 +33,18 @@
 // scan kernel geometry
 // ---------------------------------------------------------------------------------------------
 #define SK_THREADS      256                 // 4 waves of 64
+#define SK_WAVES        (SK_THREADS / 64)
 #define SK_SPAN         128                 // window-end positions per thread
+#define SK_SPAN_CH      8                   // 16-base chunks per span
 #define SK_TILE         (SK_THREADS * SK_SPAN)
-#define SK_CH           16                  // bytes per LDS chunk (one ds_read_b128)
-#define SK_SPAN_CH      (SK_SPAN / SK_CH)   // 8 chunks per span
-#define SK_LEAD         32                  // bytes staged in front of the tile (>= k-1, 16-aligned)
-#define SK_TILE_CH      ((SK_TILE + SK_LEAD) / SK_CH)
-// one 16-byte pad after every SK_SPAN_CH chunks: lane stride 36 dwords -> conflict-free b128 reads
-#define SK_LDS_CH       (SK_TILE_CH + SK_TILE_CH / SK_SPAN_CH + 1)
+#define SK_NREC         (SK_THREADS + 1)    // record 0 = the 128 bases in front of the tile
+#define SK_REC_DW       12                  // per record: 8 code words (u32) + 8 invalid masks (u16) = 48 B;
+                                            // 12-dword lane stride keeps ds_read_b128 conflict-free
+#define SK_NCHUNK       (SK_NREC * SK_SPAN_CH)
+#define SK_EVQ          (64 + 9 * 64)       // minimizer-run events: drained below 64 twice per chunk
+#define SK_PQ           (64 + 64)           // windows waiting for their table probe
 
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
-
-// per-wave queue of windows that passed stage 1 and still need their table probe
-#define SK_WAVES        (SK_THREADS / 64)
-#define SK_QCAP         (64 + 4 * 64)       // drained below 64 before every group of 4 windows
-
-__device__ __forceinline__ uint32_t sk_lds_slot(uint32_t chunk) { return chunk + chunk / SK_SPAN_CH; }
 
 struct sk_table_view {
     const uint64_t *keys;
@@ -73,7 +69,6 @@ __device__ __forceinline__ void sk_resolve(uint64_t canon, uint32_t slot, uint64
     }
 }
 
-// is minimizer hash `mz` (possibly) one of the strain's?  blk = its filter block
 // stage 2 for one queued window: slot from the k-mer hash, 62-bit compare, atomicAdd on a hit
 __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, uint32_t *counts)
 {
@@ -82,6 +77,7 @@ __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t,
     if (key != SK_EMPTY64) sk_resolve(canon, slot, key, t, counts);
 }
 
+// is minimizer hash `mz` (possibly) one of the strain's?  blk = its filter block
 __device__ __forceinline__ bool sk_filter_test(const uint2 blk, uint32_t mz)
 {
     const uint32_t g = mz * 0x9E3779B1u;
@@ -90,184 +86,260 @@ __device__ __forceinline__ bool sk_filter_test(const uint2 blk, uint32_t mz)
     return (t & 1u) != 0u;
 }
 
-struct sk_roll {
-    uint64_t fwd, rc;       // forward / reverse-complement packed windows (62 bits)
-    uint32_t run;           // consecutive ACGT bytes ending here
-    uint32_t soft;          // consecutive bytes that are not hard breakers (N, '\n', NUL)
-};
+// ---- phase 1 helpers: 4 bytes at a time (SWAR) -------------------------------------------------
+// bit 7 of every byte of the result is set iff that byte of x is non-zero
+__device__ __forceinline__ uint32_t sk_nz_msb(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; }
 
-__device__ __forceinline__ void sk_step(sk_roll &s, uint32_t b)
+// w = 4 stream bytes (first base in the low byte).  codes8: their 2-bit codes, first base in bits
+// 7..6.  inv4: bit i set iff byte i is not A/C/G/T (any case).  bad: bit 7 of byte i set iff it is
+// neither A/C/G/T nor N/n nor '\n' (a byte only the exact byte-string path can judge).
+__device__ __forceinline__ void sk_decode4(uint32_t w, uint32_t &codes8, uint32_t &inv4, uint32_t &bad)
 {
-    const uint32_t code = sk_code(b);
-    s.fwd = ((s.fwd << 2) | code) & SK_KMASK62;
-    s.rc  = (s.rc >> 2) | ((uint64_t)(3u - code) << 60);
-    s.run  = sk_is_acgt(b) ? s.run + 1u : 0u;
-    s.soft = sk_is_hard_break(b) ? 0u : s.soft + 1u;
+    const uint32_t u  = w & 0xDFDFDFDFu;                                   // upper-cased letters
+    const uint32_t x  = (w >> 1) & 0x03030303u;                            // A0 C1 T2 G3
+    const uint32_t cd = x ^ ((x >> 1) & 0x01010101u);                      // A0 C1 G2 T3
+    codes8 = (cd * 0x40100401u) >> 24;                                     // gather 4 x 2 bits
+    const uint32_t lut = 0x47544341u;                                      // 'A','C','T','G' by x
+    const uint32_t d  = __builtin_amdgcn_perm(lut, lut, x) ^ u;            // 0 <=> the byte is that letter
+    const uint32_t m1 = sk_nz_msb(d);
+    inv4 = ((((m1 >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+    bad |= m1 & sk_nz_msb(u ^ 0x4E4E4E4Eu) & sk_nz_msb(w ^ 0x0A0A0A0Au) & 0x80808080u;
 }
 
-// hash of the canonical 16-mer that ends at the current base
-__device__ __forceinline__ uint32_t sk_mmer_hash(const sk_roll &s)
+__device__ __forceinline__ uint32_t sk_revcomp32(uint32_t x)              // 16 packed bases
 {
-    const uint32_t f16 = (uint32_t)s.fwd;
-    const uint32_t r16 = (uint32_t)(s.rc >> 30);
-    return sk_mhash(f16 < r16 ? f16 : r16);
+    uint32_t y = __builtin_bitreverse32(x);
+    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+    return ~y;
 }
 
-// THE hot kernel.  One thread owns SK_SPAN consecutive window-end positions and rolls over
-// them in 16-base chunks held in registers (bytes staged through LDS, coalesced 16 B loads):
-//   roll      fwd/rc 2-bit packing, ACGT run length                      (registers)
-//   minimizer sliding minimum of the 16-mer hashes over the window        (registers;
-//             block-decomposed: prefix minima of this chunk + suffix minima of the last)
-//   stage 1   "does the strain contain this minimizer at all?"  One 8-byte load from the
-//             L2-resident minimizer filter, only when the lane's minimizer changes (about once
-//             per 8 windows); the verdict is kept in a register until it changes again.
-//             Windows of reads unrelated to the strain stop here (false positives ~0.1 %).
-//   stage 2   table probe (HBM / Infinity Cache), only for windows whose minimizer passed:
-//             slot from the k-mer hash, full 62-bit compare, atomicAdd on a hit
-template <bool BLOOM, bool STATS, int ABLATE>      // ABLATE (timing experiments only; wrong counts):
+// canonical packed 31-mer of the window that ends at tile-relative position e, from the LDS records
+__device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_t e)
+{
+    const uint32_t b = e + SK_SPAN;                        // record 0 holds the 128 bases before the tile
+    const uint32_t c = b >> 4, s = 2u * (15u - (b & 15u));
+    const uint32_t w0 = rec[(c >> 3) * SK_REC_DW + (c & 7u)];
+    const uint32_t w1 = rec[((c - 1u) >> 3) * SK_REC_DW + ((c - 1u) & 7u)];
+    const uint32_t w2 = rec[((c - 2u) >> 3) * SK_REC_DW + ((c - 2u) & 7u)];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, s);
+    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, s) & 0x3FFFFFFFu;
+    const uint64_t fwd = ((uint64_t)hi << 32) | lo;
+    uint64_t r = ((uint64_t)__builtin_bitreverse32(lo) << 32) | __builtin_bitreverse32(hi);
+    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+    const uint64_t rc = (~r) >> 2;
+    return fwd > rc ? fwd : rc;
+}
+
+// THE hot kernel.  A workgroup owns SK_TILE consecutive window-end positions of the record stream.
+//
+//   phase 1  (cooperative, coalesced 16 B loads) every 16 stream bytes become one packed code
+//            word (2 bits/base) + a 16-bit "not ACGT" mask in LDS; bytes that are neither ACGT,
+//            N nor '\n' raise the batch's "needs the byte-string kernel" flag.
+//   phase 2  each thread walks its 128 positions in 16-base chunks, all in registers:
+//              16-mer state   f16/r16 roll by one lshl_or / alignbit per base
+//              minimizer      sliding minimum of the 16-mer hashes over the 31-mer window
+//                             (prefix minima of this chunk + suffix minima of the previous one)
+//              live mask      "31 valid bases end here" for the 16 positions by bit tricks
+//              runs           maximal runs of live windows with one minimizer -> one EVENT each
+//   stage 1  events are queued per wave and judged 64 at a time: one 8 B load from the
+//            L2-resident filter "is this minimizer in the strain at all?".  Reads unrelated to
+//            the strain stop here (~1 % false positives).
+//   stage 2  windows of passing runs are rebuilt from LDS (full 62-bit canonical key), queued,
+//            and probed 64 at a time in the HBM table; atomicAdd on the row counter on a hit.
+template <bool FILTER, bool STATS, int ABLATE>     // ABLATE (timing experiments only; wrong counts):
 __global__ __launch_bounds__(SK_THREADS)           // 1 = no filter/table memory at all, 2 = no table probes
 void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, uint32_t *__restrict__ counts, uint32_t *__restrict__ flags)
 {
-    __shared__ sk_u4 lds[SK_LDS_CH];
-    __shared__ uint64_t queue[SK_WAVES][SK_QCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t rec[SK_NREC * SK_REC_DW];
+    __shared__ uint2    evq_all[SK_WAVES][SK_EVQ];
+    __shared__ uint64_t pq_all[SK_WAVES][SK_PQ];
 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // first window-end position
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    uint64_t *const wq = queue[tid >> 6];
-    uint32_t qn = 0;                                              // queued windows (wave-uniform)
 
-    // ---- stage bytes [tile0 - LEAD, tile0 + TILE) into LDS, 16 B per lane, coalesced --------
-    for (uint32_t c = tid; c < SK_TILE_CH; c += SK_THREADS) {
-        const int64_t off = (int64_t)tile0 - SK_LEAD + (int64_t)c * SK_CH;
-        sk_u4 v;
-        if (off >= 0 && (uint64_t)off + SK_CH <= nbytes) {
-            v = __builtin_nontemporal_load((const sk_u4 *)(stream + off));
-        } else {
-            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};   // '\n' fill
-            for (int i = 0; i < SK_CH; i++) {
-                const int64_t p = off + i;
-                if (p >= 0 && (uint64_t)p < nbytes) {
-                    w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
+    // ================= phase 1: bytes -> packed codes + invalid masks ==========================
+    uint32_t bad = 0;
+#pragma unroll
+    for (int it = 0; it < (SK_NCHUNK + SK_THREADS - 1) / SK_THREADS; it++) {
+        const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+        if (c < SK_NCHUNK) {
+            const int64_t off = (int64_t)tile0 - SK_SPAN + (int64_t)c * 16;
+            sk_u4 v;
+            if (off >= 0 && (uint64_t)off + 16u <= nbytes) {
+                v = __builtin_nontemporal_load((const sk_u4 *)(stream + off));
+            } else {
+                uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};   // '\n' fill
+                for (int i = 0; i < 16; i++) {
+                    const int64_t p = off + i;
+                    if (p >= 0 && (uint64_t)p < nbytes)
+                        w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
                 }
+                v = (sk_u4){w[0], w[1], w[2], w[3]};
             }
-            v = (sk_u4){w[0], w[1], w[2], w[3]};
+            uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+            sk_decode4(v.x, c0, i0, bad);
+            sk_decode4(v.y, c1, i1, bad);
+            sk_decode4(v.z, c2, i2, bad);
+            sk_decode4(v.w, c3, i3, bad);
+            const uint32_t r = c >> 3, sl = c & 7u;
+            rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+            ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
         }
-        lds[sk_lds_slot(c)] = v;
     }
     __syncthreads();
 
-    sk_roll s;
-    s.fwd = 0; s.rc = 0; s.run = 0; s.soft = 0;
-    uint32_t wide_seen = 0;
-    uint32_t n_live = 0, n_load = 0, n_probe = 0;             // STATS only
-    const uint32_t chunk0 = tid * SK_SPAN_CH;
-    const uint64_t pos0 = tile0 + (uint64_t)tid * SK_SPAN;       // window-end position of span byte 0
+    // ================= phase 2 ==================================================================
+    uint2    *const evq = evq_all[tid >> 6];
+    uint64_t *const pq  = pq_all[tid >> 6];
+    uint32_t qe = 0, qp = 0;                                      // queue fills (wave-uniform)
+    uint32_t n_live = 0, n_load = 0, n_probe = 0;                 // STATS only
 
-    uint32_t S[17];                     // suffix minima of the previous chunk's 16-mer hashes
-#pragma unroll
-    for (int i = 0; i < 17; i++) S[i] = 0xFFFFFFFFu;
-    uint32_t cur_mz = 0xFFFFFFFFu;      // minimizer hash the verdict below belongs to
-    bool     cur_pass = false;          // stage-1 verdict for cur_mz
-
-    // ---- warm-up chunk 0: rolling state only ---------------------------------------------
-    {
-        const sk_u4 v = lds[sk_lds_slot(chunk0)];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int o = 0; o < 16; o++) sk_step(s, (w[o >> 2] >> (8 * (o & 3))) & 0xFFu);
-    }
-
-#pragma unroll 1
-    for (uint32_t j = 1; j < SK_SPAN_CH + 2; j++) {
-        const sk_u4 v = lds[sk_lds_slot(chunk0 + j)];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t H[16];
-        const bool emit_chunk = j >= 2;                        // chunk 1 only warms the minima up
-        const uint64_t pbase = pos0 + (uint64_t)(j - 2) * SK_CH;
-        uint32_t P = 0xFFFFFFFFu;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint64_t canon[4];
-            uint32_t mz[4];
-            bool     live[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int o = q * 4 + i;
-                sk_step(s, (w[q] >> (8 * i)) & 0xFFu);
-                const uint32_t h = sk_mmer_hash(s);
-                H[o] = h;
-                P = h < P ? h : P;
-                mz[i] = S[o + 1] < P ? S[o + 1] : P;
-                const uint64_t p = pbase + (uint64_t)o;
-                const bool in_range = emit_chunk & (p >= emit_begin) & (p < nbytes);
-                canon[i] = s.fwd > s.rc ? s.fwd : s.rc;
-                live[i] = in_range & (s.run >= (uint32_t)SK_K);
-                wide_seen |= (uint32_t)(in_range & (s.run < (uint32_t)SK_K) & (s.soft >= (uint32_t)SK_K));
+    // drain events in batches of 64 (and the rest when `all`): stage 1, then expansion to stage 2
+    auto drain = [&](bool all) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        while (qe >= 64u || (all && qe > 0u)) {
+            const uint32_t n = qe < 64u ? qe : 64u;
+            qe -= n;
+            const bool active = lane < n;
+            uint2 ev = make_uint2(0u, 0u);
+            if (active) ev = evq[qe + lane];
+            bool pass = false;
+            if (active) {
+                if (!FILTER) pass = true;
+                else if (ABLATE == 1) pass = ev.x == 0x12345u;
+                else pass = sk_filter_test(table.bloom[ev.x & table.bloom_mask], ev.x);
             }
-            if (!emit_chunk) continue;
-            if (BLOOM) {
-                // stage 1: look the minimizer up only where it differs from the one already judged
-                uint32_t m[4];
-                bool     need[4];
-                uint32_t prev = cur_mz;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    m[i] = live[i] ? mz[i] : prev;
-                    need[i] = m[i] != prev;
-                    prev = m[i];
+            if (STATS) n_load += active;
+            if (__ballot(pass)) {
+                const uint32_t len = pass ? ((ev.y >> 16) & 15u) + 1u : 0u;
+                const uint32_t start = ev.y & 0x7FFFu;
+                for (uint32_t k = 0;; k++) {
+                    const bool act = k < len;
+                    const unsigned long long mk = __ballot(act);
+                    if (!mk) break;
+                    if (act) {
+                        const uint64_t canon = sk_window_canon(rec, start + k);
+                        pq[qp + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = canon;
+                    }
+                    qp += (uint32_t)__popcll(mk);
+                    if (STATS) n_probe += act;
+                    if (qp >= 64u) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        qp -= 64u;
+                        const uint64_t cn = pq[qp + lane];
+                        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe(cn, table, counts);
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
-                uint2 b[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    b[i] = make_uint2(0u, 0u);
-                    if (need[i] && ABLATE != 1) b[i] = table.bloom[m[i] & table.bloom_mask];
-                    if (STATS) { n_live += live[i]; n_load += need[i]; }
-                }
-                bool pass = cur_pass;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (need[i]) pass = sk_filter_test(b[i], m[i]) || (ABLATE == 1 && m[i] == 0x12345u);
-                    live[i] = live[i] & pass;
-                }
-                cur_pass = pass;
-                cur_mz = prev;
-            }
-            if (ABLATE == 2) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) live[i] = live[i] & (canon[i] == 0x123456789ull);
-            }
-            // queue the windows that passed; stage 2 runs on full waves when 64 are waiting
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const unsigned long long mask = __ballot(live[i]);
-                if (mask) {
-                    if (live[i]) wq[qn + __popcll(mask & ((1ull << lane) - 1ull))] = canon[i];
-                    qn += (uint32_t)__popcll(mask);
-                    if (STATS) n_probe += live[i];
-                }
-            }
-            if (qn >= 64u) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                do {
-                    qn -= 64u;
-                    sk_probe(wq[qn + lane], table, counts);
-                } while (qn >= 64u);
-                __builtin_amdgcn_wave_barrier();
             }
         }
-        // suffix minima of this chunk for the next one
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // one event: a run of `len` live windows with minimizer `mz` starting at tile position `start`
+    auto push_event = [&](bool cond, uint32_t mz, uint32_t start, uint32_t len) {
+        const unsigned long long m = __ballot(cond);
+        if (m) {
+            if (cond)
+                evq[qe + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                    make_uint2(mz, start | ((len - 1u) << 16));
+            qe += (uint32_t)__popcll(m);
+        }
+    };
+
+    const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;
+    const sk_u4 ca = *(const sk_u4 *)(my);
+    const sk_u4 cb = *(const sk_u4 *)(my + 4);
+    const sk_u4 iv = *(const sk_u4 *)(my + 8);
+    const uint32_t cw[8]  = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+    const uint32_t inv[8] = {iv.x & 0xFFFFu, iv.x >> 16, iv.y & 0xFFFFu, iv.y >> 16,
+                             iv.z & 0xFFFFu, iv.z >> 16, iv.w & 0xFFFFu, iv.w >> 16};
+    const uint32_t *pv = rec + tid * SK_REC_DW;
+    const uint32_t cw_m2 = pv[6], cw_m1 = pv[7];                  // the two chunks before the span
+    uint32_t vlo = pv[11];                                        // invalid masks of those two chunks
+
+    uint32_t f16 = cw_m2, r16 = sk_revcomp32(cw_m2);              // 16-mer ending at the last base of chunk -2
+    uint32_t S[17], H[16];
+    S[16] = 0xFFFFFFFFu;
+
+    // warm-up over chunk -1: 16-mer hashes and their suffix minima
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+        const uint32_t code = (cw_m1 >> (30 - 2 * o)) & 3u;
+        f16 = (f16 << 2) | code;
+        r16 = __builtin_amdgcn_alignbit(code ^ 3u, r16, 2);
+        H[o] = sk_mhash(f16 < r16 ? f16 : r16);
+    }
+    S[15] = H[15];
+#pragma unroll
+    for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
+
+    const uint64_t pos0 = tile0 + (uint64_t)tid * SK_SPAN;       // stream position of span window 0
+
+#pragma unroll 1
+    for (uint32_t j = 0; j < SK_SPAN_CH; j++) {
+        uint32_t cwj = cw[0], invj = inv[0];
+#pragma unroll
+        for (int t = 1; t < 8; t++) { cwj = (j == (uint32_t)t) ? cw[t] : cwj; invj = (j == (uint32_t)t) ? inv[t] : invj; }
+
+        // live mask: bit o <=> the 31 bases ending at chunk offset o are all ACGT
+        const uint64_t v = ~(((uint64_t)invj << 32) | vlo);       // valid bits: chunks j-2, j-1, j
+        vlo = (vlo >> 16) | (invj << 16);
+        uint64_t rr = v & (v << 1);
+        rr &= rr << 2;
+        rr &= rr << 4;
+        rr &= rr << 8;
+        rr &= rr << 15;                                            // runs of >= 31
+        uint32_t live16 = (uint32_t)(rr >> 32) & 0xFFFFu;
+        const uint64_t pbase = pos0 + (uint64_t)j * 16u;
+        if (pbase < emit_begin) {
+            const uint64_t dlt = emit_begin - pbase;
+            live16 = dlt >= 16u ? 0u : live16 & (0xFFFFu << (uint32_t)dlt);
+        }
+        if (STATS) n_live += (uint32_t)__popc(live16);
+
+        const uint32_t ebase = tid * SK_SPAN + j * 16u;            // tile-relative index of offset 0
+        uint32_t run_mz = 0, run_start = 0, run_len = 0;
+        uint32_t P = 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 0; o < 16; o++) {
+            const uint32_t code = (cwj >> (30 - 2 * o)) & 3u;
+            f16 = (f16 << 2) | code;
+            r16 = __builtin_amdgcn_alignbit(code ^ 3u, r16, 2);
+            const uint32_t h = sk_mhash(f16 < r16 ? f16 : r16);
+            H[o] = h;
+            P = h < P ? h : P;
+            const uint32_t mz = S[o + 1] < P ? S[o + 1] : P;
+            const bool lv = ((live16 >> o) & 1u) != 0u;
+            const bool end_run = (run_len != 0u) & (!lv | (mz != run_mz));
+            push_event(end_run, run_mz, run_start, run_len);
+            const bool fresh = lv & (end_run | (run_len == 0u));
+            run_mz = fresh ? mz : run_mz;
+            run_start = fresh ? ebase + (uint32_t)o : run_start;
+            run_len = lv ? (fresh ? 1u : run_len + 1u) : 0u;
+            if (o == 7 && qe >= 64u) drain(false);
+        }
+        push_event(run_len != 0u, run_mz, run_start, run_len);
+        if (qe >= 64u) drain(false);
+
         S[15] = H[15];
 #pragma unroll
         for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
     }
-    // drain what is left in the queue
+
+    // ---- tail: everything still queued ---------------------------------------------------------
+    drain(true);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane < qn) sk_probe(wq[lane], table, counts);
-    if (wide_seen) atomicAdd(&flags[0], 1u);
+    if (lane < qp) {
+        const uint64_t cn = pq[lane];
+        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe(cn, table, counts);
+    }
+    if (bad) atomicAdd(&flags[0], 1u);
     if (STATS) {
         atomicAdd((unsigned long long *)&flags[4], (unsigned long long)n_live);
         atomicAdd((unsigned long long *)&flags[6], (unsigned long long)n_load);
