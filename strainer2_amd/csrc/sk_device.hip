@@ -42,7 +42,8 @@
                                             // 12-dword lane stride keeps ds_read_b128 conflict-free
 #define SK_NCHUNK       (SK_NREC * SK_SPAN_CH)
 #define SK_EVQ          (64 + 9 * 64)       // minimizer-run events: drained below 64 twice per chunk
-#define SK_PQ           (64 + 64)           // windows waiting for their table probe
+#define SK_WQ           (64 + 16)           // tile positions of windows waiting for their table probe
+#define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
 
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
 
@@ -153,7 +154,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 {
     __shared__ __attribute__((aligned(16))) uint32_t rec[SK_NREC * SK_REC_DW];
     __shared__ uint2    evq_all[SK_WAVES][SK_EVQ];
-    __shared__ uint64_t pq_all[SK_WAVES][SK_PQ];
+    __shared__ uint16_t wq_all[SK_WAVES][SK_WQ];
 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // first window-end position
     const uint32_t tid = threadIdx.x;
@@ -192,52 +193,74 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 
     // ================= phase 2 ==================================================================
     uint2    *const evq = evq_all[tid >> 6];
-    uint64_t *const pq  = pq_all[tid >> 6];
-    uint32_t qe = 0, qp = 0;                                      // queue fills (wave-uniform)
+    uint16_t *const wq  = wq_all[tid >> 6];
+    uint32_t qe = 0, qw = 0;                                      // queue fills (wave-uniform)
     uint32_t n_live = 0, n_load = 0, n_probe = 0;                 // STATS only
 
-    // drain events in batches of 64 (and the rest when `all`): stage 1, then expansion to stage 2
-    auto drain = [&](bool all) {
+    // Stage 1 is software-pipelined: a batch of up to SK_BATCH*64 events has its filter blocks
+    // loaded (issue) and is judged one drain site later (complete), so the L2 latency hides
+    // behind the rolling work in between.
+    uint2    pev[SK_BATCH], pblk[SK_BATCH];
+    uint32_t pn = 0;                                              // events in the pending batch
+#pragma unroll
+    for (int b = 0; b < SK_BATCH; b++) { pev[b] = make_uint2(0u, 0u); pblk[b] = make_uint2(0u, 0u); }
+
+    auto probe_batch = [&]() {                                    // stage 2 on 64 queued windows
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        while (qe >= 64u || (all && qe > 0u)) {
-            const uint32_t n = qe < 64u ? qe : 64u;
-            qe -= n;
-            const bool active = lane < n;
-            uint2 ev = make_uint2(0u, 0u);
-            if (active) ev = evq[qe + lane];
+        qw -= 64u;
+        const uint64_t cn = sk_window_canon(rec, wq[qw + lane]);
+        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe(cn, table, counts);
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    auto complete = [&]() {                                       // judge the pending batch
+#pragma unroll
+        for (int b = 0; b < SK_BATCH; b++) {
+            const bool active = lane + 64u * (uint32_t)b < pn;
             bool pass = false;
             if (active) {
                 if (!FILTER) pass = true;
-                else if (ABLATE == 1) pass = ev.x == 0x12345u;
-                else pass = sk_filter_test(table.bloom[ev.x & table.bloom_mask], ev.x);
+                else if (ABLATE == 1) pass = pev[b].x == 0x12345u;
+                else pass = sk_filter_test(pblk[b], pev[b].x);
             }
-            if (STATS) n_load += active;
-            if (__ballot(pass)) {
-                const uint32_t len = pass ? ((ev.y >> 16) & 15u) + 1u : 0u;
-                const uint32_t start = ev.y & 0x7FFFu;
-                for (uint32_t k = 0;; k++) {
-                    const bool act = k < len;
-                    const unsigned long long mk = __ballot(act);
-                    if (!mk) break;
-                    if (act) {
-                        const uint64_t canon = sk_window_canon(rec, start + k);
-                        pq[qp + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = canon;
-                    }
-                    qp += (uint32_t)__popcll(mk);
-                    if (STATS) n_probe += act;
-                    if (qp >= 64u) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_wave_barrier();
-                        qp -= 64u;
-                        const uint64_t cn = pq[qp + lane];
-                        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe(cn, table, counts);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
+            // passing runs (rare): one at a time, their windows' positions go to the wave's
+            // window queue, which stage 2 consumes 64 at a time with every lane busy
+            unsigned long long m = __ballot(pass);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)pev[b].y, l);
+                const uint32_t len = ((inf >> 16) & 15u) + 1u, start = inf & 0x7FFFu;
+                if (lane < len) wq[qw + lane] = (uint16_t)(start + lane);
+                qw += len;
+                if (STATS) n_probe += lane < len;
+                if (qw >= 64u) probe_batch();
             }
         }
+        pn = 0;
+    };
+
+    auto issue = [&]() {                                          // start the next batch's filter loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        const uint32_t n = qe < 64u * SK_BATCH ? qe : 64u * SK_BATCH;
+        qe -= n;
+#pragma unroll
+        for (int b = 0; b < SK_BATCH; b++) {
+            if (lane + 64u * (uint32_t)b < n) {
+                pev[b] = evq[qe + lane + 64u * (uint32_t)b];
+                if (FILTER && ABLATE != 1) pblk[b] = table.bloom[pev[b].x & table.bloom_mask];
+                if (STATS) n_load += 1u;
+            }
+        }
+        pn = n;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // a drain site: judge what was issued at the previous site, issue what has queued up since
+    auto pump = [&]() {
+        do { complete(); issue(); } while (qe >= 64u);
     };
 
     // one event: a run of `len` live windows with minimizer `mz` starting at tile position `start`
@@ -279,6 +302,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
 
     const uint64_t pos0 = tile0 + (uint64_t)tid * SK_SPAN;       // stream position of span window 0
+    uint32_t run_mz = 0, run_start = 0, run_len = 0;              // current run of live windows sharing a minimizer
 
 #pragma unroll 1
     for (uint32_t j = 0; j < SK_SPAN_CH; j++) {
@@ -303,7 +327,6 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         if (STATS) n_live += (uint32_t)__popc(live16);
 
         const uint32_t ebase = tid * SK_SPAN + j * 16u;            // tile-relative index of offset 0
-        uint32_t run_mz = 0, run_start = 0, run_len = 0;
         uint32_t P = 0xFFFFFFFFu;
 #pragma unroll
         for (int o = 0; o < 16; o++) {
@@ -315,28 +338,28 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             P = h < P ? h : P;
             const uint32_t mz = S[o + 1] < P ? S[o + 1] : P;
             const bool lv = ((live16 >> o) & 1u) != 0u;
-            const bool end_run = (run_len != 0u) & (!lv | (mz != run_mz));
+            const bool end_run = (run_len != 0u) & (!lv | (mz != run_mz) | (run_len == 16u));
             push_event(end_run, run_mz, run_start, run_len);
             const bool fresh = lv & (end_run | (run_len == 0u));
             run_mz = fresh ? mz : run_mz;
             run_start = fresh ? ebase + (uint32_t)o : run_start;
             run_len = lv ? (fresh ? 1u : run_len + 1u) : 0u;
-            if (o == 7 && qe >= 64u) drain(false);
+            if (o == 7 && qe >= 64u) pump();
         }
-        push_event(run_len != 0u, run_mz, run_start, run_len);
-        if (qe >= 64u) drain(false);
+        if (qe >= 64u) pump();
 
         S[15] = H[15];
 #pragma unroll
         for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
     }
 
-    // ---- tail: everything still queued ---------------------------------------------------------
-    drain(true);
+    // ---- tail: the last run, then everything still queued or pending ---------------------------
+    push_event(run_len != 0u, run_mz, run_start, run_len);
+    while (pn != 0u || qe != 0u) { complete(); issue(); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane < qp) {
-        const uint64_t cn = pq[lane];
+    if (lane < qw) {
+        const uint64_t cn = sk_window_canon(rec, wq[lane]);
         if (ABLATE != 2 || cn == 0x123456789ull) sk_probe(cn, table, counts);
     }
     if (bad) atomicAdd(&flags[0], 1u);
