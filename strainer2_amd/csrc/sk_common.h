@@ -54,15 +54,17 @@ SK_HD uint32_t sk_hash62(uint64_t key)
 
 /* ---- minimizer-keyed placement (device table + prefilter) --------------------------------
  * Every 31-mer window contains w = 16 overlapping 16-mers (m = 16, 32 bits packed).  Its
- * "minimizer hash" mz is the minimum over those of sk_mhash(canonical 16-mer), canonical =
- * min(16-mer, its reverse complement): orientation-independent, so a window and the strain
- * key it equals get the same mz.  Consecutive windows mostly share their minimizer, so
+ * "minimizer hash" mz is the minimum over those of sk_mhash(16-mer, its reverse complement),
+ * a hash of the canonical (smaller) of the two: orientation-independent, so a window and the strain key it equals
+ * get the same mz.  Consecutive windows mostly share their minimizer, so
  * everything placed by mz (the prefilter block, the table line) is re-used ~w/2 times in a
  * row by the scanning lane.  sk_khash is a cheap per-k-mer hash for bits inside those. */
-SK_HD uint32_t sk_mhash(uint32_t c16)
+SK_HD uint32_t sk_mhash(uint32_t f16, uint32_t r16)
 {
-    uint32_t h = c16 * 0x9E3779B1u;
-    return h ^ (h >> 16);
+    /* canonical 16-mer = min(f, r); one multiply; top bit cleared so that 0xFFFFFFFF is never a
+     * hash.  (f ^ r or f + r instead of min() would be cheaper but are palindromic in the base
+     * positions: only 2^16 / 7^8 distinct values, which makes every minimizer collide.) */
+    return ((f16 < r16 ? f16 : r16) * 0x9E3779B1u) >> 1;
 }
 
 SK_HD uint32_t sk_khash(uint64_t key)
@@ -72,6 +74,10 @@ SK_HD uint32_t sk_khash(uint64_t key)
     x ^= x >> 15;
     return x * 0x9E3779B1u;                 /* use the HIGH bits */
 }
+
+/* minimizer filter: block index and the four test bits of a minimizer hash */
+SK_HD uint32_t sk_filter_block(uint32_t mz, uint32_t shift) { return (mz * 0x9E3779B1u) >> shift; }
+SK_HD uint32_t sk_filter_bits(uint32_t mz) { return mz * 0x85EBCA77u; }
 
 /* reverse complement of a packed 31-mer */
 SK_HD uint64_t sk_revcomp62(uint64_t key)
@@ -89,7 +95,7 @@ SK_HD uint32_t sk_minimizer62(uint64_t key)
     for (int i = 0; i < 16; i++) {
         const uint32_t f = (uint32_t)(key >> (2 * (15 - i)));
         const uint32_t r = (uint32_t)(rc >> (2 * i));
-        const uint32_t h = sk_mhash(f < r ? f : r);
+        const uint32_t h = sk_mhash(f, r);
         mz = h < mz ? h : mz;
     }
     return mz;

@@ -42,7 +42,7 @@
                                             // 12-dword lane stride keeps ds_read_b128 conflict-free
 #define SK_NCHUNK       (SK_NREC * SK_SPAN_CH)
 #define SK_EVQ          (64 + 9 * 64)       // minimizer-run events: drained below 64 twice per chunk
-#define SK_WQ           (64 + 16)           // tile positions of windows waiting for their table probe
+#define SK_WQ           (64 + 64)           // tile positions of windows waiting for their table probe
 #define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
 
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
@@ -55,7 +55,7 @@ struct sk_table_view {
     // (about nrows/8 items).  64-bit blocks chosen by the low bits of the minimizer hash,
     // two bits in each 32-bit half.
     const uint2    *bloom;
-    uint32_t        bloom_mask;      // number of 64-bit blocks - 1
+    uint32_t        bloom_shift;     // 32 - log2(number of 64-bit blocks)
 };
 
 // follow the probe sequence of `canon` from `slot` (first key already loaded)
@@ -81,7 +81,7 @@ __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t,
 // is minimizer hash `mz` (possibly) one of the strain's?  blk = its filter block
 __device__ __forceinline__ bool sk_filter_test(const uint2 blk, uint32_t mz)
 {
-    const uint32_t g = mz * 0x9E3779B1u;
+    const uint32_t g = sk_filter_bits(mz);
     const uint32_t t = (blk.x >> (g >> 27)) & (blk.x >> ((g >> 22) & 31u)) &
                        (blk.y >> ((g >> 17) & 31u)) & (blk.y >> ((g >> 12) & 31u));
     return (t & 1u) != 0u;
@@ -220,9 +220,9 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             const bool active = lane + 64u * (uint32_t)b < pn;
             bool pass = false;
             if (active) {
-                if (!FILTER) pass = true;
+                if (!FILTER) pass = pev[b].x != 0xFFFFFFFFu;
                 else if (ABLATE == 1) pass = pev[b].x == 0x12345u;
-                else pass = sk_filter_test(pblk[b], pev[b].x);
+                else pass = (pev[b].x != 0xFFFFFFFFu) && sk_filter_test(pblk[b], pev[b].x);
             }
             // passing runs (rare): one at a time, their windows' positions go to the wave's
             // window queue, which stage 2 consumes 64 at a time with every lane busy
@@ -231,11 +231,14 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 const int l = __builtin_ctzll(m);
                 m &= m - 1ull;
                 const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)pev[b].y, l);
-                const uint32_t len = ((inf >> 16) & 15u) + 1u, start = inf & 0x7FFFu;
-                if (lane < len) wq[qw + lane] = (uint16_t)(start + lane);
-                qw += len;
-                if (STATS) n_probe += lane < len;
-                if (qw >= 64u) probe_batch();
+                const uint32_t len = (inf >> 15) + 1u, start = inf & 0x7FFFu;
+                for (uint32_t k = 0; k < len; k += 64u) {         // a run is at most one span (128) long
+                    const uint32_t n = len - k < 64u ? len - k : 64u;
+                    if (lane < n) wq[qw + lane] = (uint16_t)(start + k + lane);
+                    qw += n;
+                    if (STATS) n_probe += lane < n;
+                    if (qw >= 64u) probe_batch();
+                }
             }
         }
         pn = 0;
@@ -250,7 +253,8 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         for (int b = 0; b < SK_BATCH; b++) {
             if (lane + 64u * (uint32_t)b < n) {
                 pev[b] = evq[qe + lane + 64u * (uint32_t)b];
-                if (FILTER && ABLATE != 1) pblk[b] = table.bloom[pev[b].x & table.bloom_mask];
+                if (FILTER && ABLATE != 1 && pev[b].x != 0xFFFFFFFFu)
+                    pblk[b] = table.bloom[sk_filter_block(pev[b].x, table.bloom_shift)];
                 if (STATS) n_load += 1u;
             }
         }
@@ -263,52 +267,51 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         do { complete(); issue(); } while (qe >= 64u);
     };
 
-    // one event: a run of `len` live windows with minimizer `mz` starting at tile position `start`
-    auto push_event = [&](bool cond, uint32_t mz, uint32_t start, uint32_t len) {
+    // one event = one maximal run of windows that share a minimizer hash (0xFFFFFFFF: a dead
+    // stretch, judged "no" without a lookup).  `rel` = chunk-relative offset of its first window
+    // (negative when it began in an earlier chunk), `o` = offset of the first window after it.
+    auto push_event = [&](bool cond, uint32_t mz, uint32_t ebase, int32_t rel, int o) {
         const unsigned long long m = __ballot(cond);
         if (m) {
             if (cond)
                 evq[qe + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                    make_uint2(mz, start | ((len - 1u) << 16));
+                    make_uint2(mz, (ebase + (uint32_t)rel) | ((uint32_t)(o - 1 - rel) << 15));
             qe += (uint32_t)__popcll(m);
         }
     };
 
-    const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;
-    const sk_u4 ca = *(const sk_u4 *)(my);
-    const sk_u4 cb = *(const sk_u4 *)(my + 4);
-    const sk_u4 iv = *(const sk_u4 *)(my + 8);
-    const uint32_t cw[8]  = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-    const uint32_t inv[8] = {iv.x & 0xFFFFu, iv.x >> 16, iv.y & 0xFFFFu, iv.y >> 16,
-                             iv.z & 0xFFFFu, iv.z >> 16, iv.w & 0xFFFFu, iv.w >> 16};
-    const uint32_t *pv = rec + tid * SK_REC_DW;
-    const uint32_t cw_m2 = pv[6], cw_m1 = pv[7];                  // the two chunks before the span
-    uint32_t vlo = pv[11];                                        // invalid masks of those two chunks
-
-    uint32_t f16 = cw_m2, r16 = sk_revcomp32(cw_m2);              // 16-mer ending at the last base of chunk -2
+    const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;           // this thread's record
+    const uint32_t *pv = rec + tid * SK_REC_DW;                   // the record before it
+    uint32_t cw_prev = pv[7];                                     // code word of the chunk before the span
+    uint32_t rc_prev = sk_revcomp32(cw_prev);
+    uint32_t vlo = pv[11];                                        // invalid masks of the two chunks before
     uint32_t S[17], H[16];
     S[16] = 0xFFFFFFFFu;
 
-    // warm-up over chunk -1: 16-mer hashes and their suffix minima
+    // warm-up over chunk -1: hashes of the 16-mers that end in it, and their suffix minima
+    {
+        const uint32_t cw2 = pv[6], rc2 = sk_revcomp32(cw2);
 #pragma unroll
-    for (int o = 0; o < 16; o++) {
-        const uint32_t code = (cw_m1 >> (30 - 2 * o)) & 3u;
-        f16 = (f16 << 2) | code;
-        r16 = __builtin_amdgcn_alignbit(code ^ 3u, r16, 2);
-        H[o] = sk_mhash(f16 < r16 ? f16 : r16);
+        for (int o = 0; o < 16; o++) {
+            const uint32_t f16 = o < 15 ? __builtin_amdgcn_alignbit(cw2, cw_prev, 30 - 2 * o) : cw_prev;
+            const uint32_t r16 = o < 15 ? __builtin_amdgcn_alignbit(rc_prev, rc2, 2 * o + 2) : rc_prev;
+            H[o] = sk_mhash(f16, r16);
+        }
+        S[15] = H[15];
+#pragma unroll
+        for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
     }
-    S[15] = H[15];
-#pragma unroll
-    for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
 
     const uint64_t pos0 = tile0 + (uint64_t)tid * SK_SPAN;       // stream position of span window 0
-    uint32_t run_mz = 0, run_start = 0, run_len = 0;              // current run of live windows sharing a minimizer
+    uint32_t run_mz = 0xFFFFFFFFu;                                // minimizer hash of the current run
+    int32_t  run_rel = 0;                                         // its first window, relative to the chunk
 
 #pragma unroll 1
     for (uint32_t j = 0; j < SK_SPAN_CH; j++) {
-        uint32_t cwj = cw[0], invj = inv[0];
-#pragma unroll
-        for (int t = 1; t < 8; t++) { cwj = (j == (uint32_t)t) ? cw[t] : cwj; invj = (j == (uint32_t)t) ? inv[t] : invj; }
+        const uint32_t cwj = my[j];
+        const uint32_t ipair = my[8u + (j >> 1)];
+        const uint32_t invj = (j & 1u) ? ipair >> 16 : ipair & 0xFFFFu;
+        const uint32_t rcj = sk_revcomp32(cwj);
 
         // live mask: bit o <=> the 31 bases ending at chunk offset o are all ACGT
         const uint64_t v = ~(((uint64_t)invj << 32) | vlo);       // valid bits: chunks j-2, j-1, j
@@ -325,28 +328,30 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             live16 = dlt >= 16u ? 0u : live16 & (0xFFFFu << (uint32_t)dlt);
         }
         if (STATS) n_live += (uint32_t)__popc(live16);
+        const uint32_t dead16 = ~live16;
 
         const uint32_t ebase = tid * SK_SPAN + j * 16u;            // tile-relative index of offset 0
         uint32_t P = 0xFFFFFFFFu;
 #pragma unroll
         for (int o = 0; o < 16; o++) {
-            const uint32_t code = (cwj >> (30 - 2 * o)) & 3u;
-            f16 = (f16 << 2) | code;
-            r16 = __builtin_amdgcn_alignbit(code ^ 3u, r16, 2);
-            const uint32_t h = sk_mhash(f16 < r16 ? f16 : r16);
+            // the 16-mer that ends at offset o and its reverse complement, straight from the words
+            const uint32_t f16 = o < 15 ? __builtin_amdgcn_alignbit(cw_prev, cwj, 30 - 2 * o) : cwj;
+            const uint32_t r16 = o < 15 ? __builtin_amdgcn_alignbit(rcj, rc_prev, 2 * o + 2) : rcj;
+            const uint32_t h = sk_mhash(f16, r16);
             H[o] = h;
             P = h < P ? h : P;
-            const uint32_t mz = S[o + 1] < P ? S[o + 1] : P;
-            const bool lv = ((live16 >> o) & 1u) != 0u;
-            const bool end_run = (run_len != 0u) & (!lv | (mz != run_mz) | (run_len == 16u));
-            push_event(end_run, run_mz, run_start, run_len);
-            const bool fresh = lv & (end_run | (run_len == 0u));
-            run_mz = fresh ? mz : run_mz;
-            run_start = fresh ? ebase + (uint32_t)o : run_start;
-            run_len = lv ? (fresh ? 1u : run_len + 1u) : 0u;
+            uint32_t mz = S[o + 1] < P ? S[o + 1] : P;
+            mz |= (uint32_t)__builtin_amdgcn_sbfe((int)dead16, o, 1);          // dead window: all ones
+            const bool chg = mz != run_mz;
+            push_event(chg, run_mz, ebase, run_rel, o);
+            run_rel = chg ? o : run_rel;
+            run_mz = mz;
             if (o == 7 && qe >= 64u) pump();
         }
         if (qe >= 64u) pump();
+        run_rel -= 16;
+        cw_prev = cwj;
+        rc_prev = rcj;
 
         S[15] = H[15];
 #pragma unroll
@@ -354,7 +359,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     }
 
     // ---- tail: the last run, then everything still queued or pending ---------------------------
-    push_event(run_len != 0u, run_mz, run_start, run_len);
+    push_event(true, run_mz, tid * SK_SPAN + SK_SPAN, run_rel, 0);
     while (pn != 0u || qe != 0u) { complete(); issue(); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -468,15 +473,15 @@ __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, uin
     }
 }
 
-__global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *bloom_words, uint32_t bloom_mask)
+__global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *bloom_words, uint32_t bloom_shift)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = in[i];
     if (k == SK_EMPTY64) return;
     const uint32_t mz = sk_minimizer62(k);
-    const uint32_t g = mz * 0x9E3779B1u;
-    uint32_t *blk = bloom_words + 2u * (size_t)(mz & bloom_mask);
+    const uint32_t g = sk_filter_bits(mz);
+    uint32_t *blk = bloom_words + 2u * (size_t)sk_filter_block(mz, bloom_shift);
     atomicOr(&blk[0], (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)));
     atomicOr(&blk[1], (1u << ((g >> 17) & 31u)) | (1u << ((g >> 12) & 31u)));
 }
@@ -658,7 +663,7 @@ extern "C" int sk_table_load(sk_ctx *c, const uint64_t *keys, uint32_t nrows, ui
             SK_HIP(c, hipMalloc((void **)&c->d_bloom, bbytes));
             SK_HIP(c, hipMemsetAsync(c->d_bloom, 0, bbytes, c->stream));
             hipLaunchKernelGGL(sk_bloom_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
-                               d_in, nrows, (uint32_t *)c->d_bloom, (uint32_t)(((uint64_t)1 << blocks_log2) - 1));
+                               d_in, nrows, (uint32_t *)c->d_bloom, 32u - blocks_log2);
             c->bloom_blocks_log2 = blocks_log2;
         }
         uint32_t flags[2] = {0, 0};
@@ -710,7 +715,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     sk_table_view tv;
     tv.keys = c->d_keys; tv.rowid = c->d_rowid; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
     tv.bloom = c->d_bloom;
-    tv.bloom_mask = c->bloom_blocks_log2 ? (uint32_t)(((uint64_t)1 << c->bloom_blocks_log2) - 1) : 0u;
+    tv.bloom_shift = 32u - c->bloom_blocks_log2;
     sk_wide_view wv;
     wv.keys31 = c->d_wide_keys; wv.rows = c->d_wide_rows; wv.index = c->d_wide_index;
     wv.wmask = c->wide_mask; wv.nwide = c->nwide;
