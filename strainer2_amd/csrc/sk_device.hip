@@ -41,7 +41,7 @@
 #define SK_REC_DW       12                  // per record: 8 code words (u32) + 8 invalid masks (u16) = 48 B;
                                             // 12-dword lane stride keeps ds_read_b128 conflict-free
 #define SK_NCHUNK       (SK_NREC * SK_SPAN_CH)
-#define SK_EVQ          (64 + 9 * 64)       // minimizer-run events: drained below 64 twice per chunk
+#define SK_EVQ          (64 + 5 * 64)       // minimizer-run events: drained below 64 every 4 windows
 #define SK_WQ           (64 + 64)           // tile positions of windows waiting for their table probe
 #define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
 
@@ -346,7 +346,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             push_event(chg, run_mz, ebase, run_rel, o);
             run_rel = chg ? o : run_rel;
             run_mz = mz;
-            if (o == 7 && qe >= 64u) pump();
+            if ((o & 3) == 3 && o != 15 && qe >= 64u) pump();
         }
         if (qe >= 64u) pump();
         run_rel -= 16;
