@@ -12,8 +12,9 @@
 //                     sk_scan_main saw such a window in the batch (device-side early exit).
 //
 // Data layout in HBM:
-//   keys   [S]  u64   open addressing, linear probing, S = 2^s slots, empty = all ones
-//   rowid  [S]  u32   row index of the key in that slot (read on hits only)
+//   slots  [S]  16 B  {u64 key, u32 row, u32 pad}: open addressing, linear probing, S = 2^s,
+//                     empty = key all ones.  Key and row id share a slot so that a hit costs one
+//                     random line fetch, not two.
 //   counts [ncols][nrows] u32
 //   stream      u8    record stream: sequence bytes, records separated by '\n'
 //
@@ -48,8 +49,7 @@
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
 
 struct sk_table_view {
-    const uint64_t *keys;
-    const uint32_t *rowid;
+    const sk_u4    *slots;           // {key lo, key hi, row, pad}
     uint32_t        mask;
     // L2-resident prefilter: a Bloom set of the MINIMIZER hashes that occur in the strain
     // (about nrows/8 items).  64-bit blocks chosen by the low bits of the minimizer hash,
@@ -58,24 +58,19 @@ struct sk_table_view {
     uint32_t        bloom_shift;     // 32 - log2(number of 64-bit blocks)
 };
 
-// follow the probe sequence of `canon` from `slot` (first key already loaded)
-__device__ __forceinline__ void sk_resolve(uint64_t canon, uint32_t slot, uint64_t key,
-                                           const sk_table_view &t, uint32_t *counts)
-{
-    for (;;) {
-        if (key == canon) { atomicAdd(&counts[t.rowid[slot]], 1u); return; }
-        if (key == SK_EMPTY64) return;
-        slot = (slot + 1u) & t.mask;
-        key = t.keys[slot];
-    }
-}
+__device__ __forceinline__ uint64_t sk_slot_key(const sk_u4 e) { return ((uint64_t)e.y << 32) | e.x; }
 
-// stage 2 for one queued window: slot from the k-mer hash, 62-bit compare, atomicAdd on a hit
+// stage 2 for one window: slot from the k-mer hash, linear probing, 62-bit compare, atomicAdd on a hit
 __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, uint32_t *counts)
 {
-    const uint32_t slot = sk_slot0(0u, sk_khash(canon), t.mask);
-    const uint64_t key = t.keys[slot];
-    if (key != SK_EMPTY64) sk_resolve(canon, slot, key, t, counts);
+    uint32_t slot = sk_slot0(0u, sk_khash(canon), t.mask);
+    for (;;) {
+        const sk_u4 e = t.slots[slot];
+        const uint64_t key = sk_slot_key(e);
+        if (key == canon) { atomicAdd(&counts[e.z], 1u); return; }
+        if (key == SK_EMPTY64) return;
+        slot = (slot + 1u) & t.mask;
+    }
 }
 
 // is minimizer hash `mz` (possibly) one of the strain's?  blk = its filter block
@@ -428,9 +423,7 @@ void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         if (opure) {                                   // e.g. a window with U whose revcomp wins
             uint64_t key = 0;
             for (int i = 0; i < SK_K; i++) key = (key << 2) | sk_code((uint8_t)o[i]);
-            const uint32_t slot = sk_slot0(sk_minimizer62(key), sk_khash(key), table.mask);
-            const uint64_t first = table.keys[slot];
-            if (first != SK_EMPTY64) sk_resolve(key, slot, first, table, counts);
+            sk_probe(key, table, counts);
         } else if (wide.nwide) {
             uint32_t slot = sk_hash_wide(o) & wide.wmask;
             for (;;) {
@@ -455,19 +448,18 @@ __global__ void sk_fill64(uint64_t *p, uint64_t n, uint64_t v)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-__global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, uint64_t *keys,
-                                uint32_t *rowid, uint32_t mask, uint32_t *flags)
+__global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_u4 *slots, uint32_t mask, uint32_t *flags)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = in[i];
     if (k == SK_EMPTY64) return;                       // wide row: not in this table
     if (k > SK_KMASK62) { atomicAdd(&flags[1], 1u); return; }
-    uint32_t slot = sk_slot0(sk_minimizer62(k), sk_khash(k), mask);
+    uint32_t slot = sk_slot0(0u, sk_khash(k), mask);
     for (;;) {
-        const unsigned long long old = atomicCAS((unsigned long long *)&keys[slot],
+        const unsigned long long old = atomicCAS((unsigned long long *)&slots[slot],
                                                 (unsigned long long)SK_EMPTY64, (unsigned long long)k);
-        if (old == SK_EMPTY64) { rowid[slot] = i; return; }
+        if (old == SK_EMPTY64) { ((uint32_t *)&slots[slot])[2] = i; return; }
         if (old == k) { atomicAdd(&flags[1], 1u); return; }     // duplicate key
         slot = (slot + 1u) & mask;
     }
@@ -496,8 +488,7 @@ struct sk_ctx {
     int          device;
     hipStream_t  stream;
     // table
-    uint64_t    *d_keys;
-    uint32_t    *d_rowid;
+    sk_u4       *d_keys;              // the slot array (name kept: "is a table loaded" checks)
     uint32_t     slots_log2;
     uint2       *d_bloom;
     uint32_t     bloom_blocks_log2;       // 0 = no prefilter
@@ -591,7 +582,6 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
 static void sk_table_release(sk_ctx *c)
 {
     hipFree(c->d_keys); c->d_keys = NULL;
-    hipFree(c->d_rowid); c->d_rowid = NULL;
     hipFree(c->d_bloom); c->d_bloom = NULL;
     hipFree(c->d_counts); c->d_counts = NULL;
     hipFree(c->d_wide_keys); c->d_wide_keys = NULL;
@@ -638,20 +628,18 @@ extern "C" int sk_table_load(sk_ctx *c, const uint64_t *keys, uint32_t nrows, ui
     while (((uint64_t)1 << lg) * (uint64_t)c->table_load_pct < (uint64_t)nrows * 100ull && lg < 31) lg++;
     const uint64_t slots = (uint64_t)1 << lg;
     c->slots_log2 = lg;
-    SK_HIP(c, hipMalloc((void **)&c->d_keys, slots * sizeof(uint64_t)));
-    SK_HIP(c, hipMalloc((void **)&c->d_rowid, slots * sizeof(uint32_t)));
+    SK_HIP(c, hipMalloc((void **)&c->d_keys, slots * sizeof(sk_u4)));
     const size_t cbytes = (size_t)(nrows ? nrows : 1) * ncols * sizeof(uint32_t);
     SK_HIP(c, hipMalloc((void **)&c->d_counts, cbytes));
     SK_HIP(c, hipMemsetAsync(c->d_counts, 0, cbytes, c->stream));
-    SK_HIP(c, hipMemsetAsync(c->d_rowid, 0, slots * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(sk_fill64, dim3(2048), dim3(256), 0, c->stream, c->d_keys, slots, SK_EMPTY64);
+    hipLaunchKernelGGL(sk_fill64, dim3(2048), dim3(256), 0, c->stream, (uint64_t *)c->d_keys, 2 * slots, SK_EMPTY64);
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 16 * sizeof(uint32_t), c->stream));
     if (nrows) {
         uint64_t *d_in = NULL;
         SK_HIP(c, hipMalloc((void **)&d_in, (size_t)nrows * sizeof(uint64_t)));
         SK_HIP(c, hipMemcpyAsync(d_in, keys, (size_t)nrows * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(sk_table_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
-                           d_in, nrows, c->d_keys, c->d_rowid, (uint32_t)(slots - 1), c->d_flags);
+                           d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags);
         // minimizer filter: automatic size = smallest power of two >= 4 bits per key (the set holds
         // ~nrows/8 minimizers, i.e. ~32 bits each: false positives ~0.1 %); 2 MiB for a 5 Mbp strain
         long bb = c->bloom_bits_log2;
@@ -713,7 +701,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     const uint64_t ntiles = (nbytes + SK_TILE - 1) / SK_TILE;
     if (ntiles > 0x7FFFFFFFull) return sk_fail(c, SK_E_ARG, "batch too large");
     sk_table_view tv;
-    tv.keys = c->d_keys; tv.rowid = c->d_rowid; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
+    tv.slots = c->d_keys; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
     tv.bloom = c->d_bloom;
     tv.bloom_shift = 32u - c->bloom_blocks_log2;
     sk_wide_view wv;
