@@ -162,6 +162,18 @@ def main():
     assert args.ablate or (int(counts.sum()) % args.steps == 0 and np.all(counts % args.steps == 0)), "counts not K x one pass"
     hits_per_pass = int(counts.sum()) // args.steps
 
+    # PCIe-inclusive rate (host buffer -> pinned staging -> H2D -> scan), reported beside `value`,
+    # never as it: 2 passes of sk_scan_stream over the same record stream
+    host_rate = None
+    if world == 1 and not args.ablate:
+        ctx.scan_stream(reads[: 64 << 20], 3)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            ctx.scan_stream(reads, 3)
+        ctx.sync()
+        host_rate = 2 * nbases / (time.perf_counter() - t1)
+
     if args.stats and rank == 0:
         st = ctx.scan_stats()
         n = args.steps + args.warmup
@@ -189,6 +201,7 @@ def main():
                                    "reads resident in HBM as a record stream" % (args.reads, args.read_len),
                        "strain_keys": int(ks.nrows), "reads_per_gpu": args.reads, "read_len": args.read_len,
                        "bases_per_step_per_gpu": nbases, "hits_per_pass_rank0_or_sum": hits_per_pass,
+                       "pcie_inclusive_bases_per_s_host_buffers": host_rate,
                        "sharding": "reads sharded by rank, table replicated, one RCCL all-reduce of counts" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
