@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--bloom-bits-log2", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments: 1 = no filter/table memory, 2 = no table probes (counts are wrong)")
     ap.add_argument("--stats", action="store_true", help="debug counters (slower kernel variant)")
     args = ap.parse_args()
@@ -107,13 +108,17 @@ def main():
     import torch.distributed as dist
     import strainer2_amd as sk
 
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(torch.cuda.device_count(), 1)      # (rehearsal: more ranks than GPUs share a card)
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     ks = sk.Keyset.from_stream(sstream)
-    ctx = sk.KmerContext(local_rank)
+    ctx = sk.KmerContext(device)
     if args.bloom_bits_log2 is not None:
         ctx.set_option("bloom_bits_log2", args.bloom_bits_log2)
     if args.stats:
@@ -159,6 +164,12 @@ def main():
     # for N > 1 after the all-reduce, the sum over ranks); one pass is checked against the oracle
     # in tests/ and smoke().  Here: every count is a multiple of K and the total is sane.
     counts = ctx.counts(2)
+    if world > 1:                                   # every rank must hold the same reduced table
+        chk = torch.tensor([int(counts.astype(np.uint64).sum())], dtype=torch.int64, device="cuda")
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert int(lo.item()) == int(hi.item()), "ranks disagree after the all-reduce"
     assert args.ablate or (int(counts.sum()) % args.steps == 0 and np.all(counts % args.steps == 0)), "counts not K x one pass"
     hits_per_pass = int(counts.sum()) // args.steps
 
