@@ -18,6 +18,7 @@
 #define _GNU_SOURCE
 #include "kso_oracle.h"
 #include <ctype.h>
+#include <errno.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -593,6 +594,288 @@ int kso_main(int argc, char **argv, FILE *out, FILE *err)
     if (progress) fclose(progress);
     return 0;
 }
+
+/* ==================================================================================== */
+/* strain_detect restatement: src/strain_detect.c (whole file)                          */
+
+enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
+enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
+
+static int sd_file_type(const char *s)                    /* src/strain_detect.c:728-747 */
+{
+    if (!strcmp(s, "SE") || !strcmp(s, "se")) return SD_SE;
+    if (!strcmp(s, "PE") || !strcmp(s, "pe")) return SD_PE;
+    if (!strcmp(s, "PEI") || !strcmp(s, "pei") || !strcmp(s, "IPE") || !strcmp(s, "ipe")) return SD_PEI;
+    return SD_UNKNOWN;
+}
+
+static void sd_usage(FILE *err)                           /* src/strain_detect.c:750-764 */
+{
+    fputs("Usage paired end with 2 files:\n\tstrain_detect -r <reference_genome.fna> -a <informative_kmer_file.txt> -b <paired-end-file1> -c <paired-end-file1> -t PE -o <kmer outfile>\n", err);
+    fputs("Usage paired end interleaved 1 file:\n\tstrain_detect -r <reference_genome.fna> -a <informative_kmer_file.txt> -b <paired-end-file1>  -t PEI -o <kmer outfile>\n", err);
+    fputs("Usage single end 1 file:\n\tstrain_detect -r <reference_genome.fna> -a <informative_kmer_file.txt> -b <single-end-file1>  -t SE -o <kmer outfile>\n", err);
+    fputs("Usage single end 1 file:\n\tstrain_detect -r <reference_genome.fna> -a <informative_kmer_file.txt> -B <batch-list-of-metagenomes> -o <kmer outfile>\n\n", err);
+    fputs("format for metagenomics batch file is:\n", err);
+    fputs("PE\tfile1_PE1.fasta\tfile1_PE2.fasta\n", err);
+    fputs("SE\tfile1_PE1.fasta\n", err);
+    fputs("PEI\tfile1_PE1.fasta\n", err);
+    fputs("\nlines that begin with # are considered comments and ignored\n", err);
+    fputs("\ninformative kmer file is a list of all of the kmers left in the reference genome post scrubbing\n", err);
+}
+
+/* flag the listed k-mers as informative: src/strain_detect.c:668-726 (gzgets in 99-byte pieces,
+ * no case folding, '#' lines skipped, every piece whose length is not k reported on stdout) */
+static int sd_flag_informative(kso_table *t, const char *path, int k, FILE *out, FILE *err, unsigned *n_out)
+{
+    gzFile g = gzopen(path, "r");
+    char line[100], *rcbuf = (char *)malloc(101), *nl;
+    unsigned n = 0;
+    if (!g) { fprintf(err, "could not read file %s in hash_scrubbed_kmers()\n", path); free(rcbuf); return 1; }
+    while (gzgets(g, line, 100)) {
+        if (line[0] == '#') continue;
+        if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
+        if ((int)strlen(line) == k) {
+            unsigned *vec = table_find(t, orient(line, rcbuf, k));
+            if (vec) { vec[SD_TYPE] = SD_INFORMATIVE; n++; }
+            else fprintf(out, "error could not find informative kmer %s in the total kmer list\n", line);
+        } else {
+            fprintf(out, "error string length in the scrubbed kmer file (%s) must be the same size as the kmer length "
+                         "(scrubbed kmer, scrubbed kmer len, seed len): %s, %d, %d\n", path, line, (int)strlen(line), k);
+        }
+    }
+    free(rcbuf);
+    gzclose(g);
+    *n_out = n;
+    return 0;
+}
+
+static int sd_cmp_desc(const void *a, const void *b) { return (int)(*(const unsigned *)b - *(const unsigned *)a); }
+
+static int sd_removed(unsigned threshold, const unsigned *c, unsigned n)
+{
+    unsigned i; int r = 0;
+    for (i = 0; i < n; i++) if (c[i] >= threshold) r++;
+    return r;
+}
+
+/* -g: src/strain_detect.c:160-240 */
+static int sd_background_filter(kso_table *t, const char *list, double fraction, unsigned n_inform, int k,
+                                FILE *out, FILE *err)
+{
+    unsigned keep = (unsigned)(int)(n_inform * fraction), *c = (unsigned *)calloc(n_inform ? n_inform : 1, sizeof *c);
+    unsigned i, n = 0, threshold = 1;
+    int demoted = 0;
+    fprintf(out, "#removing %f proportion of %s kmers; informative %d keep at least %d\n", fraction, list, n_inform, keep);
+    if (kso_scan_list(t, list, NULL, k, SD_BACKGROUND, NULL, err, NULL) != KSO_OK) { free(c); return 1; }
+    for (i = 0; i < t->M; i++) {
+        const unsigned *v = t->slot[i].vec;
+        if (!v || v[SD_TYPE] != SD_INFORMATIVE) continue;
+        if (n >= n_inform) { fputs("Error: too many background kmers\n", err); free(c); return 1; }
+        c[n++] = v[SD_BACKGROUND];
+    }
+    qsort(c, n_inform, sizeof *c, sd_cmp_desc);
+    if (keep >= 1 && c[keep - 1] > threshold) threshold = c[keep - 1];
+    while ((unsigned)sd_removed(threshold, c, n_inform) > keep) threshold++;
+    for (i = 0; i < t->M; i++) {
+        unsigned *v = t->slot[i].vec;
+        if (v && v[SD_TYPE] == SD_INFORMATIVE && v[SD_BACKGROUND] >= threshold) { v[SD_TYPE] = SD_PLAIN; demoted++; }
+    }
+    fprintf(out, "#final_threshold %d removes %d background kmers %d removed\n", threshold, sd_removed(threshold, c, n_inform), demoted);
+    free(c);
+    return 0;
+}
+
+/* whole-read reverse complement through the complement map: src/BIO_sequence.c:244-253 */
+static void sd_revcomp(char *dst, const char *src, size_t l)
+{
+    size_t i;
+    for (i = 0; i < l; i++) dst[l - 1 - i] = (char)g_comp[(unsigned char)src[i]];
+    dst[l] = '\0';
+}
+
+/* tally pass over one read: src/strain_detect.c:455-492 / 509-540.  Orientation here is
+ * strcmp(window, rc_window) > 0 ? window : rc_window on the pre-reversed read. */
+static void sd_tally(kso_table *t, char *s, size_t l, int k, char *rc, int *hits, int *inf, unsigned long long *evaluated)
+{
+    size_t i;
+    int has_n;
+    char *w = s, *r;
+    sd_revcomp(rc, s, l);
+    r = rc + (l - (size_t)k);
+    has_n = has_enn(s);
+    for (i = 0; i + (size_t)k <= l; i++) {
+        char keep = w[k];
+        const char *o;
+        w[k] = '\0';
+        r[k] = '\0';
+        o = strcmp(w, r) > 0 ? w : r;
+        if (!has_n || !has_enn(o)) {
+            const unsigned *vec = table_find(t, o);
+            if (vec) { (*hits)++; if (vec[SD_TYPE] == SD_INFORMATIVE) (*inf)++; }
+        }
+        w[k] = keep;
+        w++;
+        r--;
+        (*evaluated)++;
+    }
+}
+
+/* emission pass over one read: src/strain_detect.c:552-585 / 590-621 */
+static void sd_emit(kso_table *t, char *s, size_t l, int k, char *rcbuf, gzFile gz, const char *name,
+                    int h1, int i1, int h2, int i2)
+{
+    size_t i;
+    if (l < (size_t)k) return;
+    for (i = 0; i + (size_t)k <= l; i++) {
+        char *w = s + i, keep = w[k];
+        const char *o;
+        w[k] = '\0';
+        o = orient(w, rcbuf, k);
+        if (!has_enn(o)) {
+            const unsigned *vec = table_find(t, o);
+            if (vec && vec[SD_TYPE] == SD_INFORMATIVE) gzprintf(gz, "%s\t%d\t%d\t%d\t%d\t%s\n", name, h1, i1, h2, i2, o);
+        }
+        w[k] = keep;
+    }
+}
+
+/* one metagenome (pair): src/strain_detect.c:387-663, including its carry-over behaviour: the
+ * per-read tallies and the PE1 copy are only refreshed for reads of at least k bases, so a short
+ * read inherits the previous read's tallies and sequence. */
+static int sd_quantify(kso_table *t, const char *f1, const char *f2, int k, gzFile gz, int mode,
+                       unsigned genome_kmers, unsigned genome_inf, FILE *err)
+{
+    kso_reader *r1 = rd_open_file(f1), *r2 = NULL;
+    kso_buf copy = { NULL, 0, 0 }, rc = { NULL, 0, 0 };
+    char *rcbuf = (char *)malloc((size_t)k + 1);
+    int h1 = 0, i1 = 0, h2 = 0, i2 = 0;
+    size_t copy_len = 0;
+    unsigned long long evaluated = 0, reads = 0;
+    long l, l2;
+    if (!r1) { fprintf(err, "could not read file (read1) %s in quantify_hits_PE() (error: %s)\n", f1, strerror(errno)); return 1; }
+    if (mode == SD_PE) {
+        r2 = rd_open_file(f2);
+        if (!r2) { fprintf(err, "could not read file (read2) is_PE %s in quantify_hits_PE() (error: (null))\n", f2); return 1; }
+    } else if (mode == SD_PEI) r2 = r1;
+    while ((l = rd_record(r1)) >= 0) {
+        if (r1->seq.len >= (size_t)k) {
+            reads++;
+            h1 = i1 = 0;
+            copy_len = r1->seq.len;
+            upcase(r1->seq.p);
+            copy.len = 0; buf_reserve(&copy, copy_len); memcpy(copy.p, r1->seq.p, copy_len + 1);
+            rc.len = 0; buf_reserve(&rc, copy_len + 1);
+            sd_tally(t, r1->seq.p, copy_len, k, rc.p, &h1, &i1, &evaluated);
+        }
+        if (mode != SD_SE) {
+            l2 = rd_record(r2);
+            if (r2->seq.len >= (size_t)k) {
+                h2 = i2 = 0;
+                if (l2 < 0) {
+                    fprintf(err, "reached end of PE2 (%s) before end of PE1 (%s), check that file names are correct\n",
+                            f2 ? f2 : "(null)", f1);
+                    return 1;
+                }
+                upcase(r2->seq.p);
+                rc.len = 0; buf_reserve(&rc, r2->seq.len + 1);
+                sd_tally(t, r2->seq.p, r2->seq.len, k, rc.p, &h2, &i2, &evaluated);
+            }
+        }
+        if (h1 + h2 >= 1 && i1 + i2 >= 1) {
+            if (copy.p) sd_emit(t, copy.p, copy_len, k, rcbuf, gz, f1, h1, i1, h2, i2);
+            if (mode != SD_SE) sd_emit(t, r2->seq.p, r2->seq.len, k, rcbuf, gz, f1, h1, i1, h2, i2);
+        }
+    }
+    gzprintf(gz, "#%s\ttotal_kmer_evaluated\t%lld\n", f1, evaluated);
+    gzprintf(gz, "#%s\ttotal_reads_evaluated\t%lld\n", f1, reads);
+    gzprintf(gz, "#%s\ttotal_genome_kmers\t%lld\n", f1, (long long)genome_kmers);
+    gzprintf(gz, "#%s\ttotal_genome_informative_kmers\t%lld\n", f1, (long long)genome_inf);
+    free(copy.p); free(rc.p); free(rcbuf);
+    if (r2 && r2 != r1) rd_close(r2);
+    rd_close(r1);
+    return 0;
+}
+
+int ksd_main(int argc, char **argv, FILE *out, FILE *err)
+{
+    const int k = 31;
+    const char *a = NULL, *r = NULL, *b = NULL, *b2 = NULL, *B = NULL, *tt = NULL, *g = NULL, *o = NULL;
+    int c, mode = SD_SE, rc;
+    unsigned n_inform = 0, i, genome_inf = 0;
+    kso_table *t;
+    gzFile gz;
+
+    optind = 1;
+    while ((c = getopt(argc, argv, "g:r:a:A:b:c:B:S:M:o:t:Hhuspn")) != -1) {
+        switch (c) {
+        case 'a': a = optarg; break;
+        case 'A': break;
+        case 'b': b = optarg; break;
+        case 'c': b2 = optarg; break;
+        case 'B': B = optarg; break;
+        case 'r': r = optarg; break;
+        case 'g': g = optarg; break;
+        case 'o': o = optarg; break;
+        case 'n': mode = SD_SE; break;
+        case 't': tt = optarg; break;
+        default:  sd_usage(err); break;
+        }
+    }
+    if (!a || !o || !r) { sd_usage(err); return 1; }
+    if (!b && !B) { sd_usage(err); return 1; }
+    if (tt) {
+        mode = sd_file_type(tt);
+        if (mode == SD_UNKNOWN) { fputs("unknown filetype specification. allowed are SE, PE, PEI\n\n", out); sd_usage(err); return 1; }
+    }
+    if (b && mode == SD_PE && !b2) {
+        fputs("commandline PE mapping requires two files (-b [file1] and -c [file2])\n\n", out); sd_usage(err); return 1;
+    }
+    if (b && B) {
+        fputs("cannot have -B flag and -b flag\nEither have a file with metagenomics files to be detect the strain in or "
+              "specify one metagenomic file to detect the strain in\n", out);
+        sd_usage(err); return 1;
+    }
+    t = kso_table_new(KSO_DEFAULT_CAPACITY);
+    rc = kso_build_from_file(t, r, k, SD_PLAIN, 0, 0, SD_NCOLS, 0);
+    if (rc == KSO_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", r); return 1; }
+    if (rc == KSO_E_SHORT_CONTIG) return 139;
+    if (sd_flag_informative(t, a, k, out, err, &n_inform)) return 1;
+    if (g && sd_background_filter(t, g, 0.5, n_inform, k, out, err)) return 1;
+
+    for (i = 0; i < t->M; i++) if (t->slot[i].vec && t->slot[i].vec[SD_TYPE] == SD_INFORMATIVE) genome_inf++;
+    gz = gzopen(o, "wb9");
+    if (!gz) { fprintf(err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
+    if (B) {
+        FILE *fp = fopen(B, "r");
+        char *line = NULL, *nl, *tok, *f1, *f2;
+        size_t cap = 0;
+        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); return 1; }
+        while (getline(&line, &cap, fp) != -1) {
+            int m;
+            if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
+            tok = strtok(line, "\t");
+            if (!tok) { gzclose(gz); return 139; }          /* reference: strcmp(NULL, ...) */
+            m = sd_file_type(tok);
+            if (m == SD_UNKNOWN) { fprintf(out, "unknown file type skipping line (%s)\n", tok); continue; }
+            f1 = strtok(NULL, "\t");
+            if (!f1) { fprintf(out, "ERROR: no first file specified for %s\n", line); continue; }
+            if (m == SD_PE) {
+                f2 = strtok(NULL, "\t");
+                if (!f2) { fprintf(out, "ERROR: no second file specified for PE: %s\n", line); continue; }
+                if (sd_quantify(t, f1, f2, k, gz, m, t->N, genome_inf, err)) { gzclose(gz); return 1; }
+            } else if (sd_quantify(t, f1, NULL, k, gz, m, t->N, genome_inf, err)) { gzclose(gz); return 1; }
+        }
+        free(line);
+        fclose(fp);
+    } else if (sd_quantify(t, b, b2, k, gz, mode, t->N, genome_inf, err)) { gzclose(gz); return 1; }
+    gzclose(gz);
+    kso_table_free(t);
+    return 0;
+}
+
+#ifdef KSD_MAIN
+int main(int argc, char **argv) { return ksd_main(argc, argv, stdout, stderr); }
+#endif
 
 #ifdef KSO_MAIN
 int main(int argc, char **argv)

@@ -78,6 +78,12 @@ void  kso_free(void *p);
 /* Whole-program restatement: argv as the reference's kmer_scrub_count. Returns exit status. */
 int kso_main(int argc, char **argv, FILE *out, FILE *err);
 
+/* Whole-program restatement of the reference's strain_detect (src/strain_detect.c): argv as the
+ * reference, messages the reference prints on stdout go to `out`, stderr texts to `err`, the
+ * gz result file is written with zlib level 9 like the reference.  Returns the exit status
+ * (139 where the reference would crash on a NULL token). */
+int ksd_main(int argc, char **argv, FILE *out, FILE *err);
+
 #ifdef __cplusplus
 }
 #endif

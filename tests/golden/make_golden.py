@@ -25,6 +25,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF_BIN = os.path.join(REPO, "oracle", "_ref", "kmer_scrub_count")
+REF_SD = os.path.join(REPO, "oracle", "_ref", "strain_detect")
+SD_CASES = os.path.join(HERE, "sd_cases")
 REF_TEST = "/root/reference/test"
 CASES = os.path.join(HERE, "cases")
 BUNDLED = os.path.join(HERE, "bundled")
@@ -75,11 +77,136 @@ def run_case(name, argv, note):
     print(f"{name}: rc={p.returncode} stdout={len(p.stdout)}B stderr={len(p.stderr)}B")
 
 
+def run_sd_case(name, argv, note):
+    """strain_detect golden: stdout, stderr, status and the DECOMPRESSED -o file."""
+    d = os.path.join(SD_CASES, name)
+    p = subprocess.run([REF_SD] + argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    with open(os.path.join(d, "expected.stdout"), "wb") as f:
+        f.write(p.stdout)
+    with open(os.path.join(d, "expected.stderr"), "wb") as f:
+        f.write(p.stderr)
+    hits = None
+    if "-o" in argv:
+        of = os.path.join(d, argv[argv.index("-o") + 1])
+        if os.path.exists(of):
+            with gzip.open(of, "rb") as f:
+                hits = f.read()
+            os.remove(of)
+            with open(os.path.join(d, "expected.hits"), "wb") as f:
+                f.write(hits)
+    with open(os.path.join(d, "case.json"), "w") as f:
+        json.dump({"argv": argv, "returncode": p.returncode, "note": note, "has_hits": hits is not None}, f, indent=1)
+    print(f"sd/{name}: rc={p.returncode} stdout={len(p.stdout)}B stderr={len(p.stderr)}B hits={None if hits is None else len(hits)}B")
+
+
+def canon(k):
+    r = rc(k)
+    return k if k >= r else r
+
+
+def make_sd_cases():
+    if os.path.isdir(SD_CASES):
+        shutil.rmtree(SD_CASES)
+    rng = random.Random(0x5D5D)
+    strain = rand_dna(rng, 1500)
+    strain = strain[:700] + "N" + strain[701:]
+    kmers = [strain[i:i + 31] for i in range(0, len(strain) - 30) if "N" not in strain[i:i + 31]]
+    inf = [kmers[i] for i in range(0, len(kmers), 9)]                 # every 9th k-mer is "informative"
+
+    def reads_from(n, seed, lens=(31, 60, 100, 151)):
+        r = random.Random(seed)
+        out = []
+        for i in range(n):
+            ln = r.choice(lens)
+            if r.random() < 0.7:
+                a = r.randrange(0, len(strain) - ln)
+                s = strain[a:a + ln]
+                if r.random() < 0.5:
+                    s = rc(s.replace("N", "A"))
+            else:
+                s = rand_dna(r, ln)
+            if i % 6 == 5:
+                s = s[:r.choice((5, 20, 30))]                          # short read: carries the previous tallies
+            if i % 10 == 3:
+                s = s[:10] + "N" + s[11:]
+            if i % 13 == 7:
+                s = s.lower()
+            out.append(s)
+        return out
+
+    def fasta(reads, tag):
+        return "".join(f">{tag}{i}\n{r}\n" for i, r in enumerate(reads))
+
+    def fastq(reads, tag):
+        return "".join(f"@{tag}{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads))
+
+    # ------------------------------------------------------------ batch list with everything
+    d = os.path.join(SD_CASES, "batch")
+    write(os.path.join(d, "strain.fa"), ">s\n" + wrap(strain, 70) + "\n")
+    lines = ["# informative k-mers", "#second comment"] + inf[:40] + [rc(inf[40]), inf[41].lower(), inf[5], "ACGT",
+             rand_dna(rng, 31), inf[42] + "A"] + inf[43:]
+    write(os.path.join(d, "inf.txt.gz"), "\n".join(lines) + "\n", gz=True)
+    r1, r2 = reads_from(60, 1), reads_from(60, 2)
+    write(os.path.join(d, "pe_1.fa"), fasta(r1, "a"))
+    write(os.path.join(d, "pe_2.fa"), fasta(r2, "b"))
+    se = reads_from(50, 3)
+    write(os.path.join(d, "se.fq.gz"), fastq(se, "s"), gz=True)
+    il = reads_from(40, 4)
+    write(os.path.join(d, "il.fa"), fasta(il, "i"))
+    short2 = reads_from(30, 5)
+    write(os.path.join(d, "pe_short2.fa"), fasta(short2[:20], "c"))           # PE2 runs out early (FASTA)
+    write(os.path.join(d, "B.txt"), "PE\tpe_1.fa\tpe_2.fa\nSE\tse.fq.gz\n#comment line\nXX\tfoo\nPEI\til.fa\nse\tpe_1.fa\n"
+                                    "PE\tpe_1.fa\nSE\nPE\tpe_2.fa\tpe_short2.fa\n")
+    run_sd_case("batch", ["-r", "strain.fa", "-a", "inf.txt.gz", "-B", "B.txt", "-o", "hits.gz"],
+                "SE/PE/PEI, comments and unknown types in -B, short reads inheriting tallies, PE2 ending early, "
+                "odd lines in the informative list")
+
+    # ------------------------------------------------------------ command-line forms
+    for name, extra in (("cli_se", ["-b", "se.fq.gz", "-t", "SE"]), ("cli_pe", ["-b", "pe_1.fa", "-c", "pe_2.fa", "-t", "PE"]),
+                        ("cli_pei", ["-b", "il.fa", "-t", "pei"]), ("cli_default", ["-b", "pe_1.fa"])):
+        dd = os.path.join(SD_CASES, name)
+        os.makedirs(dd, exist_ok=True)
+        for f in ("strain.fa", "inf.txt.gz", "pe_1.fa", "pe_2.fa", "se.fq.gz", "il.fa"):
+            shutil.copyfile(os.path.join(d, f), os.path.join(dd, f))
+        run_sd_case(name, ["-r", "strain.fa", "-a", "inf.txt.gz"] + extra + ["-o", "out.gz"], "single metagenome on the command line")
+
+    # ------------------------------------------------------------ background filter (-g)
+    dd = os.path.join(SD_CASES, "background")
+    os.makedirs(dd, exist_ok=True)
+    for f in ("strain.fa", "pe_1.fa", "pe_2.fa", "se.fq.gz"):
+        shutil.copyfile(os.path.join(d, f), os.path.join(dd, f))
+    write(os.path.join(dd, "inf.txt"), "\n".join(inf) + "\n")
+    bg = reads_from(80, 9, lens=(151,))
+    write(os.path.join(dd, "bg1.fa"), fasta(bg[:40], "g"))
+    write(os.path.join(dd, "bg2.fa"), fasta(bg[40:], "h"))
+    write(os.path.join(dd, "bg.txt"), "bg1.fa\nbg2.fa\n")
+    write(os.path.join(dd, "B.txt"), "PE\tpe_1.fa\tpe_2.fa\nSE\tse.fq.gz\n")
+    run_sd_case("background", ["-r", "strain.fa", "-a", "inf.txt", "-g", "bg.txt", "-B", "B.txt", "-o", "hits.gz"],
+                "-g demotes informative k-mers that are frequent in the background metagenomes")
+
+    # ------------------------------------------------------------ argument errors
+    dd = os.path.join(SD_CASES, "errors")
+    os.makedirs(dd, exist_ok=True)
+    for f in ("strain.fa", "inf.txt.gz", "pe_1.fa"):
+        shutil.copyfile(os.path.join(d, f), os.path.join(dd, f))
+    for name, argv in (("err_missing", ["-r", "strain.fa", "-a", "inf.txt.gz"]),
+                       ("err_type", ["-r", "strain.fa", "-a", "inf.txt.gz", "-b", "pe_1.fa", "-t", "XX", "-o", "o.gz"]),
+                       ("err_pe_one_file", ["-r", "strain.fa", "-a", "inf.txt.gz", "-b", "pe_1.fa", "-t", "PE", "-o", "o.gz"]),
+                       ("err_b_and_B", ["-r", "strain.fa", "-a", "inf.txt.gz", "-b", "pe_1.fa", "-B", "x", "-o", "o.gz"]),
+                       ("err_no_inf", ["-r", "strain.fa", "-a", "nope.gz", "-b", "pe_1.fa", "-o", "o.gz"]),
+                       ("err_no_read1", ["-r", "strain.fa", "-a", "inf.txt.gz", "-b", "nope.fa", "-o", "o.gz"])):
+        d3 = os.path.join(SD_CASES, name)
+        shutil.copytree(dd, d3)
+        run_sd_case(name, argv, "argument / file errors")
+    shutil.rmtree(dd)
+
+
 def main():
     if not os.path.exists(REF_BIN):
         sys.exit("build the reference first: make -C oracle ref")
     if os.path.isdir(CASES):
         shutil.rmtree(CASES)
+    make_sd_cases()
     rng = random.Random(0x5EED31)
 
     # ---------------------------------------------------------------- case: mixed
@@ -228,6 +355,22 @@ def main():
              "rows_with_ref_gt1_pan_gt0_meta_gt0": nz}
     with open(os.path.join(BUNDLED, "step1_facts.json"), "w") as f:
         json.dump(facts, f, indent=1)
+    # step 3 (strain_detect) needs step 2's k-mer list: strains/B8.scrubbed_kmers.gz is the output of the
+    # reference's scripts/kmer_scrub_filter.py -m 0.01 on the step-1 TSV (md5 fe981fa5..., generated once
+    # in the build container and kept as a data fixture)
+    scrub = "strains/B8.scrubbed_kmers.gz"
+    if os.path.exists(os.path.join(BUNDLED, scrub)):
+        argv3 = ["-r", strain, "-a", scrub, "-B", "target_metagenomes.txt", "-o", "step3_hits.gz"]
+        p3 = subprocess.run([REF_SD] + argv3, cwd=BUNDLED, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        with gzip.open(os.path.join(BUNDLED, "step3_hits.gz"), "rb") as f:
+            hits = f.read()
+        os.remove(os.path.join(BUNDLED, "step3_hits.gz"))
+        with open(os.path.join(BUNDLED, "step3_expected.hits"), "wb") as f:
+            f.write(hits)
+        with open(os.path.join(BUNDLED, "step3_facts.json"), "w") as f:
+            json.dump({"argv": argv3, "returncode": p3.returncode, "stdout": p3.stdout.decode(), "stderr": p3.stderr.decode(),
+                       "hits_md5": hashlib.md5(hits).hexdigest(), "hits_lines": hits.count(b"\n")}, f, indent=1)
+        print("bundled step 3:", hashlib.md5(hits).hexdigest(), hits.count(b"\n"))
     print("bundled:", facts["stdout_md5"], facts["stdout_lines"], col_sums, nz)
 
 
