@@ -90,6 +90,17 @@ int sk_scan_stream(sk_ctx *ctx, const uint8_t *stream, uint64_t nbytes, uint32_t
 /* Same, for a batch already resident in HBM (device pointer). */
 int sk_scan_device(sk_ctx *ctx, const void *dev_stream, uint64_t nbytes, uint32_t col);
 
+/* strain_detect's per-READ view of the same scan (src/strain_detect.c:443-541): one batch of the
+ * record stream whose records start at rec_start[0..nrec) (byte offsets into `stream`, ascending;
+ * a record ends at the next start).  For record r: out_tally[2r] = windows that hit any key,
+ * out_tally[2r+1] = windows that hit a key whose counter in column `type_col` equals
+ * `informative_value`; each of the latter is also logged as {window-end offset, row} in out_hits
+ * (unordered; *out_nhits may exceed hits_cap: then only hits_cap entries were stored).  Synchronous. */
+typedef struct sk_hit { uint32_t pos, row; } sk_hit;
+int sk_tally_batch(sk_ctx *ctx, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec,
+                   uint32_t type_col, uint32_t informative_value, uint32_t *out_tally /* 2*nrec */,
+                   sk_hit *out_hits, uint64_t hits_cap, uint64_t *out_nhits);
+
 /* Wait for all queued work of the context. */
 int sk_sync(sk_ctx *ctx);
 
@@ -178,6 +189,11 @@ int skh_print_counts(sk_ctx *ctx, const skh_keyset *ks, FILE *out, int with_drug
 /* The whole program with the reference's argv contract (src/kmer_scrub_count.c:29-131).
  * Extra environment: SK_DEVICE (default 0).  Returns the process exit status. */
 int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err);
+
+/* The whole strain_detect program with the reference's argv contract (src/strain_detect.c:61-158):
+ * -r -a -o and one of -b [-c] [-t SE|PE|PEI] / -B, optional -g.  Messages the reference prints on
+ * stdout go to `out`, stderr texts to `err`; the -o file is gz level 9.  Returns the exit status. */
+int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err);
 
 /* Record reader exposed for tests: decode `path` into the record stream, calling `sink` with
  * successive chunks (records separated by '\n'; a long record may be cut with a k-1 overlap).

@@ -60,14 +60,47 @@ struct sk_table_view {
 
 __device__ __forceinline__ uint64_t sk_slot_key(const sk_u4 e) { return ((uint64_t)e.y << 32) | e.x; }
 
-// stage 2 for one window: slot from the k-mer hash, linear probing, 62-bit compare, atomicAdd on a hit
-__device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, uint32_t *counts)
+// What a hit does.  COUNT mode (kmer_scrub_count): bump the row's counter in the scanned column.
+// TALLY mode (strain_detect, src/strain_detect.c:477-485): bump the per-RECORD tallies (all hits /
+// hits on rows whose type column holds `inf_value`) and log the latter as (position, row).
+struct sk_sink {
+    uint32_t       *counts;        // COUNT: counts + col * nrows
+    const uint32_t *rec_start;     // TALLY: batch offset of every record's first byte, ascending
+    uint32_t        nrec;
+    uint32_t       *tally;         // TALLY: [2 * nrec]
+    const uint32_t *type;          // TALLY: type column
+    uint32_t        inf_value;
+    uint2          *hits;          // TALLY: (window-end offset in batch, row)
+    unsigned long long *nhits;
+    unsigned long long  hits_cap;
+};
+
+template <bool TALLY>
+__device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32_t pos)
+{
+    if (!TALLY) { atomicAdd(&k.counts[row], 1u); return; }
+    uint32_t lo = 0, hi = k.nrec;                      // last record whose start <= pos
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (k.rec_start[mid] <= pos) lo = mid; else hi = mid;
+    }
+    atomicAdd(&k.tally[2u * lo], 1u);
+    if (k.type[row] == k.inf_value) {
+        atomicAdd(&k.tally[2u * lo + 1u], 1u);
+        const unsigned long long i = atomicAdd(k.nhits, 1ull);
+        if (i < k.hits_cap) k.hits[i] = make_uint2(pos, row);
+    }
+}
+
+// stage 2 for one window: slot from the k-mer hash, linear probing, 62-bit compare
+template <bool TALLY>
+__device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, const sk_sink &k, uint32_t pos)
 {
     uint32_t slot = sk_slot0(0u, sk_khash(canon), t.mask);
     for (;;) {
         const sk_u4 e = t.slots[slot];
         const uint64_t key = sk_slot_key(e);
-        if (key == canon) { atomicAdd(&counts[e.z], 1u); return; }
+        if (key == canon) { sk_on_hit<TALLY>(k, e.z, pos); return; }
         if (key == SK_EMPTY64) return;
         slot = (slot + 1u) & t.mask;
     }
@@ -142,10 +175,10 @@ __device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_
 //            the strain stop here (~1 % false positives).
 //   stage 2  windows of passing runs are rebuilt from LDS (full 62-bit canonical key), queued,
 //            and probed 64 at a time in the HBM table; atomicAdd on the row counter on a hit.
-template <bool FILTER, bool STATS, int ABLATE>     // ABLATE (timing experiments only; wrong counts):
+template <bool FILTER, bool STATS, int ABLATE, bool TALLY>   // ABLATE (timing experiments only; wrong counts):
 __global__ __launch_bounds__(SK_THREADS)           // 1 = no filter/table memory at all, 2 = no table probes
 void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
-                  sk_table_view table, uint32_t *__restrict__ counts, uint32_t *__restrict__ flags)
+                  sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags)
 {
     __shared__ __attribute__((aligned(16))) uint32_t rec[SK_NREC * SK_REC_DW];
     __shared__ uint2    evq_all[SK_WAVES][SK_EVQ];
@@ -204,8 +237,9 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         qw -= 64u;
-        const uint64_t cn = sk_window_canon(rec, wq[qw + lane]);
-        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe(cn, table, counts);
+        const uint32_t e = wq[qw + lane];
+        const uint64_t cn = sk_window_canon(rec, e);
+        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe<TALLY>(cn, table, sink, (uint32_t)tile0 + e);
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -359,8 +393,9 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (lane < qw) {
-        const uint64_t cn = sk_window_canon(rec, wq[lane]);
-        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe(cn, table, counts);
+        const uint32_t e = wq[lane];
+        const uint64_t cn = sk_window_canon(rec, e);
+        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe<TALLY>(cn, table, sink, (uint32_t)tile0 + e);
     }
     if (bad) atomicAdd(&flags[0], 1u);
     if (STATS) {
@@ -383,9 +418,10 @@ struct sk_wide_view {
     uint32_t        nwide;
 };
 
+template <bool TALLY>
 __global__ __launch_bounds__(256)
 void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
-                  sk_table_view table, sk_wide_view wide, uint32_t *__restrict__ counts,
+                  sk_table_view table, sk_wide_view wide, sk_sink sink,
                   const uint32_t *__restrict__ flags)
 {
     if (flags[0] == 0u) return;                        // no window with a non-ACGT byte in this batch
@@ -423,7 +459,7 @@ void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         if (opure) {                                   // e.g. a window with U whose revcomp wins
             uint64_t key = 0;
             for (int i = 0; i < SK_K; i++) key = (key << 2) | sk_code((uint8_t)o[i]);
-            sk_probe(key, table, counts);
+            sk_probe<TALLY>(key, table, sink, (uint32_t)p);
         } else if (wide.nwide) {
             uint32_t slot = sk_hash_wide(o) & wide.wmask;
             for (;;) {
@@ -432,7 +468,7 @@ void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 const char *cand = wide.keys31 + (size_t)(e - 1u) * 32u;
                 bool same = true;
                 for (int i = 0; i < SK_K; i++) same &= (cand[i] == o[i]);
-                if (same) { atomicAdd(&counts[wide.rows[e - 1u]], 1u); break; }
+                if (same) { sk_on_hit<TALLY>(sink, wide.rows[e - 1u], (uint32_t)p); break; }
                 slot = (slot + 1u) & wide.wmask;
             }
         }
@@ -695,7 +731,8 @@ extern "C" int sk_table_load_wide(sk_ctx *c, const char *keys31, const uint32_t 
 }
 
 // launch main + wide kernels over one device-resident batch
-static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, uint64_t emit_begin, uint32_t col)
+static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, uint64_t emit_begin, uint32_t col,
+                          const sk_sink *tally_sink = NULL)
 {
     if (nbytes <= emit_begin) return SK_OK;
     const uint64_t ntiles = (nbytes + SK_TILE - 1) / SK_TILE;
@@ -707,7 +744,11 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     sk_wide_view wv;
     wv.keys31 = c->d_wide_keys; wv.rows = c->d_wide_rows; wv.index = c->d_wide_index;
     wv.wmask = c->wide_mask; wv.nwide = c->nwide;
-    uint32_t *counts = c->d_counts + (size_t)col * c->nrows;
+    sk_sink sink;
+    memset(&sink, 0, sizeof sink);
+    if (tally_sink) sink = *tally_sink;
+    else sink.counts = c->d_counts + (size_t)col * c->nrows;
+    const dim3 grid((uint32_t)ntiles), block(SK_THREADS);
 
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), c->stream));
     hipEvent_t e0 = NULL, e1 = NULL;
@@ -717,21 +758,16 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         SK_HIP(c, hipEventCreate(&e1));
         SK_HIP(c, hipEventRecord(e0, c->stream));
     }
-    if (c->ablate == 1 && c->bloom_blocks_log2)
-        hipLaunchKernelGGL((sk_scan_main<true, false, 1>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
-    else if (c->ablate == 2 && c->bloom_blocks_log2)
-        hipLaunchKernelGGL((sk_scan_main<true, false, 2>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
-    else if (c->stats && c->bloom_blocks_log2)
-        hipLaunchKernelGGL((sk_scan_main<true, true, 0>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
-    else if (c->bloom_blocks_log2)
-        hipLaunchKernelGGL((sk_scan_main<true, false, 0>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
-    else
-        hipLaunchKernelGGL((sk_scan_main<false, false, 0>), dim3((uint32_t)ntiles), dim3(SK_THREADS), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, counts, c->d_flags);
+#define SK_LAUNCH_MAIN(F, S, A, T) hipLaunchKernelGGL((sk_scan_main<F, S, A, T>), grid, block, 0, c->stream, \
+                                                      d_stream, nbytes, emit_begin, tv, sink, c->d_flags)
+    const bool filter = c->bloom_blocks_log2 != 0;
+    if (tally_sink)                      { if (filter) SK_LAUNCH_MAIN(true, false, 0, true); else SK_LAUNCH_MAIN(false, false, 0, true); }
+    else if (c->ablate == 1 && filter)   SK_LAUNCH_MAIN(true, false, 1, false);
+    else if (c->ablate == 2 && filter)   SK_LAUNCH_MAIN(true, false, 2, false);
+    else if (c->stats && filter)         SK_LAUNCH_MAIN(true, true, 0, false);
+    else if (filter)                     SK_LAUNCH_MAIN(true, false, 0, false);
+    else                                 SK_LAUNCH_MAIN(false, false, 0, false);
+#undef SK_LAUNCH_MAIN
     if (timed) {
         SK_HIP(c, hipEventRecord(e1, c->stream));
         c->ev.push_back(e0);
@@ -739,10 +775,53 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     }
     uint64_t wblocks = (nbytes - emit_begin + 255) / 256;
     if (wblocks > 16384) wblocks = 16384;
-    hipLaunchKernelGGL(sk_scan_wide, dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
-                       d_stream, nbytes, emit_begin, tv, wv, counts, c->d_flags);
+    if (tally_sink)
+        hipLaunchKernelGGL(sk_scan_wide<true>, dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, wv, sink, c->d_flags);
+    else
+        hipLaunchKernelGGL(sk_scan_wide<false>, dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, wv, sink, c->d_flags);
     SK_HIP(c, hipGetLastError());
     return SK_OK;
+}
+
+// Per-record tallies of one batch (strain_detect): synchronous.
+extern "C" int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec,
+                              uint32_t type_col, uint32_t informative_value, uint32_t *out_tally,
+                              sk_hit *out_hits, uint64_t hits_cap, uint64_t *out_nhits)
+{
+    if (!c || !stream || !rec_start || !out_tally || !out_nhits || (hits_cap && !out_hits)) return SK_E_ARG;
+    if (!c->d_keys) return sk_fail(c, SK_E_STATE, "no table loaded");
+    if (type_col >= c->ncols) return sk_fail(c, SK_E_ARG, "column %u out of range", type_col);
+    if (nbytes == 0 || nrec == 0 || nbytes > 0xFFFFFFF0ull) return sk_fail(c, SK_E_ARG, "bad batch size");
+    SK_HIP(c, hipSetDevice(c->device));
+    uint8_t *d_stream = NULL; uint32_t *d_rec = NULL, *d_tally = NULL; uint2 *d_hits = NULL; unsigned long long *d_n = NULL;
+    int rc = SK_OK;
+    unsigned long long nh = 0;
+    do {
+        if (hipMalloc((void **)&d_stream, nbytes + 16) != hipSuccess || hipMalloc((void **)&d_rec, (size_t)nrec * 4) != hipSuccess ||
+            hipMalloc((void **)&d_tally, (size_t)nrec * 8) != hipSuccess || hipMalloc((void **)&d_n, 8) != hipSuccess ||
+            hipMalloc((void **)&d_hits, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2)) != hipSuccess) { rc = sk_fail(c, SK_E_NOMEM, "hipMalloc (tally batch)"); break; }
+        hipMemcpyAsync(d_stream, stream, nbytes, hipMemcpyHostToDevice, c->stream);
+        hipMemcpyAsync(d_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, c->stream);
+        hipMemsetAsync(d_tally, 0, (size_t)nrec * 8, c->stream);
+        hipMemsetAsync(d_n, 0, 8, c->stream);
+        sk_sink sink;
+        memset(&sink, 0, sizeof sink);
+        sink.rec_start = d_rec; sink.nrec = nrec; sink.tally = d_tally;
+        sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
+        sink.hits = d_hits; sink.nhits = d_n; sink.hits_cap = hits_cap;
+        rc = sk_launch_scan(c, d_stream, nbytes, 0, 0, &sink);
+        if (rc) break;
+        hipMemcpyAsync(out_tally, d_tally, (size_t)nrec * 8, hipMemcpyDeviceToHost, c->stream);
+        hipMemcpyAsync(&nh, d_n, 8, hipMemcpyDeviceToHost, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = sk_fail(c, SK_E_HIP, "tally batch failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        const unsigned long long take = nh < hits_cap ? nh : hits_cap;
+        if (take && hipMemcpy(out_hits, d_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess) { rc = sk_fail(c, SK_E_HIP, "hits download"); break; }
+        *out_nhits = nh;
+    } while (0);
+    hipFree(d_stream); hipFree(d_rec); hipFree(d_tally); hipFree(d_hits); hipFree(d_n);
+    return rc;
 }
 
 extern "C" int sk_scan_device(sk_ctx *c, const void *dev_stream, uint64_t nbytes, uint32_t col)

@@ -1,0 +1,172 @@
+/* sk_parser.h -- FASTA/FASTQ record parser shared by the host-layer sources (internal).
+ *
+ * Push-style state machine over inflated blocks with the observable behaviour of the reference's
+ * parser (src/kseq.h:166-211): what counts as a header, how sequence lines are joined, the CR rule,
+ * FASTQ quality accounting, and the three ways a file can end:
+ *   END_RESET  (-1 after the lengths were reset: the file ended inside/after a FASTA-style record)
+ *   END_STALE  (-1 before the reset: the file ended while seeking the next header after a FASTQ record;
+ *               the reference's seq.l still holds the previous record's length)
+ *   END_TRUNC  (-2: quality string length mismatch; seq.l is that record's sequence length)
+ */
+#ifndef SK_PARSER_H
+#define SK_PARSER_H
+#include <ctype.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { SKP_END_NONE = 0, SKP_END_RESET = 1, SKP_END_STALE = 2, SKP_END_TRUNC = 3 };
+
+enum { P_SEEK, P_NAME, P_COMMENT, P_LINE_START, P_SEQ, P_PLUS, P_QUAL, P_STOP };
+
+typedef int (*rec_fn)(void *user, char *seq, size_t len);
+
+typedef struct {
+    int     state;
+    int     name_any, line_any, qual_any;
+    char   *seq;  size_t seq_len, seq_cap;
+    char   *qual; size_t qual_len, qual_cap;
+    rec_fn  on_record;
+    void   *user;
+    int64_t nrecords;
+    int     sink_rc;
+    int     end_kind;       /* SKP_END_* once the input is exhausted or the parser stopped */
+    size_t  end_len;        /* the reference's seq.l at that point */
+    size_t  last_len;       /* length of the last record handed out */
+} parser;
+
+static void grow(char **p, size_t *cap, size_t need)
+{
+    if (need + 1 > *cap) {
+        size_t nc = *cap ? *cap : 4096;
+        while (nc < need + 1) nc *= 2;
+        *p = (char *)realloc(*p, nc);
+        *cap = nc;
+    }
+}
+
+static void parser_init(parser *ps, rec_fn fn, void *user)
+{
+    memset(ps, 0, sizeof *ps);
+    ps->state = P_SEEK;
+    ps->on_record = fn;
+    ps->user = user;
+}
+
+static void parser_free(parser *ps) { free(ps->seq); free(ps->qual); }
+
+static void emit(parser *ps)
+{
+    grow(&ps->seq, &ps->seq_cap, ps->seq_len);
+    ps->seq[ps->seq_len] = '\0';
+    ps->nrecords++;
+    ps->last_len = ps->seq_len;
+    if (ps->on_record) {
+        int rc = ps->on_record(ps->user, ps->seq, ps->seq_len);
+        if (rc) { ps->sink_rc = rc; ps->state = P_STOP; }
+    }
+}
+
+static void begin_header(parser *ps)
+{
+    ps->state = P_NAME;
+    ps->name_any = 0;
+    ps->seq_len = 0;
+    ps->qual_len = 0;
+}
+
+/* a trailing CR is dropped once the accumulated text is longer than one byte (src/kseq.h:136) */
+static void strip_cr(char *p, size_t *len) { if (*len > 1 && p[*len - 1] == '\r') (*len)--; }
+
+static void finish_fastq(parser *ps)
+{
+    if (ps->qual_len == ps->seq_len) { emit(ps); if (ps->state != P_STOP) ps->state = P_SEEK; }
+    else { ps->state = P_STOP; ps->end_kind = SKP_END_TRUNC; ps->end_len = ps->seq_len; }   /* -2: dropped, file over */
+}
+
+static void parser_feed(parser *ps, const unsigned char *b, size_t n)
+{
+    size_t i = 0;
+    while (i < n && ps->state != P_STOP) {
+        switch (ps->state) {
+        case P_SEEK:
+            while (i < n && b[i] != '>' && b[i] != '@') i++;
+            if (i < n) { i++; begin_header(ps); }
+            break;
+        case P_NAME:
+            while (i < n) {
+                int c = b[i++];
+                ps->name_any = 1;
+                if (isspace(c)) { ps->state = (c == '\n') ? P_LINE_START : P_COMMENT; break; }
+            }
+            break;
+        case P_COMMENT: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            if (nl) { i = (size_t)(nl - b) + 1; ps->state = P_LINE_START; } else i = n;
+            break; }
+        case P_LINE_START: {
+            int c = b[i++];
+            if (c == '\n') break;
+            if (c == '>' || c == '@') { emit(ps); if (ps->state != P_STOP) begin_header(ps); break; }
+            if (c == '+') { ps->state = P_PLUS; break; }
+            grow(&ps->seq, &ps->seq_cap, ps->seq_len + 1);
+            ps->seq[ps->seq_len++] = (char)c;
+            ps->line_any = 0;
+            ps->state = P_SEQ;
+            break; }
+        case P_SEQ: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            size_t take = nl ? (size_t)(nl - (b + i)) : n - i;
+            ps->line_any = 1;
+            grow(&ps->seq, &ps->seq_cap, ps->seq_len + take);
+            memcpy(ps->seq + ps->seq_len, b + i, take);
+            ps->seq_len += take;
+            i += take;
+            if (nl) { i++; strip_cr(ps->seq, &ps->seq_len); ps->state = P_LINE_START; }
+            break; }
+        case P_PLUS: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            if (nl) { i = (size_t)(nl - b) + 1; ps->state = P_QUAL; ps->qual_len = 0; ps->qual_any = 0; } else i = n;
+            break; }
+        case P_QUAL: {
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            size_t take = nl ? (size_t)(nl - (b + i)) : n - i;
+            ps->qual_any = 1;
+            grow(&ps->qual, &ps->qual_cap, ps->qual_len + take);
+            memcpy(ps->qual + ps->qual_len, b + i, take);
+            ps->qual_len += take;
+            i += take;
+            if (nl) {
+                i++;
+                strip_cr(ps->qual, &ps->qual_len);
+                ps->qual_any = 0;
+                if (ps->qual_len >= ps->seq_len) finish_fastq(ps);
+            }
+            break; }
+        default: i = n; break;
+        }
+    }
+}
+
+static void parser_eof(parser *ps)
+{
+    const int st = ps->state;
+    if (st == P_STOP) return;
+    switch (ps->state) {
+    case P_NAME:       if (ps->name_any) emit(ps); break;     /* header cut by EOF: empty record */
+    case P_COMMENT:    emit(ps); break;
+    case P_LINE_START: emit(ps); break;
+    case P_SEQ:        if (ps->line_any) strip_cr(ps->seq, &ps->seq_len); emit(ps); break;
+    case P_QUAL:       if (ps->qual_any) strip_cr(ps->qual, &ps->qual_len); finish_fastq(ps); break;
+    default: break;                                           /* P_SEEK, P_PLUS (-2) */
+    }
+    if (ps->end_kind == SKP_END_NONE) {
+        if (st == P_SEEK) { ps->end_kind = SKP_END_STALE; ps->end_len = ps->last_len; }
+        else if (st == P_PLUS) { ps->end_kind = SKP_END_TRUNC; ps->end_len = ps->seq_len; }
+        else { ps->end_kind = SKP_END_RESET; ps->end_len = 0; }
+    }
+    ps->state = P_STOP;
+}
+
+
+#endif

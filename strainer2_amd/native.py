@@ -14,8 +14,8 @@ def library_path():
     return os.path.join(_HERE, "lib", "libstrainer_kmer.so")
 
 
-def cli_path():
-    return os.path.join(_HERE, "bin", "kmer_scrub_count")
+def cli_path(name="kmer_scrub_count"):
+    return os.path.join(_HERE, "bin", name)
 
 
 def _load():
@@ -39,13 +39,13 @@ SK_E_OPEN = -5
 # every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load",
-    "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_sync", "sk_counts_fetch",
+    "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
     "sk_counts_allreduce", "sk_scan_timing", "sk_set_option", "sk_scan_stats", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
     "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
-    "skh_kmer_scrub_count_main", "skh_decode_file",
+    "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_decode_file",
 ]
 
 
@@ -69,6 +69,8 @@ lib.sk_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
 lib.sk_table_load_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
 lib.sk_scan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.sk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+lib.sk_tally_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                               C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
 lib.sk_sync.argtypes = [C.c_void_p]
 lib.sk_counts_fetch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
 lib.sk_counts_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
@@ -208,6 +210,19 @@ class KmerContext:
             self._ck(lib.sk_scan_stream(self._h, stream.ctypes.data, stream.size, col))
         else:
             self._ck(lib.sk_scan_stream(self._h, stream, len(stream), col))
+
+    def tally_batch(self, stream: bytes, rec_start, type_col=0, informative_value=2):
+        """Per-record tallies (strain_detect): returns (tally[nrec, 2], hits[n, 2] sorted by position)."""
+        rec_start = np.ascontiguousarray(rec_start, dtype=np.uint32)
+        nrec = len(rec_start)
+        tally = np.zeros((nrec, 2), dtype=np.uint32)
+        cap = max(len(stream), 16)
+        hits = np.zeros((cap, 2), dtype=np.uint32)
+        nh = C.c_uint64(0)
+        self._ck(lib.sk_tally_batch(self._h, stream, len(stream), rec_start.ctypes.data, nrec, type_col, informative_value,
+                                    tally.ctypes.data, hits.ctypes.data, cap, C.byref(nh)))
+        hits = hits[: nh.value]
+        return tally, hits[np.argsort(hits[:, 0], kind="stable")]
 
     def scan_device(self, dev_ptr, nbytes, col):
         self._ck(lib.sk_scan_device(self._h, dev_ptr, nbytes, col))

@@ -111,3 +111,16 @@ def run_reference_cli(argv, cwd):
 
 def have_reference():
     return os.path.exists(REF_BIN)
+
+KSD_BIN = os.path.join(ORACLE_DIR, "ksd_oracle")
+REF_SD_BIN = os.path.join(ORACLE_DIR, "_ref", "strain_detect")
+
+
+def run_sd_oracle_cli(argv, cwd):
+    if not os.path.exists(KSD_BIN):
+        subprocess.run(["make", "-C", ORACLE_DIR, "ksd_oracle"], check=True, stdout=subprocess.DEVNULL)
+    return subprocess.run([KSD_BIN] + argv, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def run_sd_reference_cli(argv, cwd):
+    return subprocess.run([REF_SD_BIN] + argv, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
