@@ -176,7 +176,7 @@ def main():
     # PCIe-inclusive rate (host buffer -> pinned staging -> H2D -> scan), reported beside `value`,
     # never as it: 2 passes of sk_scan_stream over the same record stream
     host_rate = None
-    if world == 1 and not args.ablate:
+    if world == 1 and not args.ablate and not args.stats:
         ctx.scan_stream(reads[: 64 << 20], 3)
         ctx.sync()
         t1 = time.perf_counter()

@@ -74,6 +74,13 @@ const char *sk_strerror(int code);
  * sk_table_load_wide().  Row order is the caller's (the host layer passes BIO_hash slot order).
  * Replaces the insert half of GEN_hash_sequences_set_count_vec(): src/genome_compare.c:1007-1019. */
 int sk_table_load(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t ncols);
+/* Same, with a "locality" permutation: locality[r] = position of row r's key in an order in which
+ * keys that follow each other in the strain are neighbours (the host layer passes first-occurrence
+ * order).  The device keeps its counters in that order, so the hits of one read land on adjacent
+ * counters and their atomics coalesce.  Invisible through sk_counts_fetch/set and sk_tally_batch
+ * (they speak caller rows); sk_counts_device_ptr/sk_counts_allreduce see the block in locality
+ * order, which is the same on every rank that loaded the same key set. */
+int sk_table_load_ex(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t ncols, const uint32_t *locality);
 
 /* Wide keys: rows whose 31-byte upper-cased oriented key contains bytes other than ACGT
  * (IUPAC letters in the strain: SURVEY 8(a) a3/a6).  keys31 = nwide * 32 bytes, each key
@@ -147,6 +154,7 @@ typedef struct skh_keyset {
     uint32_t  nwide;        /* how many of them are wide (non-ACGT bytes)                       */
     uint64_t *packed;       /* [nrows] canonical packed key or SK_KEY_NONE                      */
     uint32_t *first_count;  /* [nrows] column-0 value after the build phase                     */
+    uint32_t *locality;     /* [nrows] first-occurrence rank of each row's key along the strain    */
     char     *wide_keys;    /* [nwide*32]                                                       */
     uint32_t *wide_rows;    /* [nwide]                                                          */
     uint32_t  final_slots;  /* M of the replayed reference table                                */

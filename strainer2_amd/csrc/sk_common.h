@@ -52,19 +52,18 @@ SK_HD uint32_t sk_hash62(uint64_t key)
     return h;
 }
 
-/* ---- minimizer-keyed placement (device table + prefilter) --------------------------------
- * Every 31-mer window contains w = 16 overlapping 16-mers (m = 16, 32 bits packed).  Its
- * "minimizer hash" mz is the minimum over those of sk_mhash(16-mer, its reverse complement),
- * a hash of the canonical (smaller) of the two: orientation-independent, so a window and the strain key it equals
- * get the same mz.  Consecutive windows mostly share their minimizer, so
- * everything placed by mz (the prefilter block, the table line) is re-used ~w/2 times in a
- * row by the scanning lane.  sk_khash is a cheap per-k-mer hash for bits inside those. */
-SK_HD uint32_t sk_mhash(uint32_t f16, uint32_t r16)
+/* ---- minimizers (prefilter) ----------------------------------------------------------------
+ * Every 31-mer window contains w = 16 overlapping 16-mers (m = 16, 32 bits packed).  The scan
+ * computes the FORWARD-strand minimizer hash of each window, mz = min over those of
+ * sk_mhash(16-mer); no reverse complement is involved there.  Strand symmetry comes from the
+ * build side instead: for every strain key K both mz(K) and mz(revcomp K) go into the filter, so
+ * a read window that equals K in either orientation finds its own forward minimizer present.
+ * Consecutive windows mostly share their minimizer: one filter lookup per run of ~7 windows. */
+SK_HD uint32_t sk_mhash(uint32_t f16)
 {
-    /* canonical 16-mer = min(f, r); one multiply; top bit cleared so that 0xFFFFFFFF is never a
-     * hash.  (f ^ r or f + r instead of min() would be cheaper but are palindromic in the base
-     * positions: only 2^16 / 7^8 distinct values, which makes every minimizer collide.) */
-    return ((f16 < r16 ? f16 : r16) * 0x9E3779B1u) >> 1;
+    /* one multiply; the multiplier is EVEN so bit 0 of every hash is 0 and 0xFFFFFFFF (the scan's
+     * "dead stretch" marker) is never a hash */
+    return f16 * 0x9E3779B2u;
 }
 
 SK_HD uint32_t sk_khash(uint64_t key)
@@ -87,15 +86,12 @@ SK_HD uint64_t sk_revcomp62(uint64_t key)
     return r;
 }
 
-/* minimizer hash of a packed 31-mer (build side; the scan kernel rolls it) */
+/* forward minimizer hash of a packed 31-mer (build side; the scan kernel slides it) */
 SK_HD uint32_t sk_minimizer62(uint64_t key)
 {
-    const uint64_t rc = sk_revcomp62(key);
     uint32_t mz = 0xFFFFFFFFu;
     for (int i = 0; i < 16; i++) {
-        const uint32_t f = (uint32_t)(key >> (2 * (15 - i)));
-        const uint32_t r = (uint32_t)(rc >> (2 * i));
-        const uint32_t h = sk_mhash(f, r);
+        const uint32_t h = sk_mhash((uint32_t)(key >> (2 * (15 - i))));
         mz = h < mz ? h : mz;
     }
     return mz;

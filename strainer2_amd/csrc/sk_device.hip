@@ -42,7 +42,7 @@
 #define SK_REC_DW       12                  // per record: 8 code words (u32) + 8 invalid masks (u16) = 48 B;
                                             // 12-dword lane stride keeps ds_read_b128 conflict-free
 #define SK_NCHUNK       (SK_NREC * SK_SPAN_CH)
-#define SK_EVQ          (64 + 5 * 64)       // minimizer-run events: drained below 64 every 4 windows
+#define SK_EVQ          (64 + 3 * 64)       // minimizer-run events: drained below 64 every 2 windows
 #define SK_WQ           (64 + 64)           // tile positions of windows waiting for their table probe
 #define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
 
@@ -70,14 +70,16 @@ struct sk_sink {
     uint32_t       *tally;         // TALLY: [2 * nrec]
     const uint32_t *type;          // TALLY: type column
     uint32_t        inf_value;
-    uint2          *hits;          // TALLY: (window-end offset in batch, row)
+    const uint32_t *inv;           // TALLY: counter index -> caller's row (NULL = identity)
+    uint2          *hits;          // TALLY: (window-end offset in batch, caller's row)
     unsigned long long *nhits;
     unsigned long long  hits_cap;
 };
 
-template <bool TALLY>
+template <bool TALLY, bool NOATOMIC = false>
 __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32_t pos)
 {
+    if (NOATOMIC) { if (row == 0x7FFFFFFFu) k.counts[0] = pos; return; }      // timing experiment only
     if (!TALLY) { atomicAdd(&k.counts[row], 1u); return; }
     uint32_t lo = 0, hi = k.nrec;                      // last record whose start <= pos
     while (hi - lo > 1u) {
@@ -88,19 +90,19 @@ __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32
     if (k.type[row] == k.inf_value) {
         atomicAdd(&k.tally[2u * lo + 1u], 1u);
         const unsigned long long i = atomicAdd(k.nhits, 1ull);
-        if (i < k.hits_cap) k.hits[i] = make_uint2(pos, row);
+        if (i < k.hits_cap) k.hits[i] = make_uint2(pos, k.inv ? k.inv[row] : row);
     }
 }
 
 // stage 2 for one window: slot from the k-mer hash, linear probing, 62-bit compare
-template <bool TALLY>
+template <bool TALLY, bool NOATOMIC = false>
 __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, const sk_sink &k, uint32_t pos)
 {
     uint32_t slot = sk_slot0(0u, sk_khash(canon), t.mask);
     for (;;) {
         const sk_u4 e = t.slots[slot];
         const uint64_t key = sk_slot_key(e);
-        if (key == canon) { sk_on_hit<TALLY>(k, e.z, pos); return; }
+        if (key == canon) { sk_on_hit<TALLY, NOATOMIC>(k, e.z, pos); return; }
         if (key == SK_EMPTY64) return;
         slot = (slot + 1u) & t.mask;
     }
@@ -166,7 +168,7 @@ __device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_
 //            N nor '\n' raise the batch's "needs the byte-string kernel" flag.
 //   phase 2  each thread walks its 128 positions in 16-base chunks, all in registers:
 //              16-mer state   f16/r16 roll by one lshl_or / alignbit per base
-//              minimizer      sliding minimum of the 16-mer hashes over the 31-mer window
+//              minimizer      sliding minimum of the (forward-strand) 16-mer hashes over the window
 //                             (prefix minima of this chunk + suffix minima of the previous one)
 //              live mask      "31 valid bases end here" for the 16 positions by bit tricks
 //              runs           maximal runs of live windows with one minimizer -> one EVENT each
@@ -239,7 +241,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         qw -= 64u;
         const uint32_t e = wq[qw + lane];
         const uint64_t cn = sk_window_canon(rec, e);
-        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe<TALLY>(cn, table, sink, (uint32_t)tile0 + e);
+        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe<TALLY, ABLATE == 3>(cn, table, sink, (uint32_t)tile0 + e);
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -312,20 +314,16 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;           // this thread's record
     const uint32_t *pv = rec + tid * SK_REC_DW;                   // the record before it
     uint32_t cw_prev = pv[7];                                     // code word of the chunk before the span
-    uint32_t rc_prev = sk_revcomp32(cw_prev);
     uint32_t vlo = pv[11];                                        // invalid masks of the two chunks before
     uint32_t S[17], H[16];
     S[16] = 0xFFFFFFFFu;
 
     // warm-up over chunk -1: hashes of the 16-mers that end in it, and their suffix minima
     {
-        const uint32_t cw2 = pv[6], rc2 = sk_revcomp32(cw2);
+        const uint32_t cw2 = pv[6];
 #pragma unroll
-        for (int o = 0; o < 16; o++) {
-            const uint32_t f16 = o < 15 ? __builtin_amdgcn_alignbit(cw2, cw_prev, 30 - 2 * o) : cw_prev;
-            const uint32_t r16 = o < 15 ? __builtin_amdgcn_alignbit(rc_prev, rc2, 2 * o + 2) : rc_prev;
-            H[o] = sk_mhash(f16, r16);
-        }
+        for (int o = 0; o < 16; o++)
+            H[o] = sk_mhash(o < 15 ? __builtin_amdgcn_alignbit(cw2, cw_prev, 30 - 2 * o) : cw_prev);
         S[15] = H[15];
 #pragma unroll
         for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
@@ -340,7 +338,6 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         const uint32_t cwj = my[j];
         const uint32_t ipair = my[8u + (j >> 1)];
         const uint32_t invj = (j & 1u) ? ipair >> 16 : ipair & 0xFFFFu;
-        const uint32_t rcj = sk_revcomp32(cwj);
 
         // live mask: bit o <=> the 31 bases ending at chunk offset o are all ACGT
         const uint64_t v = ~(((uint64_t)invj << 32) | vlo);       // valid bits: chunks j-2, j-1, j
@@ -363,10 +360,8 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         uint32_t P = 0xFFFFFFFFu;
 #pragma unroll
         for (int o = 0; o < 16; o++) {
-            // the 16-mer that ends at offset o and its reverse complement, straight from the words
-            const uint32_t f16 = o < 15 ? __builtin_amdgcn_alignbit(cw_prev, cwj, 30 - 2 * o) : cwj;
-            const uint32_t r16 = o < 15 ? __builtin_amdgcn_alignbit(rcj, rc_prev, 2 * o + 2) : rcj;
-            const uint32_t h = sk_mhash(f16, r16);
+            // the 16-mer that ends at offset o, straight from the two code words
+            const uint32_t h = sk_mhash(o < 15 ? __builtin_amdgcn_alignbit(cw_prev, cwj, 30 - 2 * o) : cwj);
             H[o] = h;
             P = h < P ? h : P;
             uint32_t mz = S[o + 1] < P ? S[o + 1] : P;
@@ -375,12 +370,11 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             push_event(chg, run_mz, ebase, run_rel, o);
             run_rel = chg ? o : run_rel;
             run_mz = mz;
-            if ((o & 3) == 3 && o != 15 && qe >= 64u) pump();
+            if ((o & 1) == 1 && o != 15 && qe >= 64u) pump();
         }
         if (qe >= 64u) pump();
         run_rel -= 16;
         cw_prev = cwj;
-        rc_prev = rcj;
 
         S[15] = H[15];
 #pragma unroll
@@ -484,7 +478,8 @@ __global__ void sk_fill64(uint64_t *p, uint64_t n, uint64_t v)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-__global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_u4 *slots, uint32_t mask, uint32_t *flags)
+__global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_u4 *slots, uint32_t mask, uint32_t *flags,
+                                const uint32_t *__restrict__ perm)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -495,10 +490,31 @@ __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long *)&slots[slot],
                                                 (unsigned long long)SK_EMPTY64, (unsigned long long)k);
-        if (old == SK_EMPTY64) { ((uint32_t *)&slots[slot])[2] = i; return; }
+        if (old == SK_EMPTY64) { ((uint32_t *)&slots[slot])[2] = perm ? perm[i] : i; return; }
         if (old == k) { atomicAdd(&flags[1], 1u); return; }     // duplicate key
         slot = (slot + 1u) & mask;
     }
+}
+
+// counter columns live in "locality order" on the device (perm: caller's row -> counter index)
+__global__ void sk_gather_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+__global__ void sk_scatter_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[perm[i]] = src[i];
+}
+
+__global__ void sk_invert_perm(uint32_t *__restrict__ inv, const uint32_t *__restrict__ perm, uint32_t n, uint32_t *flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (perm[i] >= n) { atomicAdd(&flags[1], 1u); return; }
+    inv[perm[i]] = i;
 }
 
 __global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *bloom_words, uint32_t bloom_shift)
@@ -507,11 +523,13 @@ __global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uin
     if (i >= n) return;
     const uint64_t k = in[i];
     if (k == SK_EMPTY64) return;
-    const uint32_t mz = sk_minimizer62(k);
-    const uint32_t g = sk_filter_bits(mz);
-    uint32_t *blk = bloom_words + 2u * (size_t)sk_filter_block(mz, bloom_shift);
-    atomicOr(&blk[0], (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)));
-    atomicOr(&blk[1], (1u << ((g >> 17) & 31u)) | (1u << ((g >> 12) & 31u)));
+    for (int strand = 0; strand < 2; strand++) {      // a read may carry the key in either orientation
+        const uint32_t mz = sk_minimizer62(strand ? sk_revcomp62(k) : k);
+        const uint32_t g = sk_filter_bits(mz);
+        uint32_t *blk = bloom_words + 2u * (size_t)sk_filter_block(mz, bloom_shift);
+        atomicOr(&blk[0], (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)));
+        atomicOr(&blk[1], (1u << ((g >> 17) & 31u)) | (1u << ((g >> 12) & 31u)));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -530,6 +548,9 @@ struct sk_ctx {
     uint32_t     bloom_blocks_log2;       // 0 = no prefilter
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
+    uint32_t    *d_perm, *d_inv;      // locality order of the counters (NULL = caller's row order)
+    uint32_t    *d_tmp;               // [nrows] scratch for fetch/set through the permutation
+    std::vector<uint32_t> h_perm;     // host copy of the permutation (empty = identity)
     // wide keys
     char        *d_wide_keys;
     uint32_t    *d_wide_rows;
@@ -620,6 +641,10 @@ static void sk_table_release(sk_ctx *c)
     hipFree(c->d_keys); c->d_keys = NULL;
     hipFree(c->d_bloom); c->d_bloom = NULL;
     hipFree(c->d_counts); c->d_counts = NULL;
+    hipFree(c->d_perm); c->d_perm = NULL;
+    c->h_perm.clear();
+    hipFree(c->d_inv); c->d_inv = NULL;
+    hipFree(c->d_tmp); c->d_tmp = NULL;
     hipFree(c->d_wide_keys); c->d_wide_keys = NULL;
     hipFree(c->d_wide_rows); c->d_wide_rows = NULL;
     hipFree(c->d_wide_index); c->d_wide_index = NULL;
@@ -655,7 +680,19 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
 
 extern "C" int sk_table_load(sk_ctx *c, const uint64_t *keys, uint32_t nrows, uint32_t ncols)
 {
+    return sk_table_load_ex(c, keys, nrows, ncols, NULL);
+}
+
+extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows, uint32_t ncols, const uint32_t *locality)
+{
     if (!c || (!keys && nrows) || ncols == 0 || ncols > 16) return SK_E_ARG;
+    if (locality) {                                    // must be a permutation of 0..nrows-1
+        std::vector<uint8_t> seen(nrows, 0);
+        for (uint32_t i = 0; i < nrows; i++) {
+            if (locality[i] >= nrows || seen[locality[i]]) return sk_fail(c, SK_E_ARG, "locality is not a permutation");
+            seen[locality[i]] = 1;
+        }
+    }
     SK_HIP(c, hipSetDevice(c->device));
     SK_HIP(c, hipStreamSynchronize(c->stream));
     sk_table_release(c);
@@ -674,8 +711,17 @@ extern "C" int sk_table_load(sk_ctx *c, const uint64_t *keys, uint32_t nrows, ui
         uint64_t *d_in = NULL;
         SK_HIP(c, hipMalloc((void **)&d_in, (size_t)nrows * sizeof(uint64_t)));
         SK_HIP(c, hipMemcpyAsync(d_in, keys, (size_t)nrows * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        if (locality) {
+            SK_HIP(c, hipMalloc((void **)&c->d_perm, (size_t)nrows * 4));
+            SK_HIP(c, hipMalloc((void **)&c->d_inv, (size_t)nrows * 4));
+            SK_HIP(c, hipMalloc((void **)&c->d_tmp, (size_t)nrows * 4));
+            c->h_perm.assign(locality, locality + nrows);
+            SK_HIP(c, hipMemcpyAsync(c->d_perm, locality, (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
+            SK_HIP(c, hipMemsetAsync(c->d_inv, 0xFF, (size_t)nrows * 4, c->stream));
+            hipLaunchKernelGGL(sk_invert_perm, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, c->d_inv, c->d_perm, nrows, c->d_flags);
+        }
         hipLaunchKernelGGL(sk_table_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
-                           d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags);
+                           d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags, c->d_perm);
         // minimizer filter: automatic size = smallest power of two >= 4 bits per key (the set holds
         // ~nrows/8 minimizers, i.e. ~32 bits each: false positives ~0.1 %); 2 MiB for a 5 Mbp strain
         long bb = c->bloom_bits_log2;
@@ -723,7 +769,9 @@ extern "C" int sk_table_load_wide(sk_ctx *c, const char *keys31, const uint32_t 
     SK_HIP(c, hipMalloc((void **)&c->d_wide_rows, (size_t)nwide * sizeof(uint32_t)));
     SK_HIP(c, hipMalloc((void **)&c->d_wide_index, (size_t)wslots * sizeof(uint32_t)));
     SK_HIP(c, hipMemcpy(c->d_wide_keys, keys31, (size_t)nwide * 32, hipMemcpyHostToDevice));
-    SK_HIP(c, hipMemcpy(c->d_wide_rows, rows, (size_t)nwide * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::vector<uint32_t> wrows(rows, rows + nwide);
+    if (!c->h_perm.empty()) for (uint32_t i = 0; i < nwide; i++) wrows[i] = c->h_perm[rows[i]];
+    SK_HIP(c, hipMemcpy(c->d_wide_rows, wrows.data(), (size_t)nwide * sizeof(uint32_t), hipMemcpyHostToDevice));
     SK_HIP(c, hipMemcpy(c->d_wide_index, index.data(), (size_t)wslots * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->wide_mask = wslots - 1;
     c->nwide = nwide;
@@ -764,6 +812,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     if (tally_sink)                      { if (filter) SK_LAUNCH_MAIN(true, false, 0, true); else SK_LAUNCH_MAIN(false, false, 0, true); }
     else if (c->ablate == 1 && filter)   SK_LAUNCH_MAIN(true, false, 1, false);
     else if (c->ablate == 2 && filter)   SK_LAUNCH_MAIN(true, false, 2, false);
+    else if (c->ablate == 3 && filter)   SK_LAUNCH_MAIN(true, false, 3, false);
     else if (c->stats && filter)         SK_LAUNCH_MAIN(true, true, 0, false);
     else if (filter)                     SK_LAUNCH_MAIN(true, false, 0, false);
     else                                 SK_LAUNCH_MAIN(false, false, 0, false);
@@ -810,7 +859,7 @@ extern "C" int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes,
         memset(&sink, 0, sizeof sink);
         sink.rec_start = d_rec; sink.nrec = nrec; sink.tally = d_tally;
         sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
-        sink.hits = d_hits; sink.nhits = d_n; sink.hits_cap = hits_cap;
+        sink.hits = d_hits; sink.nhits = d_n; sink.hits_cap = hits_cap; sink.inv = c->d_inv;
         rc = sk_launch_scan(c, d_stream, nbytes, 0, 0, &sink);
         if (rc) break;
         hipMemcpyAsync(out_tally, d_tally, (size_t)nrec * 8, hipMemcpyDeviceToHost, c->stream);
@@ -885,7 +934,12 @@ extern "C" int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out)
     if (!c || !out) return SK_E_ARG;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
-    SK_HIP(c, hipMemcpyAsync(out, c->d_counts + (size_t)col * c->nrows, (size_t)c->nrows * 4, hipMemcpyDeviceToHost, c->stream));
+    const uint32_t *src = c->d_counts + (size_t)col * c->nrows;
+    if (c->d_perm && c->nrows) {
+        hipLaunchKernelGGL(sk_gather_u32, dim3((c->nrows + 255) / 256), dim3(256), 0, c->stream, c->d_tmp, src, c->d_perm, c->nrows);
+        src = c->d_tmp;
+    }
+    SK_HIP(c, hipMemcpyAsync(out, src, (size_t)c->nrows * 4, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(c, hipStreamSynchronize(c->stream));
     return SK_OK;
 }
@@ -895,7 +949,13 @@ extern "C" int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in)
     if (!c || !in) return SK_E_ARG;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
-    SK_HIP(c, hipMemcpyAsync(c->d_counts + (size_t)col * c->nrows, in, (size_t)c->nrows * 4, hipMemcpyHostToDevice, c->stream));
+    uint32_t *dst = c->d_counts + (size_t)col * c->nrows;
+    if (c->d_perm && c->nrows) {
+        SK_HIP(c, hipMemcpyAsync(c->d_tmp, in, (size_t)c->nrows * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(sk_scatter_u32, dim3((c->nrows + 255) / 256), dim3(256), 0, c->stream, dst, c->d_tmp, c->d_perm, c->nrows);
+    } else {
+        SK_HIP(c, hipMemcpyAsync(dst, in, (size_t)c->nrows * 4, hipMemcpyHostToDevice, c->stream));
+    }
     SK_HIP(c, hipStreamSynchronize(c->stream));
     return SK_OK;
 }

@@ -354,11 +354,13 @@ static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
     ks->short_records = b->short_records;
     ks->packed = (uint64_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint64_t));
     ks->first_count = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
+    ks->locality = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
     ks->wide_keys = (char *)malloc((size_t)(b->wn ? b->wn : 1) * 32);
     ks->wide_rows = (uint32_t *)malloc((size_t)(b->wn ? b->wn : 1) * sizeof(uint32_t));
     for (r = 0; r < b->n; r++) {
         uint64_t ent = b->order[rows[r]];
         ks->first_count[r] = b->count[rows[r]];
+        ks->locality[r] = rows[r];
         if (ent & WIDE_FLAG) { ks->packed[r] = SK_KEY_NONE; wide_newrow[ent & 0xFFFFFFFFu] = r; }
         else ks->packed[r] = ent;
     }
@@ -401,7 +403,7 @@ int skh_keyset_from_stream(skh_keyset *ks, const char *stream, size_t nbytes, ui
 void skh_keyset_free(skh_keyset *ks)
 {
     if (!ks) return;
-    free(ks->packed); free(ks->first_count); free(ks->wide_keys); free(ks->wide_rows);
+    free(ks->packed); free(ks->first_count); free(ks->locality); free(ks->wide_keys); free(ks->wide_rows);
     memset(ks, 0, sizeof *ks);
 }
 
@@ -416,7 +418,7 @@ void skh_keyset_key(const skh_keyset *ks, uint32_t row, char out[32])
 
 int skh_keyset_load(sk_ctx *ctx, const skh_keyset *ks, uint32_t ncols)
 {
-    int rc = sk_table_load(ctx, ks->packed, ks->nrows, ncols);
+    int rc = sk_table_load_ex(ctx, ks->packed, ks->nrows, ncols, ks->locality);
     if (rc) return rc;
     rc = sk_table_load_wide(ctx, ks->wide_keys, ks->wide_rows, ks->nwide);
     if (rc) return rc;

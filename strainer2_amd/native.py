@@ -38,7 +38,7 @@ SK_E_OPEN = -5
 
 # every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
-    "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load",
+    "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load", "sk_table_load_ex",
     "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
     "sk_counts_allreduce", "sk_scan_timing", "sk_set_option", "sk_scan_stats", "sk_dev_alloc", "sk_dev_free",
@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
 class _KeysetStruct(C.Structure):
     _fields_ = [("nrows", C.c_uint32), ("nwide", C.c_uint32),
                 ("packed", C.POINTER(C.c_uint64)), ("first_count", C.POINTER(C.c_uint32)),
+                ("locality", C.POINTER(C.c_uint32)),
                 ("wide_keys", C.POINTER(C.c_char)), ("wide_rows", C.POINTER(C.c_uint32)),
                 ("final_slots", C.c_uint32), ("short_records", C.c_uint64)]
 
@@ -66,6 +67,7 @@ lib.sk_last_error.restype = C.c_char_p
 lib.sk_strerror.argtypes = [C.c_int]
 lib.sk_strerror.restype = C.c_char_p
 lib.sk_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+lib.sk_table_load_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
 lib.sk_table_load_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
 lib.sk_scan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.sk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
