@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--bloom-bits-log2", type=int, default=None)
+    ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive host-buffer passes (keeps profiles clean)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments: 1 = no filter/table memory, 2 = no table probes (counts are wrong)")
     ap.add_argument("--stats", action="store_true", help="debug counters (slower kernel variant)")
@@ -176,7 +177,7 @@ def main():
     # PCIe-inclusive rate (host buffer -> pinned staging -> H2D -> scan), reported beside `value`,
     # never as it: 2 passes of sk_scan_stream over the same record stream
     host_rate = None
-    if world == 1 and not args.ablate and not args.stats:
+    if world == 1 and not args.ablate and not args.stats and not args.no_host_rate:
         ctx.scan_stream(reads[: 64 << 20], 3)
         ctx.sync()
         t1 = time.perf_counter()
