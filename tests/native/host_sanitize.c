@@ -1,0 +1,54 @@
+/* host_sanitize.c -- drives the GPU-free parts of the host layer (record parser, keyset build,
+ * BIO_hash order replay, stream writer) under AddressSanitizer + UBSan on the CPU.
+ * Built and run by tests/test_sanitizers.py:
+ *   gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -DSK_HOST_ONLY \
+ *       tests/native/host_sanitize.c strainer2_amd/csrc/sk_host.c -lz -o <tmp>/host_sanitize
+ * (GPU AddressSanitizer is not available on the pool; the device code is covered by parity tests.) */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/strainer_kmer.h"
+
+/* the device layer is not linked here: stubs that must never be reached */
+static int unreachable(const char *name) { fprintf(stderr, "device call %s in a host-only test\n", name); abort(); return -1; }
+int sk_table_load_ex(sk_ctx *c, const uint64_t *k, uint32_t n, uint32_t nc, const uint32_t *l) { (void)c; (void)k; (void)n; (void)nc; (void)l; return unreachable("sk_table_load_ex"); }
+int sk_table_load_wide(sk_ctx *c, const char *k, const uint32_t *r, uint32_t n) { (void)c; (void)k; (void)r; (void)n; return unreachable("sk_table_load_wide"); }
+int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in) { (void)c; (void)col; (void)in; return unreachable("sk_counts_set"); }
+int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out) { (void)c; (void)col; (void)out; return unreachable("sk_counts_fetch"); }
+int sk_scan_stream(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col) { (void)c; (void)s; (void)n; (void)col; return unreachable("sk_scan_stream"); }
+int sk_ctx_create(sk_ctx **o, int d) { (void)o; (void)d; return unreachable("sk_ctx_create"); }
+void sk_ctx_destroy(sk_ctx *c) { (void)c; unreachable("sk_ctx_destroy"); }
+uint32_t sk_table_rows(const sk_ctx *c) { (void)c; return (uint32_t)unreachable("sk_table_rows"); }
+uint32_t sk_table_cols(const sk_ctx *c) { (void)c; return (uint32_t)unreachable("sk_table_cols"); }
+const char *sk_strerror(int c) { (void)c; return "stub"; }
+const char *sk_last_error(const sk_ctx *c) { (void)c; return "stub"; }
+
+static unsigned long long g_bytes, g_sum;
+static int sink(void *user, const uint8_t *chunk, uint64_t n)
+{
+    uint64_t i;
+    (void)user;
+    for (i = 0; i < n; i++) g_sum += chunk[i];
+    g_bytes += n;
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    int i;
+    for (i = 1; i < argc; i++) {
+        skh_keyset ks;
+        uint64_t bases = 0;
+        char key[32];
+        int64_t nrec = skh_decode_file(argv[i], 4096, sink, NULL, &bases);
+        int rc = skh_keyset_from_file(&ks, argv[i], 50, 1, 1);
+        if (rc == SK_OK) {
+            if (ks.nrows) { skh_keyset_key(&ks, 0, key); skh_keyset_key(&ks, ks.nrows - 1, key); }
+            printf("%s: records=%lld bases=%llu keys=%u wide=%u slots=%u short=%llu\n", argv[i], (long long)nrec,
+                   (unsigned long long)bases, ks.nrows, ks.nwide, ks.final_slots, (unsigned long long)ks.short_records);
+            skh_keyset_free(&ks);
+        } else printf("%s: rc=%d\n", argv[i], rc);
+    }
+    printf("stream bytes=%llu checksum=%llu\n", g_bytes, g_sum);
+    return 0;
+}

@@ -1,0 +1,42 @@
+"""ASan + UBSan runs on the CPU: the oracle over the golden cases, and the GPU-free parts of the host
+layer (parser, keyset build, order replay, stream writer) over every fixture file."""
+import json
+import os
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+
+
+def _fixture_files(golden):
+    out = []
+    for sub in ("cases", "sd_cases"):
+        for root, _d, files in os.walk(os.path.join(golden, sub)):
+            out += [os.path.join(root, f) for f in files if f.endswith((".fa", ".fasta", ".fq", ".gz", ".fx"))]
+    return sorted(out)
+
+
+def test_host_layer_under_asan_ubsan(golden, tmp_path):
+    exe = str(tmp_path / "host_sanitize")
+    subprocess.run(["gcc"] + SAN + [os.path.join(REPO, "tests", "native", "host_sanitize.c"),
+                                   os.path.join(REPO, "strainer2_amd", "csrc", "sk_host.c"), "-lz", "-o", exe], check=True)
+    files = _fixture_files(golden)
+    assert len(files) > 30
+    p = subprocess.run([exe] + files, env=ENV, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr
+
+
+@pytest.mark.parametrize("name", ["mixed", "drug", "iupac_strain", "truncated_fastq", "contig30"])
+def test_oracle_under_asan_ubsan(golden, name, tmp_path):
+    exe = str(tmp_path / "kso_asan")
+    subprocess.run(["gcc"] + SAN + ["-DKSO_MAIN", os.path.join(REPO, "oracle", "kso_oracle.c"), "-lz", "-o", exe], check=True)
+    d = os.path.join(golden, "cases", name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    argv = [a if a != "progress.txt" and a != "prog.txt" else str(tmp_path / "p") for a in meta["argv"]]
+    p = subprocess.run([exe] + argv, cwd=d, env=ENV, capture_output=True)
+    assert p.returncode == meta["returncode"], p.stderr.decode()[-2000:]
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
