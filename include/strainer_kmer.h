@@ -122,9 +122,16 @@ int sk_counts_zero(sk_ctx *ctx, uint32_t col);
 void    *sk_counts_device_ptr(sk_ctx *ctx);
 uint32_t sk_table_rows(const sk_ctx *ctx);
 uint32_t sk_table_cols(const sk_ctx *ctx);
-/* In-library sum all-reduce (u32, wrapping) of the counter block over an RCCL communicator
- * (ncclComm_t passed as void*).  New: SURVEY 8(e). */
-int sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);
+/* Multi-GPU, one process per GPU (new: the reference is single-process).
+ * sk_comm_init: rank 0 creates an RCCL unique id and publishes it through `id_file`, the other
+ * ranks wait (at most timeout_s) for it; every rank then joins the communicator.
+ * sk_comm_sum_u32: tiny all-reduce used to agree on failure before the big one.
+ * sk_counts_allreduce: in-place sum (u32, wrapping) of the whole counter block over xGMI;
+ * rccl_comm = an ncclComm_t, or NULL for the context's own communicator. */
+int  sk_comm_init(sk_ctx *ctx, int rank, int world, const char *id_file, int timeout_s);
+void sk_comm_destroy(sk_ctx *ctx);
+int  sk_comm_sum_u32(sk_ctx *ctx, uint32_t value, uint32_t *sum);
+int  sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);
 
 /* Device-side timing of the scan kernel, from HIP events recorded on the context's stream
  * around every scan kernel since the last reset: total milliseconds and launch count. */

@@ -25,7 +25,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/strainer_kmer.h"
 #include "sk_common.h"
@@ -572,6 +574,8 @@ struct sk_ctx {
     long         bloom_bits_log2;
     long         stats;               // debug: count live windows / filter loads / table probes
     long         ablate;              // timing experiments: kernel variants that skip memory stages
+    void        *comm;                // RCCL communicator from sk_comm_init (NULL: single process)
+    int          comm_rank, comm_world;
     char         err[512];
 };
 
@@ -651,11 +655,14 @@ static void sk_table_release(sk_ctx *c)
     c->nrows = c->ncols = c->nwide = 0;
 }
 
+extern "C" void sk_comm_destroy(sk_ctx *c);
+
 extern "C" void sk_ctx_destroy(sk_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    sk_comm_destroy(c);
     sk_table_release(c);
     for (int i = 0; i < SK_NSTAGE; i++) {
         if (c->h_stage[i]) hipHostFree(c->h_stage[i]);
@@ -1006,24 +1013,104 @@ extern "C" int sk_scan_stats(sk_ctx *c, uint64_t out[3])
     return SK_OK;
 }
 
-// RCCL is resolved lazily so that the library loads on hosts without it
+// ---------------------------------------------------------------------------------------------
+// RCCL (resolved lazily so that the library loads on hosts without it)
+// ---------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } sk_nccl_id;                       // ncclUniqueId
+typedef int (*sk_nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*sk_nccl_getid_fn)(sk_nccl_id *);
+typedef int (*sk_nccl_initrank_fn)(void **, int, sk_nccl_id, int);
+typedef int (*sk_nccl_destroy_fn)(void *);
+static struct { void *lib; sk_nccl_allreduce_fn allreduce; sk_nccl_getid_fn getid; sk_nccl_initrank_fn initrank; sk_nccl_destroy_fn destroy; } g_rccl;
+
+static int sk_rccl_load(sk_ctx *c)
+{
+    if (g_rccl.lib) return SK_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return sk_fail(c, SK_E_RCCL, "cannot load librccl: %s", dlerror());
+    g_rccl.allreduce = (sk_nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+    g_rccl.getid = (sk_nccl_getid_fn)dlsym(h, "ncclGetUniqueId");
+    g_rccl.initrank = (sk_nccl_initrank_fn)dlsym(h, "ncclCommInitRank");
+    g_rccl.destroy = (sk_nccl_destroy_fn)dlsym(h, "ncclCommDestroy");
+    if (!g_rccl.allreduce || !g_rccl.getid || !g_rccl.initrank || !g_rccl.destroy) return sk_fail(c, SK_E_RCCL, "RCCL symbols missing");
+    g_rccl.lib = h;
+    return SK_OK;
+}
+
+// One process per GPU: rank 0 creates the RCCL unique id and publishes it through `id_file`
+// (written to a temporary name, then renamed); the other ranks wait for the file.  New relative to
+// the reference, which is single-process.
+extern "C" int sk_comm_init(sk_ctx *c, int rank, int world, const char *id_file, int timeout_s)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world || !id_file) return SK_E_ARG;
+    int rc = sk_rccl_load(c);
+    if (rc) return rc;
+    SK_HIP(c, hipSetDevice(c->device));
+    sk_nccl_id id;
+    memset(&id, 0, sizeof id);
+    if (rank == 0) {
+        if (g_rccl.getid(&id) != 0) return sk_fail(c, SK_E_RCCL, "ncclGetUniqueId failed");
+        std::string tmp = std::string(id_file) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof id, 1, f) != 1) { if (f) fclose(f); return sk_fail(c, SK_E_RCCL, "cannot write %s", tmp.c_str()); }
+        fclose(f);
+        if (rename(tmp.c_str(), id_file) != 0) return sk_fail(c, SK_E_RCCL, "cannot publish %s", id_file);
+    } else {
+        int waited_ms = 0;
+        for (;;) {
+            FILE *f = fopen(id_file, "rb");
+            if (f) {
+                const size_t got = fread(&id, 1, sizeof id, f);
+                fclose(f);
+                if (got == sizeof id) break;
+            }
+            if (waited_ms >= timeout_s * 1000) return sk_fail(c, SK_E_RCCL, "timed out waiting for %s", id_file);
+            usleep(20000);
+            waited_ms += 20;
+        }
+    }
+    void *comm = NULL;
+    if (g_rccl.initrank(&comm, world, id, rank) != 0) return sk_fail(c, SK_E_RCCL, "ncclCommInitRank failed (rank %d of %d)", rank, world);
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return SK_OK;
+}
+
+extern "C" void sk_comm_destroy(sk_ctx *c)
+{
+    if (c && c->comm && g_rccl.destroy) { g_rccl.destroy(c->comm); c->comm = NULL; }
+}
+
+// Sum a small host value over all ranks (agreement on "did anyone fail" before the big collective).
+extern "C" int sk_comm_sum_u32(sk_ctx *c, uint32_t value, uint32_t *sum)
+{
+    if (!c || !sum) return SK_E_ARG;
+    if (!c->comm) { *sum = value; return SK_OK; }
+    SK_HIP(c, hipSetDevice(c->device));
+    uint32_t *d = c->d_flags + 12;                     // spare words of the flag block
+    SK_HIP(c, hipMemcpyAsync(d, &value, 4, hipMemcpyHostToDevice, c->stream));
+    const int ncclUint32 = 3, ncclSum = 0;
+    if (g_rccl.allreduce(d, d, 1, ncclUint32, ncclSum, c->comm, c->stream) != 0) return sk_fail(c, SK_E_RCCL, "ncclAllReduce failed");
+    SK_HIP(c, hipMemcpyAsync(sum, d, 4, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+// In-library sum all-reduce of the whole counter block; rccl_comm == NULL uses sk_comm_init's.
 extern "C" int sk_counts_allreduce(sk_ctx *c, void *rccl_comm)
 {
-    if (!c || !rccl_comm) return SK_E_ARG;
+    if (!c) return SK_E_ARG;
     if (!c->d_counts) return sk_fail(c, SK_E_STATE, "no table loaded");
-    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
-    static allreduce_fn fn = NULL;
-    if (!fn) {
-        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) return sk_fail(c, SK_E_RCCL, "cannot load librccl: %s", dlerror());
-        fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
-        if (!fn) return sk_fail(c, SK_E_RCCL, "ncclAllReduce not found");
-    }
+    if (!rccl_comm) rccl_comm = c->comm;
+    if (!rccl_comm) return sk_fail(c, SK_E_STATE, "no communicator");
+    int rc = sk_rccl_load(c);
+    if (rc) return rc;
     SK_HIP(c, hipSetDevice(c->device));
     const int ncclUint32 = 3, ncclSum = 0;            // rccl.h: ncclDataType_t / ncclRedOp_t
-    const int rc = fn(c->d_counts, c->d_counts, (size_t)c->nrows * c->ncols, ncclUint32, ncclSum, rccl_comm, c->stream);
-    if (rc != 0) return sk_fail(c, SK_E_RCCL, "ncclAllReduce returned %d", rc);
+    if (g_rccl.allreduce(c->d_counts, c->d_counts, (size_t)c->nrows * c->ncols, ncclUint32, ncclSum, rccl_comm, c->stream) != 0)
+        return sk_fail(c, SK_E_RCCL, "ncclAllReduce failed");
     SK_HIP(c, hipStreamSynchronize(c->stream));
     return SK_OK;
 }

@@ -558,13 +558,32 @@ static void usage(FILE *err)
           "filenames of drug strains> -p [progress output file, optional]\n", err);
 }
 
+static int env_int(const char *a, const char *b, const char *c3, int dflt)
+{
+    const char *v = getenv(a);
+    if (!v && b) v = getenv(b);
+    if (!v && c3) v = getenv(c3);
+    return v ? atoi(v) : dflt;
+}
+
+/* Multi-GPU use (new; one process per GPU, any launcher that sets the usual variables):
+ *   SK_WORLD_SIZE | WORLD_SIZE | OMPI_COMM_WORLD_SIZE,  SK_RANK | RANK | OMPI_COMM_WORLD_RANK,
+ *   SK_LOCAL_RANK | LOCAL_RANK | OMPI_COMM_WORLD_LOCAL_RANK (HIP device; SK_DEVICE overrides),
+ *   SK_RCCL_ID_FILE (rendezvous file for the RCCL unique id; default /tmp/sk_rccl_id.<MASTER_PORT|uid>).
+ * List lines are dealt round-robin to the ranks, every rank's counters are summed with one RCCL
+ * all-reduce, rank 0 alone writes stdout, the progress file and the skip/progress messages. */
 int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
 {
     const char *A = NULL, *B = NULL, *C = NULL, *R = NULL, *P = NULL, *env;
     FILE *progress = NULL;
     skh_keyset ks;
     sk_ctx *ctx = NULL;
-    int c, rc, status = 1, device = 0;
+    int c, rc, status = 1, failed = 0;
+    const int world = env_int("SK_WORLD_SIZE", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", 1);
+    const int rank = env_int("SK_RANK", "RANK", "OMPI_COMM_WORLD_RANK", 0);
+    int device = env_int("SK_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", 0);
+    const int use_comm = world > 1 || getenv("SK_FORCE_COMM") != NULL;
+    uint32_t nfailed = 0;
 
     optind = 1;
     while ((c = getopt(argc, argv, "A:B:C:r:p:Hhud")) != -1) {
@@ -579,7 +598,8 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
         }
     }
     if (!R || !A || !B) { usage(err); return 1; }
-    if (P) {
+    if (world < 1 || rank < 0 || rank >= world) { fprintf(err, "kmer_scrub_count: bad rank %d of %d\n", rank, world); return 1; }
+    if (P && rank == 0) {
         progress = fopen(P, "w");
         if (!progress) { fprintf(err, "could not open progress file %s\n", P); return 1; }
         fputs("adding kmer counts for:\n", progress);
@@ -590,20 +610,51 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     rc = skh_keyset_from_file(&ks, R, SK_REF_TABLE_SLOTS, 1, 1);
     if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", R); goto done; }
     if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s\n", sk_strerror(rc)); goto done; }
-    if (ks.short_records)
+    if (ks.short_records && rank == 0)
         fprintf(err, "kmer_scrub_count: skipped %llu reference record(s) shorter than %d bases "
                      "(the original program crashes on these)\n", (unsigned long long)ks.short_records, SK_K - 1);
 
     rc = sk_ctx_create(&ctx, device);
     if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); goto done; }
+    if (use_comm) {
+        char path[256];
+        if ((env = getenv("SK_RCCL_ID_FILE")) != NULL) snprintf(path, sizeof path, "%s", env);
+        else if ((env = getenv("MASTER_PORT")) != NULL) snprintf(path, sizeof path, "/tmp/sk_rccl_id.%s", env);
+        else snprintf(path, sizeof path, "/tmp/sk_rccl_id.%d", (int)getuid());
+        if (rank == 0) remove(path);
+        {   /* RCCL prints its version banner on stdout, which here is the TSV: park fd 1 on stderr meanwhile */
+            int saved;
+            fflush(stdout);
+            saved = dup(1);
+            dup2(2, 1);
+            rc = sk_comm_init(ctx, rank, world, path, 120);
+            fflush(stdout);
+            dup2(saved, 1);
+            close(saved);
+        }
+        if (rank == 0) remove(path);
+        if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: RCCL rendezvous failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+    }
     rc = skh_keyset_load(ctx, &ks, 4);
-    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); failed = 1; }
+    if (rc == SK_OK && world > 1) rc = sk_counts_zero(ctx, 0);      /* column 0 must not be summed world times: keep it on rank 0 */
+    if (rc == SK_OK && world > 1 && rank == 0) rc = sk_counts_set(ctx, 0, ks.first_count);
 
-    if (skh_scan_list(ctx, A, NULL, 1, progress, err, 0, 1, NULL) != SK_OK) goto done;
-    if (skh_scan_list(ctx, B, NULL, 2, progress, err, 0, 1, NULL) != SK_OK) goto done;
-    if (C && skh_scan_list(ctx, C, R, 3, progress, err, 0, 1, NULL) != SK_OK) goto done;
-    rc = skh_print_counts(ctx, &ks, out, C != NULL);
-    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+    if (!failed && skh_scan_list(ctx, A, NULL, 1, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;
+    if (!failed && skh_scan_list(ctx, B, NULL, 2, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;
+    if (!failed && C && skh_scan_list(ctx, C, R, 3, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;
+    if (use_comm) {
+        /* agree first: a rank that could not read a file must not leave the others in the collective */
+        rc = sk_comm_sum_u32(ctx, (uint32_t)failed, &nfailed);
+        if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+        if (nfailed) goto done;
+        rc = sk_counts_allreduce(ctx, NULL);
+        if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: all-reduce failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+    } else if (failed) goto done;
+    if (rank == 0) {
+        rc = skh_print_counts(ctx, &ks, out, C != NULL);
+        if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+    }
     status = 0;
 done:
     if (ctx) sk_ctx_destroy(ctx);

@@ -48,6 +48,23 @@ def test_program_matches_reference_golden(golden, name, tmp_path):
             assert [ln.split("\t")[0].rstrip("\n") for ln in f] == meta["progress_col1"]
 
 
+def test_program_through_rccl_path_single_rank(golden, tmp_path):
+    """SK_FORCE_COMM=1: the one-process-per-GPU code path (RCCL unique-id rendezvous, failure agreement,
+    all-reduce of the counter block, rank 0 prints) with a world of one; output must not change."""
+    d, meta, out, err = _golden_case(golden, "drug")
+    argv = list(meta["argv"])
+    argv[argv.index("-p") + 1] = str(tmp_path / "progress")
+    env = dict(os.environ, SK_FORCE_COMM="1", SK_RCCL_ID_FILE=str(tmp_path / "rccl_id"))
+    p = subprocess.run([sk.cli_path()] + argv, cwd=d, capture_output=True, env=env)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == out
+    assert p.stderr.endswith(err)                     # (RCCL prints its version banner first)
+    # a rank that cannot read one of its files makes every rank stop with status 1 and no table
+    d2, meta2, _o, err2 = _golden_case(golden, "missing_in_list")
+    p = subprocess.run([sk.cli_path()] + meta2["argv"], cwd=d2, capture_output=True, env=env)
+    assert p.returncode == 1 and p.stdout == b"" and p.stderr.endswith(err2)
+
+
 def test_program_short_contig_divergence(golden):
     """The reference crashes (SIGSEGV) on a strain record shorter than k-1; we skip it, say so on
     stderr, and otherwise produce what the oracle produces with the record skipped."""
