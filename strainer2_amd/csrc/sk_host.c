@@ -16,6 +16,7 @@
 #define _GNU_SOURCE
 #include <ctype.h>
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -447,19 +448,78 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases)
     return rc < 0 ? (int)rc : SK_OK;
 }
 
+/* ---- list walk: files are decoded by a small pool of host threads (gz inflate + record parsing is
+ * the slow part of the whole program), batches are submitted to the one device context under a lock.
+ * SK_THREADS sets the pool size (default: min(16, online CPUs); 1 = the reference's strict sequence). */
+typedef struct {
+    sk_ctx         *ctx;
+    uint32_t        col;
+    pthread_mutex_t submit_mu;         /* sk_scan_stream is one-caller-at-a-time per context */
+    pthread_mutex_t queue_mu;
+    char          **path;              /* work list of this call (files this rank scans), in list order */
+    uint32_t        npath, next;
+    int             rc;                /* first failure ...                                         */
+    uint32_t        rc_index;          /* ... and the list position it belongs to                   */
+    uint64_t        bases;
+} scan_pool;
+
+static int pool_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
+{
+    scan_pool *p = (scan_pool *)user;
+    int rc;
+    pthread_mutex_lock(&p->submit_mu);
+    rc = sk_scan_stream(p->ctx, chunk, nbytes, p->col);
+    pthread_mutex_unlock(&p->submit_mu);
+    return rc;
+}
+
+static void *pool_worker(void *arg)
+{
+    scan_pool *p = (scan_pool *)arg;
+    for (;;) {
+        uint32_t i;
+        uint64_t bases = 0;
+        int64_t rc;
+        pthread_mutex_lock(&p->queue_mu);
+        i = p->next;
+        if (i >= p->npath || p->rc != SK_OK) { pthread_mutex_unlock(&p->queue_mu); break; }
+        p->next++;
+        pthread_mutex_unlock(&p->queue_mu);
+        rc = skh_decode_file(p->path[i], 32u << 20, pool_sink, p, &bases);
+        pthread_mutex_lock(&p->queue_mu);
+        p->bases += bases;
+        if (rc < 0 && (p->rc == SK_OK || i < p->rc_index)) { p->rc = (int)rc; p->rc_index = i; }
+        pthread_mutex_unlock(&p->queue_mu);
+    }
+    return NULL;
+}
+
 int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
                   FILE *err, uint32_t rank, uint32_t world, uint64_t *bases)
 {
     FILE *fp = fopen(list_path, "r");
     char *line = NULL, *nl;
     size_t cap = 0;
-    uint32_t idx = 0;
-    int rc = SK_OK;
+    uint32_t idx = 0, pcap = 0, i;
+    int nthreads = 1;
+    const char *env = getenv("SK_THREADS");
+    scan_pool pool;
     if (!fp) {
         if (err) fprintf(err, "could not read file %s in GEN_all_kmer_counts()\n", list_path);
         return SK_E_OPEN;
     }
     if (world == 0) world = 1;
+    memset(&pool, 0, sizeof pool);
+    pool.ctx = ctx;
+    pool.col = col;
+    pthread_mutex_init(&pool.submit_mu, NULL);
+    pthread_mutex_init(&pool.queue_mu, NULL);
+    if (env) nthreads = atoi(env);
+    else { long n = sysconf(_SC_NPROCESSORS_ONLN); nthreads = n > 16 ? 16 : (int)n; }
+    if (nthreads < 1) nthreads = 1;
+
+    /* the reference logs "<line>\t<time>" before it scans each file (src/genome_compare.c:167-170);
+     * with a pool the time is the time of the list walk */
     while (getline(&line, &cap, fp) != -1) {
         if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
         if (progress && rank == 0) {
@@ -472,20 +532,38 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
             continue;
         }
         if (idx++ % world != rank) continue;
-        rc = skh_scan_file(ctx, line, col, bases);
-        if (rc == SK_E_OPEN) {
-            if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", line);
-            break;
+        if (nthreads == 1) {                                  /* strict sequence, as the reference */
+            uint64_t b = 0;
+            int64_t rc = skh_decode_file(line, 32u << 20, pool_sink, &pool, &b);
+            pool.bases += b;
+            if (rc < 0) { pool.rc = (int)rc; pool.path = (char **)realloc(pool.path, sizeof(char *)); pool.path[0] = strdup(line); pool.npath = 1; pool.rc_index = 0; break; }
+            continue;
         }
-        if (rc != SK_OK) {
-            if (err) fprintf(err, "kmer_scrub_count: device error while scanning %s: %s (%s)\n", line,
-                             sk_strerror(rc), sk_last_error(ctx));
-            break;
-        }
+        if (pool.npath == pcap) { pcap = pcap ? pcap * 2 : 64; pool.path = (char **)realloc(pool.path, pcap * sizeof(char *)); }
+        pool.path[pool.npath++] = strdup(line);
     }
     free(line);
     fclose(fp);
-    return rc;
+    if (nthreads > 1 && pool.npath) {
+        pthread_t *th;
+        if ((uint32_t)nthreads > pool.npath) nthreads = (int)pool.npath;
+        th = (pthread_t *)malloc((size_t)nthreads * sizeof *th);
+        for (i = 0; i < (uint32_t)nthreads; i++) pthread_create(&th[i], NULL, pool_worker, &pool);
+        for (i = 0; i < (uint32_t)nthreads; i++) pthread_join(th[i], NULL);
+        free(th);
+    }
+    if (pool.rc == SK_E_OPEN) {
+        if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", pool.path[pool.rc_index]);
+    } else if (pool.rc != SK_OK) {
+        if (err) fprintf(err, "kmer_scrub_count: device error while scanning %s: %s (%s)\n", pool.path[pool.rc_index],
+                         sk_strerror(pool.rc), sk_last_error(ctx));
+    }
+    if (bases) *bases += pool.bases;
+    for (i = 0; i < pool.npath; i++) free(pool.path[i]);
+    free(pool.path);
+    pthread_mutex_destroy(&pool.submit_mu);
+    pthread_mutex_destroy(&pool.queue_mu);
+    return pool.rc;
 }
 
 /* =========================================================================================

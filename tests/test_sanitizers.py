@@ -22,7 +22,7 @@ def _fixture_files(golden):
 def test_host_layer_under_asan_ubsan(golden, tmp_path):
     exe = str(tmp_path / "host_sanitize")
     subprocess.run(["gcc"] + SAN + [os.path.join(REPO, "tests", "native", "host_sanitize.c"),
-                                   os.path.join(REPO, "strainer2_amd", "csrc", "sk_host.c"), "-lz", "-o", exe], check=True)
+                                   os.path.join(REPO, "strainer2_amd", "csrc", "sk_host.c"), "-lz", "-lpthread", "-o", exe], check=True)
     files = _fixture_files(golden)
     assert len(files) > 30
     p = subprocess.run([exe] + files, env=ENV, capture_output=True)

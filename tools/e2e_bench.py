@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""End-to-end (from files, through the drop-in program) rate: synthetic 5 Mbp strain, NFILES read
+files of READS reads each as plain FASTQ and as .gz; wall clock of strainer2_amd/bin/kmer_scrub_count
+with 1 and with SK_THREADS host decode threads.  Numbers go to DESIGN.md (never bench.py's `value`)."""
+import gzip
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from strainer2_amd import synth  # noqa: E402
+
+NFILES = int(os.environ.get("NFILES", "16"))
+READS = int(os.environ.get("READS", "500000"))
+work = os.environ.get("WORK", "/tmp/sk_e2e")
+os.makedirs(work, exist_ok=True)
+contigs = synth.make_strain()
+open(os.path.join(work, "strain.fa"), "wb").write(synth.strain_fasta(contigs))
+qual = b"I" * 150
+t0 = time.time()
+for kind in ("fq", "fq.gz"):
+    names = []
+    for i in range(NFILES):
+        p = os.path.join(work, f"reads{i}.{kind}")
+        names.append(p)
+        if os.path.exists(p):
+            continue
+        stream, _ = synth.make_reads(contigs, READS, seed=synth.SEED + 100 + i)
+        rows = stream.reshape(READS, 151)[:, :150]
+        body = b"".join(b"@r%d\n%s\n+\n%s\n" % (j, rows[j].tobytes(), qual) for j in range(READS))
+        if kind.endswith("gz"):
+            with gzip.open(p, "wb", compresslevel=4) as f:
+                f.write(body)
+        else:
+            open(p, "wb").write(body)
+    open(os.path.join(work, f"B_{kind}.txt"), "w").write("\n".join(names) + "\n")
+open(os.path.join(work, "A.txt"), "w").write(os.path.join(work, "strain.fa") + "\n")
+print(f"inputs ready in {time.time() - t0:.1f} s: {NFILES} x {READS} reads per format", flush=True)
+exe = os.path.join(REPO, "strainer2_amd", "bin", "kmer_scrub_count")
+bases = NFILES * READS * 150
+for kind in ("fq", "fq.gz"):
+    for threads in (1, 4, 16):
+        env = dict(os.environ, SK_THREADS=str(threads))
+        t = time.time()
+        with open(os.devnull, "wb") as null:
+            subprocess.run([exe, "-r", os.path.join(work, "strain.fa"), "-A", os.path.join(work, "A.txt"),
+                            "-B", os.path.join(work, f"B_{kind}.txt")], stdout=null, check=True, env=env)
+        dt = time.time() - t
+        print(f"{kind:6s} SK_THREADS={threads:2d}: {dt:6.2f} s wall for {bases / 1e9:.2f} Gbase in -B  "
+              f"=> {bases / dt / 1e9:.3f} Gbase/s end to end (includes strain build, table print)", flush=True)
