@@ -206,3 +206,43 @@ def test_full_size_properties_cfg2(ctx):
     assert np.array_equal(ctx.counts(2) + ctx.counts(3), c1)
     # (e) planted hits are found: ~2 % of reads x up to 120 windows
     assert 1_500_000 < int(c1.sum()) < 2_600_000
+
+
+def test_strain_against_itself_reproduces_multiplicity(ctx):
+    """Property at full key-set size: scanning the strain's own contigs counts every k-mer exactly as
+    often as the build phase saw it (column 0), both strands; every window is a hit (100 % pass rate
+    through both filter stages and queues)."""
+    contigs = synth.make_strain()
+    sstream = synth.strain_stream(contigs)
+    ks = sk.Keyset.from_stream(sstream)
+    ctx.load_keyset(ks, 4)
+    ctx.scan_stream(sstream, 1)
+    rc = b"\n".join(bytes(synth._COMP[c][::-1]) for c in contigs) + b"\n"
+    ctx.scan_stream(rc, 2)
+    assert np.array_equal(ctx.counts(1), ks.first_count())
+    assert np.array_equal(ctx.counts(2), ks.first_count())
+    assert np.array_equal(ctx.counts(0), ks.first_count())
+
+
+def test_low_complexity_and_repeats_vs_oracle(ctx):
+    """Homopolymers, short tandem repeats and long exact repeats: one minimizer for very long runs of
+    windows (events of maximal length), heavy key multiplicity, palindromic 16-mers."""
+    rng = random.Random(1234)
+    unit = _synth.rand_dna(rng, 700)
+    strain = (b"A" * 200 + unit + b"ACACACACAC" * 30 + unit + b"T" * 150 + b"GATC" * 60 + _synth.rand_dna(rng, 500) +
+              b"AATT" * 40 + unit[::-1] + b"C" * 90)
+    sstream = strain + b"\n"
+    ks = sk.Keyset.from_stream(sstream)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    ctx.load_keyset(ks, 4)
+    reads = [strain[i:i + 180] for i in range(0, len(strain) - 180, 37)]
+    reads += [b"A" * 300, b"T" * 77, b"AC" * 100, b"GATC" * 50, _synth.revcomp(strain[150:600]), b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAC" * 4]
+    data = b"\n".join(reads) + b"\n"
+    ctx.scan_stream(data, 1)
+    t.scan_stream(data, 1)
+    okeys, ocounts = t.rows()
+    assert ks.keys() == okeys
+    assert np.array_equal(ctx.counts(0), ocounts[:, 0])
+    assert np.array_equal(ctx.counts(1), ocounts[:, 1])
+    assert int(ocounts[:, 1].max()) > 20
