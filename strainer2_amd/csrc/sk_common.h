@@ -40,8 +40,8 @@ SK_HD int sk_is_hard_break(uint32_t b)
     return ((b & 0xDFu) == 'N') | (b == '\n') | (b == 0u);
 }
 
-/* slot hash of a packed canonical key (device table; not the reference's djb2, which only
- * matters for row ORDER and is replayed on the host) */
+/* hash of a packed canonical key for the HOST builder's de-duplication set (the reference's djb2
+ * only matters for row ORDER and is replayed separately; the device table uses sk_khash) */
 SK_HD uint32_t sk_hash62(uint64_t key)
 {
     uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
@@ -100,20 +100,9 @@ SK_HD uint32_t sk_minimizer62(uint64_t key)
 /* first table slot of a key: uniform over the table (bits 8..31 of the k-mer hash); linear
  * probing from there.  (Placing table lines by minimizer was tried and rejected: keys arrive in
  * clumps of ~8 per minimizer and linear-probe runs get long: 3.7x slower end to end.) */
-SK_HD uint32_t sk_slot0(uint32_t mz, uint32_t kh, uint32_t mask)
+SK_HD uint32_t sk_slot0(uint32_t kh, uint32_t mask)
 {
-    (void)mz;
     return (kh >> 8) & mask;
-}
-
-/* second, independent hash for the prefilter */
-SK_HD uint32_t sk_hash62b(uint64_t key)
-{
-    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    uint32_t h = (lo * 0x85EBCA6Bu) ^ hi;
-    h ^= h >> 13; h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    return h;
 }
 
 /* FNV-1a over the 31 bytes of a wide key */

@@ -1,21 +1,26 @@
 // sk_device.hip -- device layer of libstrainer_kmer.so: hand-written HIP for CDNA4 / gfx950.
 //
-// Kernels (all integer work; HBM/cache bound, no MFMA):
-//   sk_table_insert   build the open-addressed key table in HBM (atomicCAS on 64-bit slots)
-//   sk_scan_main      THE hot kernel: slide the k=31 window over a record stream,
-//                     rolling forward + reverse-complement 2-bit packing in registers,
-//                     canonical = max, probe the table, atomicAdd the row counter.
-//                     Replaces reference src/genome_compare.c:213-229 + src/BIO_hash.c:161-172.
-//   sk_scan_wide      exact byte-string path for the rare windows that contain bytes other
-//                     than ACGT (U / IUPAC / junk): reproduces the reference's signed-char
-//                     orientation compare through its COMPLEMENT map.  Runs only when
-//                     sk_scan_main saw such a window in the batch (device-side early exit).
+// Kernels (all integer/byte work; bound by VALU issue and random-access rate, no MFMA):
+//   sk_scan_main      THE hot kernel (replaces reference src/genome_compare.c:213-229 +
+//                     src/BIO_hash.c:161-172; in TALLY mode src/strain_detect.c:471-485):
+//                       phase 1  bytes -> 2-bit code words + "not ACGT" masks in LDS (SWAR)
+//                       phase 2  per thread: 16-mers by v_alignbit, sliding-minimum minimizer,
+//                                live masks by bit tricks, runs of windows sharing a minimizer
+//                       stage 1  one L2 filter lookup per run, 64 runs at a time, pipelined
+//                       stage 2  windows of passing runs rebuilt from LDS (62-bit canonical key),
+//                                probed 64 at a time in the HBM table; atomicAdd on a hit
+//   sk_scan_wide      exact byte-string path for the rare windows that contain bytes other than
+//                     ACGT (U / IUPAC / junk): the reference's signed-char orientation compare
+//                     through its COMPLEMENT map.  Early exit unless phase 1 saw such a byte.
+//   sk_table_insert   open-addressed key table (atomicCAS on the key word)
+//   sk_bloom_insert   minimizer filter (both strands of every key)
+//   sk_gather/scatter counters <-> caller row order
 //
 // Data layout in HBM:
-//   slots  [S]  16 B  {u64 key, u32 row, u32 pad}: open addressing, linear probing, S = 2^s,
-//                     empty = key all ones.  Key and row id share a slot so that a hit costs one
-//                     random line fetch, not two.
-//   counts [ncols][nrows] u32
+//   slots  [S]  16 B  {u64 key, u32 counter index, u32 pad}: open addressing, linear probing,
+//                     S = 2^s >= 2 nrows, empty = key all ones (one random line per hit)
+//   filter      8 B   blocks of the minimizer Bloom set, 2^25 bits for a 5 Mbp strain (L2-resident)
+//   counts [ncols][nrows] u32, in locality (first-occurrence) order: one read's hits are adjacent
 //   stream      u8    record stream: sequence bytes, records separated by '\n'
 //
 #include <hip/hip_runtime.h>
@@ -44,9 +49,14 @@
 #define SK_REC_DW       12                  // per record: 8 code words (u32) + 8 invalid masks (u16) = 48 B;
                                             // 12-dword lane stride keeps ds_read_b128 conflict-free
 #define SK_NCHUNK       (SK_NREC * SK_SPAN_CH)
-#define SK_EVQ          (64 + 3 * 64)       // minimizer-run events: drained below 64 every 2 windows
+#ifndef SK_PUMP_EVERY
+#define SK_PUMP_EVERY   2                   // windows between two drain sites (power of two <= 16)
+#endif
+#define SK_EVQ          (64 + (SK_PUMP_EVERY + 1) * 64)   // minimizer-run events: below 64 after every drain site
 #define SK_WQ           (64 + 64)           // tile positions of windows waiting for their table probe
+#ifndef SK_BATCH
 #define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
+#endif
 
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
 
@@ -100,7 +110,7 @@ __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32
 template <bool TALLY, bool NOATOMIC = false>
 __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, const sk_sink &k, uint32_t pos)
 {
-    uint32_t slot = sk_slot0(0u, sk_khash(canon), t.mask);
+    uint32_t slot = sk_slot0(sk_khash(canon), t.mask);
     for (;;) {
         const sk_u4 e = t.slots[slot];
         const uint64_t key = sk_slot_key(e);
@@ -169,7 +179,7 @@ __device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_
 //            word (2 bits/base) + a 16-bit "not ACGT" mask in LDS; bytes that are neither ACGT,
 //            N nor '\n' raise the batch's "needs the byte-string kernel" flag.
 //   phase 2  each thread walks its 128 positions in 16-base chunks, all in registers:
-//              16-mer state   f16/r16 roll by one lshl_or / alignbit per base
+//              16-mers        straight from two adjacent code words, one v_alignbit_b32 per base
 //              minimizer      sliding minimum of the (forward-strand) 16-mer hashes over the window
 //                             (prefix minima of this chunk + suffix minima of the previous one)
 //              live mask      "31 valid bases end here" for the 16 positions by bit tricks
@@ -372,7 +382,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             push_event(chg, run_mz, ebase, run_rel, o);
             run_rel = chg ? o : run_rel;
             run_mz = mz;
-            if ((o & 1) == 1 && o != 15 && qe >= 64u) pump();
+            if ((o & (SK_PUMP_EVERY - 1)) == SK_PUMP_EVERY - 1 && o != 15 && qe >= 64u) pump();
         }
         if (qe >= 64u) pump();
         run_rel -= 16;
@@ -488,7 +498,7 @@ __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_
     const uint64_t k = in[i];
     if (k == SK_EMPTY64) return;                       // wide row: not in this table
     if (k > SK_KMASK62) { atomicAdd(&flags[1], 1u); return; }
-    uint32_t slot = sk_slot0(0u, sk_khash(k), mask);
+    uint32_t slot = sk_slot0(sk_khash(k), mask);
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long *)&slots[slot],
                                                 (unsigned long long)SK_EMPTY64, (unsigned long long)k);

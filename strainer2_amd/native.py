@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libstrainer_kmer.so")
+    # SK_LIBRARY: another build of the same library (A/B timing of kernel variants)
+    return os.environ.get("SK_LIBRARY") or os.path.join(_HERE, "lib", "libstrainer_kmer.so")
 
 
 def cli_path(name="kmer_scrub_count"):

@@ -6,6 +6,7 @@
 set -o pipefail
 TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 1 --no-cpu --no-host-rate $@"
