@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (cfg 2: 10 M)")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of reads drawn from the strain (cfg 2: 0.02)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--bloom-bits-log2", type=int, default=None)
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive host-buffer passes (keeps profiles clean)")
@@ -98,7 +99,7 @@ def main():
     from strainer2_amd import synth
     contigs = synth.make_strain()
     sstream = synth.strain_stream(contigs)
-    reads, nbases = synth.make_reads(contigs, args.reads, args.read_len, seed=synth.SEED + 1 + rank)
+    reads, nbases = synth.make_reads(contigs, args.reads, args.read_len, hit_frac=args.hit_frac, seed=synth.SEED + 1 + rank)
 
     # CPU baseline first: it forks, and must do so before this process touches the GPU
     cpu = None
@@ -212,6 +213,7 @@ def main():
             "config": {"workload": "configs[1]: 5 Mbp synthetic strain (-r) vs %d x %d bp synthetic reads (-B) per GPU, k=31, "
                                    "reads resident in HBM as a record stream" % (args.reads, args.read_len),
                        "strain_keys": int(ks.nrows), "reads_per_gpu": args.reads, "read_len": args.read_len,
+                       "strain_read_fraction": args.hit_frac,
                        "bases_per_step_per_gpu": nbases, "hits_per_pass_rank0_or_sum": hits_per_pass,
                        "pcie_inclusive_bases_per_s_host_buffers": host_rate,
                        "sharding": "reads sharded by rank, table replicated, one RCCL all-reduce of counts" if world > 1 else "single GPU"},

@@ -41,6 +41,7 @@ extern "C" {
 #define SK_K                 31            /* seed length: src/kmer_scrub_count.c:39, src/strain_detect.c:78 */
 #define SK_REF_TABLE_SLOTS   8000000u      /* DEFAULT_GENOME_HASH_SIZE: src/genome_compare.h:20 */
 #define SK_KEY_NONE          UINT64_MAX    /* "no packed key for this row" (row is a wide key) */
+#define SK_LOCALITY_FWD      0x80000000u   /* locality[] flag: the key is the strain text itself at its first occurrence */
 
 /* error codes (0 = success) */
 #define SK_OK            0
@@ -76,8 +77,10 @@ const char *sk_strerror(int code);
 int sk_table_load(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t ncols);
 /* Same, with a "locality" permutation: locality[r] = position of row r's key in an order in which
  * keys that follow each other in the strain are neighbours (the host layer passes first-occurrence
- * order).  The device keeps its counters in that order, so the hits of one read land on adjacent
- * counters and their atomics coalesce.  Invisible through sk_counts_fetch/set and sk_tally_batch
+ * order), in the low 31 bits; bit 31 (SK_LOCALITY_FWD) says whether the key equals the strain text at
+ * that occurrence or its reverse complement.  The device keeps its counters (and a copy of the keys)
+ * in that order: the hits of one read land on adjacent counters (their atomics coalesce), and the
+ * neighbours of a window that hit are first looked for next to it instead of through the hash.  Invisible through sk_counts_fetch/set and sk_tally_batch
  * (they speak caller rows); sk_counts_device_ptr/sk_counts_allreduce see the block in locality
  * order, which is the same on every rank that loaded the same key set. */
 int sk_table_load_ex(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t ncols, const uint32_t *locality);

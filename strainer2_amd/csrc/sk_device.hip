@@ -53,6 +53,7 @@
 #define SK_PUMP_EVERY   2                   // windows between two drain sites (power of two <= 16)
 #endif
 #define SK_EVQ          (64 + (SK_PUMP_EVERY + 1) * 64)   // minimizer-run events: below 64 after every drain site
+#define SK_ANCHOR       16u                 // stage 2: one hash probe per this many consecutive windows
 #define SK_WQ           (64 + 64)           // tile positions of windows waiting for their table probe
 #ifndef SK_BATCH
 #define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
@@ -61,8 +62,10 @@
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
 
 struct sk_table_view {
-    const sk_u4    *slots;           // {key lo, key hi, row, pad}
+    const sk_u4    *slots;           // {key lo, key hi, counter index, 1 if the key is strain text at its first occurrence}
     uint32_t        mask;
+    const uint64_t *keys_by_loc;     // the keys again, by counter index (strain order): neighbours of a hit
+    uint32_t        nrows;
     // L2-resident prefilter: a Bloom set of the MINIMIZER hashes that occur in the strain
     // (about nrows/8 items).  64-bit blocks chosen by the low bits of the minimizer hash,
     // two bits in each 32-bit half.
@@ -157,7 +160,7 @@ __device__ __forceinline__ uint32_t sk_revcomp32(uint32_t x)              // 16 
 }
 
 // canonical packed 31-mer of the window that ends at tile-relative position e, from the LDS records
-__device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_t e)
+__device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_t e, bool &is_fwd)
 {
     const uint32_t b = e + SK_SPAN;                        // record 0 holds the 128 bases before the tile
     const uint32_t c = b >> 4, s = 2u * (15u - (b & 15u));
@@ -170,7 +173,8 @@ __device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_
     uint64_t r = ((uint64_t)__builtin_bitreverse32(lo) << 32) | __builtin_bitreverse32(hi);
     r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
     const uint64_t rc = (~r) >> 2;
-    return fwd > rc ? fwd : rc;
+    is_fwd = fwd > rc;
+    return is_fwd ? fwd : rc;
 }
 
 // THE hot kernel.  A workgroup owns SK_TILE consecutive window-end positions of the record stream.
@@ -247,15 +251,60 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 #pragma unroll
     for (int b = 0; b < SK_BATCH; b++) { pev[b] = make_uint2(0u, 0u); pblk[b] = make_uint2(0u, 0u); }
 
-    auto probe_batch = [&]() {                                    // stage 2 on 64 queued windows
+    // Stage 2 on the top n (<= 64) queued windows.  Queue entries of one read are consecutive tile
+    // positions, i.e. consecutive windows; if the strain contains them they are consecutive strain
+    // k-mers, whose keys sit next to each other in keys_by_loc.  So only every SK_ANCHOR-th window of
+    // such a stretch (and its first one) pays a random hash probe; the others first compare their
+    // key with the anchor's neighbour in strain order (one coalesced load) and fall back to the hash
+    // only when that fails (read error, repeated k-mer, contig end).  Every hit is a full 62-bit
+    // compare either way.
+    auto probe_some = [&](uint32_t n) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        qw -= 64u;
-        const uint32_t e = wq[qw + lane];
-        const uint64_t cn = sk_window_canon(rec, e);
-        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe<TALLY, ABLATE == 3>(cn, table, sink, (uint32_t)tile0 + e);
+        qw -= n;
+        const bool act = lane < n;
+        const uint32_t e = act ? wq[qw + lane] : 0xFFFF0000u + lane * 2u;     // inactive: never consecutive
+        bool w_fwd = false;
+        const uint64_t cn = act ? sk_window_canon(rec, e, w_fwd) : 0ull;
+        const uint32_t pos = (uint32_t)tile0 + e;
+        if (ABLATE == 2) { __builtin_amdgcn_wave_barrier(); return; }
+        const uint32_t e_prev = (uint32_t)__shfl_up((int)e, 1);
+        const bool first = (lane == 0u) | (e != e_prev + 1u);                  // first window of a stretch
+        const unsigned long long fm = __ballot(first);
+        const uint32_t first_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
+        const uint32_t k = lane - first_lane;                                  // offset inside the stretch
+        const bool anchor = act & ((k & (SK_ANCHOR - 1u)) == 0u);
+        uint32_t a_idx = 0xFFFFFFFFu, a_dir = 0u;                              // anchor's counter index / read direction
+        if (anchor) {
+            uint32_t slot = sk_slot0(sk_khash(cn), table.mask);
+            for (;;) {
+                const sk_u4 s4 = table.slots[slot];
+                const uint64_t key = sk_slot_key(s4);
+                if (key == cn) {
+                    a_idx = s4.z;
+                    a_dir = (uint32_t)w_fwd ^ (s4.w & 1u);                     // 0: the read runs along the strain, 1: against it
+                    sk_on_hit<TALLY, ABLATE == 3>(sink, a_idx, pos);
+                    break;
+                }
+                if (key == SK_EMPTY64) break;
+                slot = (slot + 1u) & table.mask;
+            }
+        }
+        const uint32_t my_anchor = lane - (k & (SK_ANCHOR - 1u));
+        const uint32_t n_idx = (uint32_t)__shfl((int)a_idx, (int)my_anchor);
+        const uint32_t n_dir = (uint32_t)__shfl((int)a_dir, (int)my_anchor);
+        if (act & !anchor) {
+            bool done = false;
+            if (n_idx != 0xFFFFFFFFu && table.keys_by_loc) {
+                const uint32_t d = k & (SK_ANCHOR - 1u);
+                const uint32_t idx = n_dir ? n_idx - d : n_idx + d;            // wraps below 0 -> >= nrows
+                if (idx < table.nrows && table.keys_by_loc[idx] == cn) { sk_on_hit<TALLY, ABLATE == 3>(sink, idx, pos); done = true; }
+            }
+            if (!done) sk_probe<TALLY, ABLATE == 3>(cn, table, sink, pos);
+        }
         __builtin_amdgcn_wave_barrier();
     };
+    auto probe_batch = [&]() { probe_some(64u); };
 
     auto complete = [&]() {                                       // judge the pending batch
 #pragma unroll
@@ -398,11 +447,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     while (pn != 0u || qe != 0u) { complete(); issue(); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane < qw) {
-        const uint32_t e = wq[lane];
-        const uint64_t cn = sk_window_canon(rec, e);
-        if (ABLATE != 2 || cn == 0x123456789ull) sk_probe<TALLY>(cn, table, sink, (uint32_t)tile0 + e);
-    }
+    if (qw) probe_some(qw);
     if (bad) atomicAdd(&flags[0], 1u);
     if (STATS) {
         atomicAdd((unsigned long long *)&flags[4], (unsigned long long)n_live);
@@ -491,18 +536,24 @@ __global__ void sk_fill64(uint64_t *p, uint64_t n, uint64_t v)
 }
 
 __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_u4 *slots, uint32_t mask, uint32_t *flags,
-                                const uint32_t *__restrict__ perm)
+                                const uint32_t *__restrict__ perm, const uint32_t *__restrict__ locality, uint64_t *keys_by_loc)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = in[i];
+    const uint32_t idx = perm ? perm[i] : i;
+    if (keys_by_loc) keys_by_loc[idx] = k;             // (all ones for a wide row: never equals a packed window)
     if (k == SK_EMPTY64) return;                       // wide row: not in this table
     if (k > SK_KMASK62) { atomicAdd(&flags[1], 1u); return; }
     uint32_t slot = sk_slot0(sk_khash(k), mask);
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long *)&slots[slot],
                                                 (unsigned long long)SK_EMPTY64, (unsigned long long)k);
-        if (old == SK_EMPTY64) { ((uint32_t *)&slots[slot])[2] = perm ? perm[i] : i; return; }
+        if (old == SK_EMPTY64) {
+            ((uint32_t *)&slots[slot])[2] = idx;
+            ((uint32_t *)&slots[slot])[3] = locality ? locality[i] >> 31 : 0u;
+            return;
+        }
         if (old == k) { atomicAdd(&flags[1], 1u); return; }     // duplicate key
         slot = (slot + 1u) & mask;
     }
@@ -561,6 +612,8 @@ struct sk_ctx {
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
     uint32_t    *d_perm, *d_inv;      // locality order of the counters (NULL = caller's row order)
+    uint32_t    *d_locality;          // the caller's locality[] as given (with the orientation bit)
+    uint64_t    *d_keys_by_loc;
     uint32_t    *d_tmp;               // [nrows] scratch for fetch/set through the permutation
     std::vector<uint32_t> h_perm;     // host copy of the permutation (empty = identity)
     // wide keys
@@ -658,6 +711,8 @@ static void sk_table_release(sk_ctx *c)
     hipFree(c->d_perm); c->d_perm = NULL;
     c->h_perm.clear();
     hipFree(c->d_inv); c->d_inv = NULL;
+    hipFree(c->d_locality); c->d_locality = NULL;
+    hipFree(c->d_keys_by_loc); c->d_keys_by_loc = NULL;
     hipFree(c->d_tmp); c->d_tmp = NULL;
     hipFree(c->d_wide_keys); c->d_wide_keys = NULL;
     hipFree(c->d_wide_rows); c->d_wide_rows = NULL;
@@ -706,8 +761,9 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
     if (locality) {                                    // must be a permutation of 0..nrows-1
         std::vector<uint8_t> seen(nrows, 0);
         for (uint32_t i = 0; i < nrows; i++) {
-            if (locality[i] >= nrows || seen[locality[i]]) return sk_fail(c, SK_E_ARG, "locality is not a permutation");
-            seen[locality[i]] = 1;
+            const uint32_t l = locality[i] & 0x7FFFFFFFu;
+            if (l >= nrows || seen[l]) return sk_fail(c, SK_E_ARG, "locality is not a permutation");
+            seen[l] = 1;
         }
     }
     SK_HIP(c, hipSetDevice(c->device));
@@ -732,13 +788,17 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
             SK_HIP(c, hipMalloc((void **)&c->d_perm, (size_t)nrows * 4));
             SK_HIP(c, hipMalloc((void **)&c->d_inv, (size_t)nrows * 4));
             SK_HIP(c, hipMalloc((void **)&c->d_tmp, (size_t)nrows * 4));
-            c->h_perm.assign(locality, locality + nrows);
-            SK_HIP(c, hipMemcpyAsync(c->d_perm, locality, (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
+            c->h_perm.resize(nrows);
+            for (uint32_t i = 0; i < nrows; i++) c->h_perm[i] = locality[i] & 0x7FFFFFFFu;
+            SK_HIP(c, hipMalloc((void **)&c->d_locality, (size_t)nrows * 4));
+            SK_HIP(c, hipMalloc((void **)&c->d_keys_by_loc, (size_t)nrows * 8));
+            SK_HIP(c, hipMemcpyAsync(c->d_locality, locality, (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
+            SK_HIP(c, hipMemcpyAsync(c->d_perm, c->h_perm.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
             SK_HIP(c, hipMemsetAsync(c->d_inv, 0xFF, (size_t)nrows * 4, c->stream));
             hipLaunchKernelGGL(sk_invert_perm, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, c->d_inv, c->d_perm, nrows, c->d_flags);
         }
         hipLaunchKernelGGL(sk_table_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
-                           d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags, c->d_perm);
+                           d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags, c->d_perm, c->d_locality, c->d_keys_by_loc);
         // minimizer filter: automatic size = smallest power of two >= 4 bits per key (the set holds
         // ~nrows/8 minimizers, i.e. ~32 bits each: false positives ~0.1 %); 2 MiB for a 5 Mbp strain
         long bb = c->bloom_bits_log2;
@@ -803,6 +863,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     const uint64_t ntiles = (nbytes + SK_TILE - 1) / SK_TILE;
     if (ntiles > 0x7FFFFFFFull) return sk_fail(c, SK_E_ARG, "batch too large");
     sk_table_view tv;
+    tv.keys_by_loc = c->d_keys_by_loc; tv.nrows = c->nrows;
     tv.slots = c->d_keys; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
     tv.bloom = c->d_bloom;
     tv.bloom_shift = 32u - c->bloom_blocks_log2;

@@ -145,7 +145,7 @@ typedef struct {
     /* wide-key set */
     char *wkeys; uint32_t *wv; uint32_t wn, wcap; uint32_t *windex; uint32_t wmask;
     /* insertion order */
-    uint64_t *order; uint32_t *count; uint32_t n, cap;
+    uint64_t *order; uint32_t *count; uint8_t *fwd_first; uint32_t n, cap;
     uint32_t default_val, incr;
     uint64_t short_records;
     signed char comp[256];
@@ -168,7 +168,7 @@ static void builder_init(builder *b, uint32_t default_val, uint32_t incr)
 static void builder_free(builder *b)
 {
     free(b->pk); free(b->pv); free(b->wkeys); free(b->wv); free(b->windex);
-    free(b->order); free(b->count);
+    free(b->order); free(b->count); free(b->fwd_first);
 }
 
 static uint32_t builder_append(builder *b, uint64_t entry)
@@ -177,9 +177,11 @@ static uint32_t builder_append(builder *b, uint64_t entry)
         b->cap = b->cap ? b->cap * 2 : 1 << 16;
         b->order = (uint64_t *)realloc(b->order, (size_t)b->cap * sizeof(uint64_t));
         b->count = (uint32_t *)realloc(b->count, (size_t)b->cap * sizeof(uint32_t));
+        b->fwd_first = (uint8_t *)realloc(b->fwd_first, (size_t)b->cap);
     }
     b->order[b->n] = entry;
     b->count[b->n] = b->default_val;
+    b->fwd_first[b->n] = 0;
     return b->n++;
 }
 
@@ -201,7 +203,8 @@ static void builder_grow_packed(builder *b)
     free(ok); free(ov);
 }
 
-static void builder_add_packed(builder *b, uint64_t key)
+/* is_fwd: the key is the strain's text itself at this occurrence (not its reverse complement) */
+static void builder_add_packed(builder *b, uint64_t key, int is_fwd)
 {
     uint64_t s = sk_hash62(key) & b->pmask;
     while (b->pk[s] != SK_EMPTY64) {
@@ -210,6 +213,7 @@ static void builder_add_packed(builder *b, uint64_t key)
     }
     b->pk[s] = key;
     b->pv[s] = builder_append(b, key);
+    b->fwd_first[b->pv[s]] = (uint8_t)is_fwd;
     if (++b->pcount * 2 > b->pmask) builder_grow_packed(b);
 }
 
@@ -259,7 +263,7 @@ static int builder_record(void *user, char *seq, size_t len)
         run = sk_is_acgt(c) ? run + 1 : 0;
         soft = sk_is_hard_break(c) ? 0 : soft + 1;
         if (run >= SK_K) {
-            builder_add_packed(b, fwd > rc ? fwd : rc);
+            builder_add_packed(b, fwd > rc ? fwd : rc, fwd > rc);
         } else if (soft >= SK_K) {
             char u[SK_K], o[SK_K + 1];
             const char *w = seq + i - (SK_K - 1);
@@ -276,7 +280,7 @@ static int builder_record(void *user, char *seq, size_t len)
             if (pure) {                              /* e.g. U in the strain whose revcomp wins */
                 uint64_t key = 0;
                 for (j = 0; j < SK_K; j++) key = (key << 2) | sk_code((uint8_t)o[j]);
-                builder_add_packed(b, key);
+                builder_add_packed(b, key, sign >= 0);
             } else {
                 builder_add_wide(b, o);
             }
@@ -361,7 +365,7 @@ static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
     for (r = 0; r < b->n; r++) {
         uint64_t ent = b->order[rows[r]];
         ks->first_count[r] = b->count[rows[r]];
-        ks->locality[r] = rows[r];
+        ks->locality[r] = rows[r] | (b->fwd_first[rows[r]] ? SK_LOCALITY_FWD : 0u);
         if (ent & WIDE_FLAG) { ks->packed[r] = SK_KEY_NONE; wide_newrow[ent & 0xFFFFFFFFu] = r; }
         else ks->packed[r] = ent;
     }
