@@ -53,7 +53,10 @@
 #define SK_PUMP_EVERY   2                   // windows between two drain sites (power of two <= 16)
 #endif
 #define SK_EVQ          (64 + (SK_PUMP_EVERY + 1) * 64)   // minimizer-run events: below 64 after every drain site
-#define SK_ANCHOR       16u                 // stage 2: one hash probe per this many consecutive windows
+#ifndef SK_ANCHOR
+#define SK_ANCHOR       16u
+#endif
+//                 // stage 2: one hash probe per this many consecutive windows
 #define SK_WQ           (64 + 64)           // tile positions of windows waiting for their table probe
 #ifndef SK_BATCH
 #define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
@@ -106,6 +109,19 @@ __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32
         atomicAdd(&k.tally[2u * lo + 1u], 1u);
         const unsigned long long i = atomicAdd(k.nhits, 1ull);
         if (i < k.hits_cap) k.hits[i] = make_uint2(pos, k.inv ? k.inv[row] : row);
+    }
+}
+
+// exact lookup: counter index of `canon`, or 0xFFFFFFFF; *is_text = the slot's orientation bit
+__device__ __forceinline__ uint32_t sk_find(uint64_t canon, const sk_table_view &t, uint32_t *is_text)
+{
+    uint32_t slot = sk_slot0(sk_khash(canon), t.mask);
+    for (;;) {
+        const sk_u4 e = t.slots[slot];
+        const uint64_t key = sk_slot_key(e);
+        if (key == canon) { *is_text = e.w & 1u; return e.z; }
+        if (key == SK_EMPTY64) return 0xFFFFFFFFu;
+        slot = (slot + 1u) & t.mask;
     }
 }
 
@@ -274,34 +290,25 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         const uint32_t first_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
         const uint32_t k = lane - first_lane;                                  // offset inside the stretch
         const bool anchor = act & ((k & (SK_ANCHOR - 1u)) == 0u);
-        uint32_t a_idx = 0xFFFFFFFFu, a_dir = 0u;                              // anchor's counter index / read direction
+        uint32_t hit = 0xFFFFFFFFu, a_dir = 0u;                                // counter index of this lane's hit
         if (anchor) {
-            uint32_t slot = sk_slot0(sk_khash(cn), table.mask);
-            for (;;) {
-                const sk_u4 s4 = table.slots[slot];
-                const uint64_t key = sk_slot_key(s4);
-                if (key == cn) {
-                    a_idx = s4.z;
-                    a_dir = (uint32_t)w_fwd ^ (s4.w & 1u);                     // 0: the read runs along the strain, 1: against it
-                    sk_on_hit<TALLY, ABLATE == 3>(sink, a_idx, pos);
-                    break;
-                }
-                if (key == SK_EMPTY64) break;
-                slot = (slot + 1u) & table.mask;
-            }
+            uint32_t is_text = 0u;
+            hit = sk_find(cn, table, &is_text);
+            a_dir = (uint32_t)w_fwd ^ is_text;                                 // 0: the read runs along the strain, 1: against it
         }
         const uint32_t my_anchor = lane - (k & (SK_ANCHOR - 1u));
-        const uint32_t n_idx = (uint32_t)__shfl((int)a_idx, (int)my_anchor);
+        const uint32_t n_idx = (uint32_t)__shfl((int)hit, (int)my_anchor);
         const uint32_t n_dir = (uint32_t)__shfl((int)a_dir, (int)my_anchor);
         if (act & !anchor) {
-            bool done = false;
             if (n_idx != 0xFFFFFFFFu && table.keys_by_loc) {
                 const uint32_t d = k & (SK_ANCHOR - 1u);
                 const uint32_t idx = n_dir ? n_idx - d : n_idx + d;            // wraps below 0 -> >= nrows
-                if (idx < table.nrows && table.keys_by_loc[idx] == cn) { sk_on_hit<TALLY, ABLATE == 3>(sink, idx, pos); done = true; }
+                if (idx < table.nrows && table.keys_by_loc[idx] == cn) hit = idx;
             }
-            if (!done) sk_probe<TALLY, ABLATE == 3>(cn, table, sink, pos);
+            if (hit == 0xFFFFFFFFu) { uint32_t unused; hit = sk_find(cn, table, &unused); }
         }
+        // one atomic instruction for the whole batch: neighbouring counters coalesce
+        if (hit != 0xFFFFFFFFu) sk_on_hit<TALLY, ABLATE == 3>(sink, hit, pos);
         __builtin_amdgcn_wave_barrier();
     };
     auto probe_batch = [&]() { probe_some(64u); };
