@@ -246,3 +246,24 @@ def test_low_complexity_and_repeats_vs_oracle(ctx):
     assert np.array_equal(ctx.counts(0), ocounts[:, 0])
     assert np.array_equal(ctx.counts(1), ocounts[:, 1])
     assert int(ocounts[:, 1].max()) > 20
+
+
+def test_plain_table_load_without_locality(ctx):
+    """sk_table_load (no locality permutation: counters in caller row order, no strain-order key copy)
+    must count exactly like the keyset path."""
+    rng = random.Random(77)
+    strain = _synth.rand_dna(rng, 30000)
+    ks = sk.Keyset.from_stream(strain + b"\n")
+    data = _synth.fuzz_stream(rng, strain, 1500, junk=b"NnRY-", p_junk=0.005, min_len=20, max_len=250)
+    ctx.load_keyset(ks, 4)
+    ctx.scan_stream(data, 2)
+    want = ctx.counts(2)
+    keys = ks.packed()
+    order = np.arange(len(keys))
+    rng2 = np.random.default_rng(5)
+    rng2.shuffle(order)                                   # any row order the caller likes
+    ctx.load_table(keys[order], 4)
+    ctx.scan_stream(data, 2)
+    got = ctx.counts(2)
+    assert np.array_equal(got, want[order])
+    assert int(want.sum()) > 10000
