@@ -267,3 +267,58 @@ def test_plain_table_load_without_locality(ctx):
     got = ctx.counts(2)
     assert np.array_equal(got, want[order])
     assert int(want.sum()) > 10000
+
+
+def test_program_cfg3_shape_vs_oracle_program(tmp_path):
+    """BASELINE cfg 3 in miniature through the programs: a strain, an -A list of genomes with long
+    contigs (two of them 1 % diverged copies of the strain, one on the other strand), a -B list of
+    gz/plain FASTQ read files, a -C list that contains the -r path itself; decoded by the host thread
+    pool.  The whole TSV must equal the oracle program's."""
+    import gzip
+    rng = random.Random(2024)
+    contigs = [_synth.rand_dna(rng, 120_000), _synth.rand_dna(rng, 80_000)]
+    (tmp_path / "strain.fa").write_bytes(b"".join(b">c%d\n" % i + b"\n".join(c[j:j + 70] for j in range(0, len(c), 70)) + b"\n"
+                                                   for i, c in enumerate(contigs)))
+
+    def mutate(seq, rate):
+        b = bytearray(seq)
+        for i in range(len(b)):
+            if rng.random() < rate:
+                b[i] = rng.choice(b"ACGT")
+        return bytes(b)
+
+    genomes = [mutate(contigs[0] + contigs[1], 0.01), _synth.revcomp(mutate(contigs[0], 0.01)),
+               _synth.rand_dna(rng, 200_000), _synth.rand_dna(rng, 150_000) + b"NNNN" + contigs[1][:5000]]
+    names = []
+    for i, g in enumerate(genomes):
+        n = "g%d.fa" % i
+        (tmp_path / n).write_bytes(b">g%d\n" % i + b"\n".join(g[j:j + 80] for j in range(0, len(g), 80)) + b"\n")
+        names.append(n)
+    (tmp_path / "A.txt").write_text("\n".join(names) + "\n")
+    whole = contigs[0] + contigs[1]
+    bnames = []
+    for f in range(4):
+        recs = []
+        for i in range(4000):
+            if rng.random() < 0.3:
+                a = rng.randrange(0, len(whole) - 150)
+                r = mutate(whole[a:a + 150], 0.005)
+                if rng.random() < 0.5:
+                    r = _synth.revcomp(r)
+            else:
+                r = _synth.rand_dna(rng, 150)
+            recs.append(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+        n = "reads%d.fq%s" % (f, ".gz" if f % 2 else "")
+        data = b"".join(recs)
+        (tmp_path / n).write_bytes(gzip.compress(data, 4) if f % 2 else data)
+        bnames.append(n)
+    (tmp_path / "B.txt").write_text("\n".join(bnames) + "\n")
+    (tmp_path / "C.txt").write_text("g1.fa\nstrain.fa\ng0.fa\n")
+    argv = ["-r", "strain.fa", "-A", "A.txt", "-B", "B.txt", "-C", "C.txt"]
+    want = _oracle.run_oracle_cli(argv, str(tmp_path))
+    got = subprocess.run([sk.cli_path()] + argv, cwd=str(tmp_path), capture_output=True)
+    assert want.returncode == got.returncode == 0
+    assert got.stderr == want.stderr == b"skipping strain.fa (identical match)\n"
+    assert got.stdout == want.stdout
+    cols = np.array([[int(x) for x in ln.split(b"\t")[1:]] for ln in got.stdout.split(b"\n")[1:] if ln])
+    assert cols.shape[1] == 4 and (cols.sum(axis=0) > [190_000, 200_000, 100_000, 200_000]).all(), cols.sum(axis=0)
