@@ -644,6 +644,8 @@ struct sk_ctx {
     long         bloom_bits_log2;
     long         stats;               // debug: count live windows / filter loads / table probes
     long         ablate;              // timing experiments: kernel variants that skip memory stages
+    void        *t_stream, *t_rec, *t_tally, *t_hits;          // grow-only scratch of sk_tally_batch
+    size_t       t_stream_cap, t_rec_cap, t_tally_cap, t_hits_cap;
     void        *comm;                // RCCL communicator from sk_comm_init (NULL: single process)
     int          comm_rank, comm_world;
     char         err[512];
@@ -742,6 +744,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
         if (c->stage_done[i]) hipEventDestroy(c->stage_done[i]);
     }
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    hipFree(c->t_stream); hipFree(c->t_rec); hipFree(c->t_tally); hipFree(c->t_hits);
     hipFree(c->d_flags);
     hipStreamDestroy(c->stream);
     delete c;
@@ -919,6 +922,17 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     return SK_OK;
 }
 
+// grow-only scratch buffer of the context
+static int sk_scratch(sk_ctx *c, void **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return SK_OK;
+    if (*p) { SK_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(*p); *p = NULL; *cap = 0; }
+    size_t want = need + need / 4 + 4096;
+    SK_HIP(c, hipMalloc(p, want));
+    *cap = want;
+    return SK_OK;
+}
+
 // Per-record tallies of one batch (strain_detect): synchronous.
 extern "C" int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec,
                               uint32_t type_col, uint32_t informative_value, uint32_t *out_tally,
@@ -929,33 +943,30 @@ extern "C" int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes,
     if (type_col >= c->ncols) return sk_fail(c, SK_E_ARG, "column %u out of range", type_col);
     if (nbytes == 0 || nrec == 0 || nbytes > 0xFFFFFFF0ull) return sk_fail(c, SK_E_ARG, "bad batch size");
     SK_HIP(c, hipSetDevice(c->device));
-    uint8_t *d_stream = NULL; uint32_t *d_rec = NULL, *d_tally = NULL; uint2 *d_hits = NULL; unsigned long long *d_n = NULL;
-    int rc = SK_OK;
+    int rc;
+    if ((rc = sk_scratch(c, &c->t_stream, &c->t_stream_cap, nbytes + 16)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_rec, &c->t_rec_cap, (size_t)nrec * 4)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)nrec * 8 + 8)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
+    unsigned long long *d_n = (unsigned long long *)((uint8_t *)c->t_tally + (size_t)nrec * 8);   // hit counter behind the tallies
     unsigned long long nh = 0;
-    do {
-        if (hipMalloc((void **)&d_stream, nbytes + 16) != hipSuccess || hipMalloc((void **)&d_rec, (size_t)nrec * 4) != hipSuccess ||
-            hipMalloc((void **)&d_tally, (size_t)nrec * 8) != hipSuccess || hipMalloc((void **)&d_n, 8) != hipSuccess ||
-            hipMalloc((void **)&d_hits, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2)) != hipSuccess) { rc = sk_fail(c, SK_E_NOMEM, "hipMalloc (tally batch)"); break; }
-        hipMemcpyAsync(d_stream, stream, nbytes, hipMemcpyHostToDevice, c->stream);
-        hipMemcpyAsync(d_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, c->stream);
-        hipMemsetAsync(d_tally, 0, (size_t)nrec * 8, c->stream);
-        hipMemsetAsync(d_n, 0, 8, c->stream);
-        sk_sink sink;
-        memset(&sink, 0, sizeof sink);
-        sink.rec_start = d_rec; sink.nrec = nrec; sink.tally = d_tally;
-        sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
-        sink.hits = d_hits; sink.nhits = d_n; sink.hits_cap = hits_cap; sink.inv = c->d_inv;
-        rc = sk_launch_scan(c, d_stream, nbytes, 0, 0, &sink);
-        if (rc) break;
-        hipMemcpyAsync(out_tally, d_tally, (size_t)nrec * 8, hipMemcpyDeviceToHost, c->stream);
-        hipMemcpyAsync(&nh, d_n, 8, hipMemcpyDeviceToHost, c->stream);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = sk_fail(c, SK_E_HIP, "tally batch failed: %s", hipGetErrorString(hipGetLastError())); break; }
-        const unsigned long long take = nh < hits_cap ? nh : hits_cap;
-        if (take && hipMemcpy(out_hits, d_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess) { rc = sk_fail(c, SK_E_HIP, "hits download"); break; }
-        *out_nhits = nh;
-    } while (0);
-    hipFree(d_stream); hipFree(d_rec); hipFree(d_tally); hipFree(d_hits); hipFree(d_n);
-    return rc;
+    SK_HIP(c, hipMemcpyAsync(c->t_stream, stream, nbytes, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(c, hipMemcpyAsync(c->t_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)nrec * 8 + 8, c->stream));
+    sk_sink sink;
+    memset(&sink, 0, sizeof sink);
+    sink.rec_start = (const uint32_t *)c->t_rec; sink.nrec = nrec; sink.tally = (uint32_t *)c->t_tally;
+    sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
+    sink.hits = (uint2 *)c->t_hits; sink.nhits = d_n; sink.hits_cap = hits_cap; sink.inv = c->d_inv;
+    rc = sk_launch_scan(c, (const uint8_t *)c->t_stream, nbytes, 0, 0, &sink);
+    if (rc) return rc;
+    SK_HIP(c, hipMemcpyAsync(out_tally, c->t_tally, (size_t)nrec * 8, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(c, hipMemcpyAsync(&nh, d_n, 8, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    const unsigned long long take = nh < hits_cap ? nh : hits_cap;
+    if (take) SK_HIP(c, hipMemcpy(out_hits, c->t_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost));
+    *out_nhits = nh;
+    return SK_OK;
 }
 
 extern "C" int sk_scan_device(sk_ctx *c, const void *dev_stream, uint64_t nbytes, uint32_t col)
