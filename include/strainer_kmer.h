@@ -97,6 +97,15 @@ int sk_table_load_wide(sk_ctx *ctx, const char *keys31, const uint32_t *rows, ui
  * GEN_calculate_kmer_count(): src/genome_compare.c:213-229 + BIO_searchHash(). */
 int sk_scan_stream(sk_ctx *ctx, const uint8_t *stream, uint64_t nbytes, uint32_t col);
 
+/* Zero-copy variant for callers that fill pinned host buffers themselves (the host layer's decode
+ * threads do): `pinned` comes from sk_pinned_alloc, holds at most 64 MiB - 64 bytes of record stream
+ * made of WHOLE records or pieces cut with the k-1 overlap, and is DMA-read in place; it may be
+ * rewritten once sk_ticket_wait(ctx, *ticket) has returned. */
+int sk_pinned_alloc(sk_ctx *ctx, void **p, uint64_t nbytes);
+int sk_pinned_free(sk_ctx *ctx, void *p);
+int sk_scan_pinned(sk_ctx *ctx, const uint8_t *pinned, uint64_t nbytes, uint32_t col, uint64_t *ticket);
+int sk_ticket_wait(sk_ctx *ctx, uint64_t ticket);
+
 /* Same, for a batch already resident in HBM (device pointer). */
 int sk_scan_device(sk_ctx *ctx, const void *dev_stream, uint64_t nbytes, uint32_t col);
 

@@ -633,6 +633,8 @@ struct sk_ctx {
     uint8_t     *d_stage[SK_NSTAGE];
     hipEvent_t   stage_done[SK_NSTAGE];
     int          stage_next;
+    hipEvent_t   copied[64];           // ring of "host buffer of ticket t has been read" events
+    uint64_t     tickets;              // tickets issued so far
     // flags: [0] wide windows seen in the current batch, [1] table build errors
     uint32_t    *d_flags;
     // timing
@@ -744,6 +746,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
         if (c->stage_done[i]) hipEventDestroy(c->stage_done[i]);
     }
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    for (int i = 0; i < 64; i++) if (c->copied[i]) hipEventDestroy(c->copied[i]);
     hipFree(c->t_stream); hipFree(c->t_rec); hipFree(c->t_tally); hipFree(c->t_hits);
     hipFree(c->d_flags);
     hipStreamDestroy(c->stream);
@@ -1014,6 +1017,60 @@ extern "C" int sk_scan_stream(sk_ctx *c, const uint8_t *stream, uint64_t nbytes,
         SK_HIP(c, hipEventRecord(c->stage_done[b], c->stream));
         done += take;
     }
+    return SK_OK;
+}
+
+// ---- zero-copy variant for callers that fill PINNED host buffers themselves ---------------------
+extern "C" int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t nbytes)
+{
+    if (!c || !p) return SK_E_ARG;
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipHostMalloc(p, nbytes ? nbytes : 16, hipHostMallocDefault));
+    return SK_OK;
+}
+
+extern "C" int sk_pinned_free(sk_ctx *c, void *p)
+{
+    if (!c) return SK_E_ARG;
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    SK_HIP(c, hipHostFree(p));
+    return SK_OK;
+}
+
+// Like sk_scan_stream, but `pinned` (from sk_pinned_alloc, at most 64 MiB - 64 bytes) is DMA-read in
+// place: the caller must leave it alone until sk_ticket_wait(*ticket) returns.
+extern "C" int sk_scan_pinned(sk_ctx *c, const uint8_t *pinned, uint64_t nbytes, uint32_t col, uint64_t *ticket)
+{
+    if (!c || (!pinned && nbytes) || !ticket) return SK_E_ARG;
+    if (!c->d_keys) return sk_fail(c, SK_E_STATE, "no table loaded");
+    if (col >= c->ncols) return sk_fail(c, SK_E_ARG, "column %u out of range", col);
+    if (nbytes > SK_STAGE_BYTES - 64) return sk_fail(c, SK_E_ARG, "pinned batch larger than the staging buffer");
+    SK_HIP(c, hipSetDevice(c->device));
+    int rc = sk_stage_init(c);
+    if (rc) return rc;
+    const uint64_t t = c->tickets++;
+    hipEvent_t &ev = c->copied[t & 63u];
+    if (!ev) SK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else SK_HIP(c, hipEventSynchronize(ev));                     // ring slot of ticket t-64
+    const int b = c->stage_next;
+    c->stage_next = (b + 1) % SK_NSTAGE;
+    SK_HIP(c, hipEventSynchronize(c->stage_done[b]));
+    if (nbytes) SK_HIP(c, hipMemcpyAsync(c->d_stage[b], pinned, nbytes, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(c, hipEventRecord(ev, c->stream));
+    rc = sk_launch_scan(c, c->d_stage[b], nbytes, 0, col);
+    if (rc) return rc;
+    SK_HIP(c, hipEventRecord(c->stage_done[b], c->stream));
+    *ticket = t;
+    return SK_OK;
+}
+
+extern "C" int sk_ticket_wait(sk_ctx *c, uint64_t ticket)
+{
+    if (!c || ticket >= c->tickets) return SK_E_ARG;
+    if (c->tickets - ticket > 64) return SK_OK;                  // its ring slot was recycled only after it completed
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipEventSynchronize(c->copied[ticket & 63u]));
     return SK_OK;
 }
 

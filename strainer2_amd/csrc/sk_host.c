@@ -81,13 +81,17 @@ typedef struct {
     uint64_t    cap, len;
     skh_sink_fn sink;
     void       *user;
+    uint8_t  *(*next_buf)(void *user);   /* optional: buffer to fill after a flush (double buffering) */
     uint64_t    bases;
     int         rc;
 } stream_writer;
 
 static int writer_flush(stream_writer *w)
 {
-    if (w->len && !w->rc) w->rc = w->sink(w->user, w->buf, w->len);
+    if (w->len && !w->rc) {
+        w->rc = w->sink(w->user, w->buf, w->len);
+        if (!w->rc && w->next_buf) w->buf = w->next_buf(w->user);
+    }
     w->len = 0;
     return w->rc;
 }
@@ -467,19 +471,81 @@ typedef struct {
     uint64_t        bases;
 } scan_pool;
 
-static int pool_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
+/* one decode worker: two pinned chunk buffers filled in turn; a buffer is rewritten only after the
+ * DMA that read it has finished (ticket) */
+typedef struct {
+    scan_pool *pool;
+    uint8_t   *pinned[2];
+    uint64_t   ticket[2];
+    int        used[2], cur;
+} scan_worker;
+
+#define POOL_CHUNK (32u << 20)
+
+static int worker_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
 {
-    scan_pool *p = (scan_pool *)user;
+    scan_worker *w = (scan_worker *)user;
     int rc;
+    pthread_mutex_lock(&w->pool->submit_mu);
+    rc = sk_scan_pinned(w->pool->ctx, chunk, nbytes, w->pool->col, &w->ticket[w->cur]);
+    pthread_mutex_unlock(&w->pool->submit_mu);
+    w->used[w->cur] = 1;
+    return rc;
+}
+
+static uint8_t *worker_next_buf(void *user)
+{
+    scan_worker *w = (scan_worker *)user;
+    w->cur ^= 1;
+    if (w->used[w->cur]) sk_ticket_wait(w->pool->ctx, w->ticket[w->cur]);
+    return w->pinned[w->cur];
+}
+
+static int worker_init(scan_worker *w, scan_pool *p)
+{
+    int rc;
+    memset(w, 0, sizeof *w);
+    w->pool = p;
     pthread_mutex_lock(&p->submit_mu);
-    rc = sk_scan_stream(p->ctx, chunk, nbytes, p->col);
+    rc = sk_pinned_alloc(p->ctx, (void **)&w->pinned[0], POOL_CHUNK);
+    if (rc == SK_OK) rc = sk_pinned_alloc(p->ctx, (void **)&w->pinned[1], POOL_CHUNK);
     pthread_mutex_unlock(&p->submit_mu);
     return rc;
+}
+
+static void worker_done(scan_worker *w)
+{
+    pthread_mutex_lock(&w->pool->submit_mu);
+    if (w->pinned[0]) sk_pinned_free(w->pool->ctx, w->pinned[0]);      /* (synchronises the stream first) */
+    if (w->pinned[1]) sk_pinned_free(w->pool->ctx, w->pinned[1]);
+    pthread_mutex_unlock(&w->pool->submit_mu);
+}
+
+/* decode one file into the worker's pinned buffers; returns records or a negative SK_E_* */
+static int64_t worker_file(scan_worker *w, const char *path, uint64_t *bases)
+{
+    stream_writer sw;
+    int64_t nrec = 0;
+    int rc;
+    memset(&sw, 0, sizeof sw);
+    sw.buf = w->pinned[w->cur];
+    sw.cap = POOL_CHUNK;
+    sw.sink = worker_sink;
+    sw.user = w;
+    sw.next_buf = worker_next_buf;
+    rc = parse_file(path, writer_record, &sw, &nrec, NULL);
+    if (rc == SK_OK) writer_flush(&sw);
+    *bases += sw.bases;
+    if (rc != SK_OK) return rc;
+    if (sw.rc) return sw.rc;
+    return nrec;
 }
 
 static void *pool_worker(void *arg)
 {
     scan_pool *p = (scan_pool *)arg;
+    scan_worker w;
+    int wrc = worker_init(&w, p);
     for (;;) {
         uint32_t i;
         uint64_t bases = 0;
@@ -489,12 +555,13 @@ static void *pool_worker(void *arg)
         if (i >= p->npath || p->rc != SK_OK) { pthread_mutex_unlock(&p->queue_mu); break; }
         p->next++;
         pthread_mutex_unlock(&p->queue_mu);
-        rc = skh_decode_file(p->path[i], 32u << 20, pool_sink, p, &bases);
+        rc = wrc != SK_OK ? wrc : worker_file(&w, p->path[i], &bases);
         pthread_mutex_lock(&p->queue_mu);
         p->bases += bases;
         if (rc < 0 && (p->rc == SK_OK || i < p->rc_index)) { p->rc = (int)rc; p->rc_index = i; }
         pthread_mutex_unlock(&p->queue_mu);
     }
+    worker_done(&w);
     return NULL;
 }
 
@@ -508,6 +575,8 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     int nthreads = 1;
     const char *env = getenv("SK_THREADS");
     scan_pool pool;
+    scan_worker seq;
+    int seq_ready = 0, seq_rc = SK_OK;
     if (!fp) {
         if (err) fprintf(err, "could not read file %s in GEN_all_kmer_counts()\n", list_path);
         return SK_E_OPEN;
@@ -538,7 +607,9 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
         if (idx++ % world != rank) continue;
         if (nthreads == 1) {                                  /* strict sequence, as the reference */
             uint64_t b = 0;
-            int64_t rc = skh_decode_file(line, 32u << 20, pool_sink, &pool, &b);
+            int64_t rc;
+            if (!seq_ready) { seq_rc = worker_init(&seq, &pool); seq_ready = 1; }
+            rc = seq_rc != SK_OK ? seq_rc : worker_file(&seq, line, &b);
             pool.bases += b;
             if (rc < 0) { pool.rc = (int)rc; pool.path = (char **)realloc(pool.path, sizeof(char *)); pool.path[0] = strdup(line); pool.npath = 1; pool.rc_index = 0; break; }
             continue;
@@ -562,6 +633,7 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
         if (err) fprintf(err, "kmer_scrub_count: device error while scanning %s: %s (%s)\n", pool.path[pool.rc_index],
                          sk_strerror(pool.rc), sk_last_error(ctx));
     }
+    if (seq_ready) worker_done(&seq);
     if (bases) *bases += pool.bases;
     for (i = 0; i < pool.npath; i++) free(pool.path[i]);
     free(pool.path);

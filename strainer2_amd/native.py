@@ -40,7 +40,8 @@ SK_E_OPEN = -5
 # every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load", "sk_table_load_ex",
-    "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
+    "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
+    "sk_ticket_wait", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
     "sk_counts_allreduce", "sk_comm_init", "sk_comm_destroy", "sk_comm_sum_u32", "sk_scan_timing", "sk_set_option", "sk_scan_stats", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
@@ -72,6 +73,10 @@ lib.sk_table_load_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
 lib.sk_table_load_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
 lib.sk_scan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.sk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+lib.sk_pinned_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64]
+lib.sk_pinned_free.argtypes = [C.c_void_p, C.c_void_p]
+lib.sk_scan_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.sk_ticket_wait.argtypes = [C.c_void_p, C.c_uint64]
 lib.sk_tally_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
 lib.sk_sync.argtypes = [C.c_void_p]
@@ -226,6 +231,26 @@ class KmerContext:
                                     tally.ctypes.data, hits.ctypes.data, cap, C.byref(nh)))
         hits = hits[: nh.value]
         return tally, hits[np.argsort(hits[:, 0], kind="stable")]
+
+    def pinned_alloc(self, nbytes):
+        """A pinned host buffer as a writable numpy uint8 array (free with pinned_free(arr))."""
+        p = C.c_void_p()
+        self._ck(lib.sk_pinned_alloc(self._h, C.byref(p), nbytes))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def pinned_free(self, arr):
+        self._ck(lib.sk_pinned_free(self._h, self._pinned.pop(arr.ctypes.data)))
+
+    def scan_pinned(self, arr, nbytes, col, offset=0):
+        t = C.c_uint64(0)
+        self._ck(lib.sk_scan_pinned(self._h, arr.ctypes.data + offset, nbytes, col, C.byref(t)))
+        return t.value
+
+    def ticket_wait(self, ticket):
+        self._ck(lib.sk_ticket_wait(self._h, ticket))
 
     def scan_device(self, dev_ptr, nbytes, col):
         self._ck(lib.sk_scan_device(self._h, dev_ptr, nbytes, col))

@@ -24,6 +24,10 @@ int sk_comm_init(sk_ctx *c, int r, int w, const char *f, int t) { (void)c; (void
 int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s) { (void)c; (void)v; (void)s; return unreachable("sk_comm_sum_u32"); }
 int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return unreachable("sk_counts_zero"); }
 int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return unreachable("sk_counts_allreduce"); }
+int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t n) { (void)c; (void)p; (void)n; return unreachable("sk_pinned_alloc"); }
+int sk_pinned_free(sk_ctx *c, void *p) { (void)c; (void)p; return unreachable("sk_pinned_free"); }
+int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64_t *t) { (void)c; (void)s; (void)n; (void)col; (void)t; return unreachable("sk_scan_pinned"); }
+int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return unreachable("sk_ticket_wait"); }
 const char *sk_strerror(int c) { (void)c; return "stub"; }
 const char *sk_last_error(const sk_ctx *c) { (void)c; return "stub"; }
 
