@@ -310,9 +310,9 @@ class KmerContext:
         self._ck(lib.sk_dev_free(self._h, ptr))
         self._bufs.remove(ptr)
 
-    def dev_upload(self, ptr, arr):
+    def dev_upload(self, ptr, arr, offset=0):
         arr = np.ascontiguousarray(arr)
-        self._ck(lib.sk_dev_upload(self._h, ptr, arr.ctypes.data, arr.nbytes))
+        self._ck(lib.sk_dev_upload(self._h, ptr + offset, arr.ctypes.data, arr.nbytes))
 
     def dev_download(self, ptr, nbytes):
         out = np.empty(nbytes, dtype=np.uint8)

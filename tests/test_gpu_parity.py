@@ -322,3 +322,24 @@ def test_program_cfg3_shape_vs_oracle_program(tmp_path):
     assert got.stdout == want.stdout
     cols = np.array([[int(x) for x in ln.split(b"\t")[1:]] for ln in got.stdout.split(b"\n")[1:] if ln])
     assert cols.shape[1] == 4 and (cols.sum(axis=0) > [190_000, 200_000, 100_000, 200_000]).all(), cols.sum(axis=0)
+
+
+def test_single_launch_beyond_4_gib(ctx):
+    """One device-resident batch of more than 2^32 bytes (64-bit positions inside the kernel): the
+    same 1.51 GB stream three times in a row must count exactly three times one copy."""
+    contigs = synth.make_strain()
+    ks = sk.Keyset.from_stream(synth.strain_stream(contigs))
+    ctx.load_keyset(ks, 4)
+    reads, _ = synth.make_reads(contigs, 10_000_000)
+    n = int(reads.size)
+    assert 3 * n > 2 ** 32
+    buf = ctx.dev_alloc(3 * n + 16)
+    for i in range(3):
+        ctx.dev_upload(buf, reads, offset=i * n)
+    ctx.scan_device(buf, n, 1)
+    ctx.scan_device(buf, 3 * n, 2)
+    ctx.sync()
+    one, three = ctx.counts(1), ctx.counts(2)
+    ctx.dev_free(buf)
+    assert int(one.sum()) > 20_000_000
+    assert np.array_equal(three, 3 * one)
