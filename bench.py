@@ -6,8 +6,8 @@ Workload at every N (weak scaling): BASELINE configs[1] per GPU -- one 5 Mbp syn
 (-r) resident as the key table, 10 M x 150 bp synthetic reads (-B; 1.5 Gbase, SURVEY 8(d)
 recipe, seed 0x5EED31 + rank) resident in HBM as a record stream.  A "step" = one pass of the
 scan over that batch (sk_scan_device -> sk_scan_main [+ sk_scan_wide early-exit]).  After the
-K timed steps the per-k-mer count vectors are summed across ranks with one RCCL all-reduce
-(inside the timed region when N > 1).  value = bases all ranks scanned / max-over-ranks time.
+K timed steps the per-k-mer count vector of the scanned (-B) column is summed across ranks with one
+RCCL all-reduce (inside the timed region when N > 1).  value = bases all ranks scanned / max-over-ranks time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu]
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -144,7 +144,7 @@ def main():
     for _ in range(args.warmup):
         ctx.scan_device(dev, nbytes, 2)
     if world > 1:
-        allreduce_counts(ctx)               # warm the communicator up
+        allreduce_counts(ctx, 2)            # warm the communicator up
     ctx.zero_counts(2)
     barrier()
     ctx.scan_timing(reset=True)
@@ -152,7 +152,7 @@ def main():
     for _ in range(args.steps):
         ctx.scan_device(dev, nbytes, 2)
     if world > 1:
-        allreduce_counts(ctx)
+        allreduce_counts(ctx, 2)            # the -B column's per-k-mer count vector (20 MB at cfg 2)
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = ctx.scan_timing(reset=True)

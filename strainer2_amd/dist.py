@@ -17,14 +17,19 @@ def shard_of(index: int, rank: int, world: int) -> bool:
     return index % world == rank
 
 
-def allreduce_counts(ctx):
-    """In-place sum of ctx's whole counter block over the default process group.
-    u32 wrap-around == i32 two's-complement sum, so the block is reduced as int32."""
+def allreduce_counts(ctx, col=None):
+    """In-place sum over the default process group of ctx's counter block -- all columns, or only
+    column `col` (the per-k-mer count vector of the list that was scanned).  The block is in the
+    device's locality order, identical on every rank that loaded the same key set.
+    u32 wrap-around == i32 two's-complement sum, so it is reduced as int32."""
     import torch
     import torch.distributed as dist
     ctx.sync()
-    n = ctx.nrows * ctx.ncols
-    t = torch.as_tensor(_DevBlock(ctx.counts_device_ptr(), n), device="cuda")
+    if col is None:
+        ptr, n = ctx.counts_device_ptr(), ctx.nrows * ctx.ncols
+    else:
+        ptr, n = ctx.counts_device_ptr() + 4 * col * ctx.nrows, ctx.nrows
+    t = torch.as_tensor(_DevBlock(ptr, n), device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
 
