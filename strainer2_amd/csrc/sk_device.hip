@@ -153,9 +153,8 @@ __device__ __forceinline__ bool sk_filter_test(const uint2 blk, uint32_t mz)
 __device__ __forceinline__ uint32_t sk_nz_msb(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; }
 
 // w = 4 stream bytes (first base in the low byte).  codes8: their 2-bit codes, first base in bits
-// 7..6.  inv4: bit i set iff byte i is not A/C/G/T (any case).  bad: bit 7 of byte i set iff it is
-// neither A/C/G/T nor N/n nor '\n' (a byte only the exact byte-string path can judge).
-__device__ __forceinline__ void sk_decode4(uint32_t w, uint32_t &codes8, uint32_t &inv4, uint32_t &bad)
+// 7..6.  inv4: bit i set iff byte i is not A/C/G/T (any case).
+__device__ __forceinline__ void sk_decode4(uint32_t w, uint32_t &codes8, uint32_t &inv4)
 {
     const uint32_t u  = w & 0xDFDFDFDFu;                                   // upper-cased letters
     const uint32_t x  = (w >> 1) & 0x03030303u;                            // A0 C1 T2 G3
@@ -163,9 +162,23 @@ __device__ __forceinline__ void sk_decode4(uint32_t w, uint32_t &codes8, uint32_
     codes8 = (cd * 0x40100401u) >> 24;                                     // gather 4 x 2 bits
     const uint32_t lut = 0x47544341u;                                      // 'A','C','T','G' by x
     const uint32_t d  = __builtin_amdgcn_perm(lut, lut, x) ^ u;            // 0 <=> the byte is that letter
-    const uint32_t m1 = sk_nz_msb(d);
-    inv4 = ((((m1 >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
-    bad |= m1 & sk_nz_msb(u ^ 0x4E4E4E4Eu) & sk_nz_msb(w ^ 0x0A0A0A0Au) & 0x80808080u;
+    inv4 = ((((sk_nz_msb(d) >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+
+// Among the (few) non-ACGT bytes of a 16-byte chunk, is there one that is neither N/n nor '\n'?
+// Such a byte can only be judged by the exact byte-string kernel.  inv16 = the chunk's mask.
+__device__ __forceinline__ uint32_t sk_chunk_has_odd_byte(const sk_u4 v, uint32_t inv16)
+{
+    uint32_t odd = 0;
+    while (inv16) {
+        const uint32_t i = (uint32_t)__builtin_ctz(inv16);
+        inv16 &= inv16 - 1u;
+        const uint32_t q = i >> 2;
+        const uint32_t w = q == 0u ? v.x : q == 1u ? v.y : q == 2u ? v.z : v.w;
+        const uint32_t b = (w >> (8u * (i & 3u))) & 0xFFu;
+        odd |= (uint32_t)(((b & 0xDFu) != 'N') & (b != '\n'));
+    }
+    return odd;
 }
 
 __device__ __forceinline__ uint32_t sk_revcomp32(uint32_t x)              // 16 packed bases
@@ -242,13 +255,15 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 v = (sk_u4){w[0], w[1], w[2], w[3]};
             }
             uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
-            sk_decode4(v.x, c0, i0, bad);
-            sk_decode4(v.y, c1, i1, bad);
-            sk_decode4(v.z, c2, i2, bad);
-            sk_decode4(v.w, c3, i3, bad);
+            sk_decode4(v.x, c0, i0);
+            sk_decode4(v.y, c1, i1);
+            sk_decode4(v.z, c2, i2);
+            sk_decode4(v.w, c3, i3);
+            const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+            bad |= sk_chunk_has_odd_byte(v, inv16);
             const uint32_t r = c >> 3, sl = c & 7u;
             rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
-            ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+            ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
         }
     }
     __syncthreads();
