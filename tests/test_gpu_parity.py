@@ -343,3 +343,32 @@ def test_single_launch_beyond_4_gib(ctx):
     ctx.dev_free(buf)
     assert int(one.sum()) > 20_000_000
     assert np.array_equal(three, 3 * one)
+
+
+def test_scan_pinned_equals_scan_stream(ctx):
+    """Zero-copy entry point: chunks of whole records in pinned memory, tickets gate buffer reuse."""
+    rng = random.Random(4242)
+    strain = _synth.rand_dna(rng, 40000)
+    ks = sk.Keyset.from_stream(strain + b"\n")
+    ctx.load_keyset(ks, 4)
+    data = _synth.fuzz_stream(rng, strain, 3000, junk=b"Nn", p_junk=0.002, min_len=31, max_len=200)
+    ctx.scan_stream(data, 1)
+    recs = data.split(b"\n")[:-1]
+    buf = ctx.pinned_alloc(1 << 16)
+    tickets = []
+    i = 0
+    while i < len(recs):                                  # refill the same small buffer again and again
+        n, j = 0, i
+        while j < len(recs) and n + len(recs[j]) + 1 <= buf.size:
+            n += len(recs[j]) + 1
+            j += 1
+        if tickets:
+            ctx.ticket_wait(tickets[-1])
+        chunk = b"\n".join(recs[i:j]) + b"\n"
+        buf[:n] = np.frombuffer(chunk, dtype=np.uint8)
+        tickets.append(ctx.scan_pinned(buf, n, 2))
+        i = j
+    ctx.sync()
+    assert len(tickets) > 5
+    assert np.array_equal(ctx.counts(1), ctx.counts(2)) and int(ctx.counts(1).sum()) > 10000
+    ctx.pinned_free(buf)
