@@ -382,17 +382,20 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     };
 
     // one event = one maximal run of windows that share a minimizer hash (0xFFFFFFFF: a dead
-    // stretch, judged "no" without a lookup).  `rel` = chunk-relative offset of its first window
-    // (negative when it began in an earlier chunk), `o` = offset of the first window after it.
-    auto push_event = [&](bool cond, uint32_t mz, uint32_t ebase, int32_t rel, int o) {
+    // stretch, judged "no" without a lookup): {mz, start | (len-1) << 15}.  With rel = chunk-relative
+    // offset of the run's first window (negative when it began in an earlier chunk) and o = offset of
+    // the first window after it, start = ebase + rel and len-1 = o-1-rel, so the info word is
+    // (ebase + ((o-1) << 15)) + rel * (1 - 2^15): the run state keeps rel pre-multiplied (`relx`).
+    auto push_event = [&](bool cond, uint32_t mz, uint32_t ebase, uint32_t relx, int o) {
         const unsigned long long m = __ballot(cond);
         if (m) {
             if (cond)
                 evq[qe + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                    make_uint2(mz, (ebase + (uint32_t)rel) | ((uint32_t)(o - 1 - rel) << 15));
+                    make_uint2(mz, ebase + (uint32_t)((o - 1) * 32768) + relx);
             qe += (uint32_t)__popcll(m);
         }
     };
+#define SK_RELX(rel) ((uint32_t)((rel) * (1 - 32768)))
 
     const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;           // this thread's record
     const uint32_t *pv = rec + tid * SK_REC_DW;                   // the record before it
@@ -414,7 +417,8 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 
     const uint64_t pos0 = tile0 + (uint64_t)tid * SK_SPAN;       // stream position of span window 0
     uint32_t run_mz = 0xFFFFFFFFu;                                // minimizer hash of the current run
-    int32_t  run_rel = 0;                                         // its first window, relative to the chunk
+    uint32_t run_relx = SK_RELX(0);                               // its first window, relative to the chunk (pre-multiplied)
+    const bool all_emit = tile0 >= emit_begin;                    // (wave-uniform) no position of this tile is masked
 
 #pragma unroll 1
     for (uint32_t j = 0; j < SK_SPAN_CH; j++) {
@@ -432,7 +436,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         rr &= rr << 15;                                            // runs of >= 31
         uint32_t live16 = (uint32_t)(rr >> 32) & 0xFFFFu;
         const uint64_t pbase = pos0 + (uint64_t)j * 16u;
-        if (pbase < emit_begin) {
+        if (!all_emit && pbase < emit_begin) {
             const uint64_t dlt = emit_begin - pbase;
             live16 = dlt >= 16u ? 0u : live16 & (0xFFFFu << (uint32_t)dlt);
         }
@@ -450,13 +454,13 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             uint32_t mz = S[o + 1] < P ? S[o + 1] : P;
             mz |= (uint32_t)__builtin_amdgcn_sbfe((int)dead16, o, 1);          // dead window: all ones
             const bool chg = mz != run_mz;
-            push_event(chg, run_mz, ebase, run_rel, o);
-            run_rel = chg ? o : run_rel;
+            push_event(chg, run_mz, ebase, run_relx, o);
+            run_relx = chg ? SK_RELX(o) : run_relx;
             run_mz = mz;
             if ((o & (SK_PUMP_EVERY - 1)) == SK_PUMP_EVERY - 1 && o != 15 && qe >= 64u) pump();
         }
         if (qe >= 64u) pump();
-        run_rel -= 16;
+        run_relx -= SK_RELX(16);
         cw_prev = cwj;
 
         S[15] = H[15];
@@ -465,7 +469,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     }
 
     // ---- tail: the last run, then everything still queued or pending ---------------------------
-    push_event(true, run_mz, tid * SK_SPAN + SK_SPAN, run_rel, 0);
+    push_event(true, run_mz, tid * SK_SPAN + SK_SPAN, run_relx, 0);
     while (pn != 0u || qe != 0u) { complete(); issue(); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
