@@ -368,7 +368,7 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             if (lane + 64u * (uint32_t)b < n) {
                 pev[b] = evq[qe + lane + 64u * (uint32_t)b];
                 if (FILTER && ABLATE != 1 && pev[b].x != 0xFFFFFFFFu)
-                    pblk[b] = table.bloom[sk_filter_block(pev[b].x, table.bloom_shift)];
+                    pblk[b] = table.bloom[sk_filter_block(pev[b].x, table.bloom_shift) & (ABLATE == 4 ? 63u : 0xFFFFFFFFu)];
                 if (STATS) n_load += 1u;
             }
         }
@@ -923,6 +923,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     else if (c->ablate == 1 && filter)   SK_LAUNCH_MAIN(true, false, 1, false);
     else if (c->ablate == 2 && filter)   SK_LAUNCH_MAIN(true, false, 2, false);
     else if (c->ablate == 3 && filter)   SK_LAUNCH_MAIN(true, false, 3, false);
+    else if (c->ablate == 4 && filter)   SK_LAUNCH_MAIN(true, false, 4, false);
     else if (c->stats && filter)         SK_LAUNCH_MAIN(true, true, 0, false);
     else if (filter)                     SK_LAUNCH_MAIN(true, false, 0, false);
     else                                 SK_LAUNCH_MAIN(false, false, 0, false);
