@@ -80,9 +80,10 @@ int sk_table_load(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t nc
  * order), in the low 31 bits; bit 31 (SK_LOCALITY_FWD) says whether the key equals the strain text at
  * that occurrence or its reverse complement.  The device keeps its counters (and a copy of the keys)
  * in that order: the hits of one read land on adjacent counters (their atomics coalesce), and the
- * neighbours of a window that hit are first looked for next to it instead of through the hash.  Invisible through sk_counts_fetch/set and sk_tally_batch
- * (they speak caller rows); sk_counts_device_ptr/sk_counts_allreduce see the block in locality
- * order, which is the same on every rank that loaded the same key set. */
+ * neighbours of a window that hit are first looked for next to it instead of through the hash.
+ * Invisible through sk_counts_fetch/set and sk_tally_batch (they speak caller rows);
+ * sk_counts_device_ptr/sk_counts_allreduce see the block in locality order, which is the same on
+ * every rank that loaded the same key set. */
 int sk_table_load_ex(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t ncols, const uint32_t *locality);
 
 /* Wide keys: rows whose 31-byte upper-cased oriented key contains bytes other than ACGT
@@ -123,7 +124,8 @@ int sk_tally_batch(sk_ctx *ctx, const uint8_t *stream, uint64_t nbytes, const ui
 /* Wait for all queued work of the context. */
 int sk_sync(sk_ctx *ctx);
 
-/* Counter access.  Layout on the device: counts[col * nrows + row], u32, wrapping.
+/* Counter access, in the caller's row order; u32, wrapping.  (On the device a column is
+ * counts[col * nrows + i] with i = row, or i = locality[row] after sk_table_load_ex.)
  * fetch/set replace reads/writes of the reference's per-key count vectors
  * (src/kmer_scrub_count.c:144-151; src/genome_compare.c:1011-1016). */
 int sk_counts_fetch(sk_ctx *ctx, uint32_t col, uint32_t *out /* nrows */);
@@ -151,7 +153,8 @@ int sk_scan_timing(sk_ctx *ctx, double *total_ms, uint64_t *launches, int reset)
 
 /* Tunables (before sk_table_load).  name: "bloom_bits_log2" (size of the prefilter in bits,
  * log2; -1 = automatic, 0 = no prefilter), "table_load_pct" (max load factor in percent),
- * "stats" (1 = count windows / prefilter loads / table probes, see sk_scan_stats).
+ * "stats" (1 = count windows / prefilter loads / table probes, see sk_scan_stats), "ablate"
+ * (timing experiments only: kernel variants that skip memory stages and give WRONG counts).
  * Unknown name -> SK_E_ARG. */
 int sk_set_option(sk_ctx *ctx, const char *name, long value);
 /* Debug counters of the scan kernel since the last table load (needs option "stats"=1):
