@@ -84,6 +84,7 @@ __device__ __forceinline__ uint64_t sk_slot_key(const sk_u4 e) { return ((uint64
 struct sk_sink {
     uint32_t       *counts;        // COUNT: counts + col * nrows
     const uint32_t *rec_start;     // TALLY: batch offset of every record's first byte, ascending
+    const uint32_t *tile_first;    // TALLY: per 32768-byte tile, index of the first record starting in or after it
     uint32_t        nrec;
     uint32_t       *tally;         // TALLY: [2 * nrec]
     const uint32_t *type;          // TALLY: type column
@@ -99,7 +100,11 @@ __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32
 {
     if (NOATOMIC) { if (row == 0x7FFFFFFFu) k.counts[0] = pos; return; }      // timing experiment only
     if (!TALLY) { atomicAdd(&k.counts[row], 1u); return; }
-    uint32_t lo = 0, hi = k.nrec;                      // last record whose start <= pos
+    // last record whose start <= pos: it starts in this tile, or is the one that runs into it
+    const uint32_t t = pos >> 15;
+    uint32_t lo = k.tile_first[t], hi = k.tile_first[t + 1u];
+    lo = lo ? lo - 1u : 0u;
+    if (hi <= lo) hi = lo + 1u;
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
         if (k.rec_start[mid] <= pos) lo = mid; else hi = mid;
@@ -109,6 +114,50 @@ __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32
         atomicAdd(&k.tally[2u * lo + 1u], 1u);
         const unsigned long long i = atomicAdd(k.nhits, 1ull);
         if (i < k.hits_cap) k.hits[i] = make_uint2(pos, k.inv ? k.inv[row] : row);
+    }
+}
+
+// TALLY for a whole wave at once (every lane calls it; `hit` = counter index or 0xFFFFFFFF): lanes of
+// one read sit next to each other, so each run of lanes with the same record adds its hit counts
+// with ONE atomic per tally word, and the hit log takes one atomic per wave.
+__device__ __forceinline__ void sk_tally_wave(const sk_sink &k, uint32_t hit, uint32_t pos, uint32_t lane)
+{
+    const bool is_hit = hit != 0xFFFFFFFFu;
+    uint32_t rec = 0xFFFFFF00u | lane;                    // distinct per lane when there is no hit
+    bool is_inf = false;
+    if (is_hit) {
+        const uint32_t t = pos >> 15;
+        uint32_t lo = k.tile_first[t], hi = k.tile_first[t + 1u];
+        lo = lo ? lo - 1u : 0u;
+        if (hi <= lo) hi = lo + 1u;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (k.rec_start[mid] <= pos) lo = mid; else hi = mid;
+        }
+        rec = lo;
+        is_inf = k.type[hit] == k.inf_value;
+    }
+    const uint32_t prev = (uint32_t)__shfl_up((int)rec, 1);
+    const bool first = (lane == 0u) | (rec != prev);
+    const unsigned long long fm = __ballot(first), hm = __ballot(is_hit), im = __ballot(is_inf);
+    if (first & is_hit) {
+        const unsigned long long above = lane == 63u ? 0ull : fm & ~((2ull << lane) - 1ull);
+        const uint32_t end = above ? (uint32_t)__builtin_ctzll(above) : 64u;
+        const unsigned long long seg = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+        atomicAdd(&k.tally[2u * rec], (uint32_t)__popcll(hm & seg));
+        const uint32_t ni = (uint32_t)__popcll(im & seg);
+        if (ni) atomicAdd(&k.tally[2u * rec + 1u], ni);
+    }
+    if (im) {
+        unsigned long long base = 0;
+        const uint32_t leader = (uint32_t)__builtin_ctzll(im);
+        if (lane == leader) base = atomicAdd(k.nhits, (unsigned long long)__popcll(im));
+        base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), (int)leader) << 32) |
+               (uint32_t)__shfl((int)(uint32_t)base, (int)leader);
+        if (is_inf) {
+            const unsigned long long i = base + (unsigned long long)__popcll(im & ((1ull << lane) - 1ull));
+            if (i < k.hits_cap) k.hits[i] = make_uint2(pos, k.inv ? k.inv[hit] : hit);
+        }
     }
 }
 
@@ -323,7 +372,8 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             if (hit == 0xFFFFFFFFu) { uint32_t unused; hit = sk_find(cn, table, &unused); }
         }
         // one atomic instruction for the whole batch: neighbouring counters coalesce
-        if (hit != 0xFFFFFFFFu) sk_on_hit<TALLY, ABLATE == 3>(sink, hit, pos);
+        if (TALLY) sk_tally_wave(sink, act ? hit : 0xFFFFFFFFu, pos, lane);
+        else if (hit != 0xFFFFFFFFu) sk_on_hit<false, ABLATE == 3>(sink, hit, pos);
         __builtin_amdgcn_wave_barrier();
     };
     auto probe_batch = [&]() { probe_some(64u); };
@@ -968,17 +1018,26 @@ extern "C" int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes,
     SK_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = sk_scratch(c, &c->t_stream, &c->t_stream_cap, nbytes + 16)) != SK_OK) return rc;
-    if ((rc = sk_scratch(c, &c->t_rec, &c->t_rec_cap, (size_t)nrec * 4)) != SK_OK) return rc;
+    const uint32_t ntiles = (uint32_t)((nbytes + 32767u) >> 15);
+    if ((rc = sk_scratch(c, &c->t_rec, &c->t_rec_cap, ((size_t)nrec + ntiles + 2) * 4)) != SK_OK) return rc;
+    std::vector<uint32_t> tile_first(ntiles + 2);
+    for (uint32_t t = 0, r = 0; t < ntiles + 2; t++) {             // first record starting at or after the tile's first byte
+        const uint64_t edge = (uint64_t)t << 15;
+        while (r < nrec && rec_start[r] < edge) r++;
+        tile_first[t] = r;
+    }
     if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)nrec * 8 + 8)) != SK_OK) return rc;
     if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
     unsigned long long *d_n = (unsigned long long *)((uint8_t *)c->t_tally + (size_t)nrec * 8);   // hit counter behind the tallies
     unsigned long long nh = 0;
     SK_HIP(c, hipMemcpyAsync(c->t_stream, stream, nbytes, hipMemcpyHostToDevice, c->stream));
     SK_HIP(c, hipMemcpyAsync(c->t_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(c, hipMemcpyAsync((uint32_t *)c->t_rec + nrec, tile_first.data(), (size_t)(ntiles + 2) * 4, hipMemcpyHostToDevice, c->stream));
     SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)nrec * 8 + 8, c->stream));
     sk_sink sink;
     memset(&sink, 0, sizeof sink);
     sink.rec_start = (const uint32_t *)c->t_rec; sink.nrec = nrec; sink.tally = (uint32_t *)c->t_tally;
+    sink.tile_first = (const uint32_t *)c->t_rec + nrec;
     sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
     sink.hits = (uint2 *)c->t_hits; sink.nhits = d_n; sink.hits_cap = hits_cap; sink.inv = c->d_inv;
     rc = sk_launch_scan(c, (const uint8_t *)c->t_stream, nbytes, 0, 0, &sink);
