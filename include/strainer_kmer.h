@@ -232,6 +232,43 @@ typedef int (*skh_sink_fn)(void *user, const uint8_t *chunk, uint64_t nbytes);
 int64_t skh_decode_file(const char *path, uint64_t chunk_bytes, skh_sink_fn sink, void *user,
                         uint64_t *bases);
 
+/* ------------------------------------------------------------------------------------------------
+ * Scrub filter: the consumer of the count table (reference scripts/kmer_scrub_filter.py, step 2 of
+ * test/example.sh).  The count columns live on the device, either uploaded from a parsed table
+ * (sk_filter_load) or taken straight from the counters a scan has just filled (sk_filter_load_counts:
+ * the table never becomes text); the ranking the script does with a full sort is a radix selection
+ * there.  A "row" is one k-mer of the strain; rows marked gone do not take part (the script's drug
+ * scrub, :62-69) but still count towards the column sums, as their dictionary entries do in the script.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sk_filter sk_filter;
+int  sk_filter_create(sk_ctx *ctx, sk_filter **out);
+void sk_filter_destroy(sk_filter *f);
+/* Counts as the table's text carries them (signed: a counter >= 2^31 was printed negative by %d and is
+ * "not > 0" to the script). */
+int  sk_filter_load(sk_filter *f, const int64_t *pan, const int64_t *meta, const uint8_t *gone /* may be NULL */, uint64_t n);
+/* Columns of the context's resident counters, in row order; drug_col < 0: no drug column, else rows
+ * with a positive drug count are gone.  Replaces print_hash_counts + the script's parse (:164-201). */
+int  sk_filter_load_counts(sk_filter *f, uint32_t pan_col, uint32_t meta_col, int32_t drug_col);
+/* Sums and sizes of the script's pangenome_hash / metagenome_hash (positive entries only) (:91-106,204). */
+int  sk_filter_sums(sk_filter *f, int64_t *pan_sum, int64_t *meta_sum, uint64_t *n_pan, uint64_t *n_meta, uint64_t *n_gone);
+/* Value histogram of one column (0 = pan, 1 = meta) over its positive entries: hist[b] = #{v == lo + b}
+ * for b < nbins, hist[nbins] = #{v >= lo + nbins}.  Feeds scrub_max_kmers' threshold walk (:30-58). */
+int  sk_filter_hist(sk_filter *f, int which, int64_t lo, uint32_t nbins, uint64_t *hist /* nbins + 1 */);
+/* joint_scrub (:87-137): remove the n_scrub rows with the largest max(pan/pan_sum, meta/meta_sum),
+ * equal scores in row order.  out[r] = 1 for every row that is NOT in the result (gone before, or
+ * removed now). */
+int  sk_filter_joint(sk_filter *f, int64_t pan_sum, int64_t meta_sum, uint64_t n_scrub, uint8_t *out /* n */);
+/* independent_scrub (:72-84): remove rows whose pan count exceeds pan_thr or meta count meta_thr. */
+int  sk_filter_above(sk_filter *f, int64_t pan_thr, int64_t meta_thr, uint8_t *out /* n */);
+
+/* The script's command line (-s/--scrub_count_file, -l/--scrub_count_list, -m/--min_fraction,
+ * -i/--independent): same stdout bytes, same exit status, the same "kept ..." lines on stderr. */
+int skh_scrub_filter_main(int argc, char **argv, FILE *out, FILE *err);
+/* Fused step 1 -> step 2: what the script would print for the table skh_print_counts would print,
+ * computed from the resident counters (columns 1, 2 and, with_drug_column, 3). */
+int skh_scrub_filter_resident(sk_ctx *ctx, const skh_keyset *ks, int with_drug_column, double min_fraction,
+                              int independent, FILE *out, FILE *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,7 @@
 
 #include "../../include/strainer_kmer.h"
 #include "sk_common.h"
+#include "sk_internal.h"
 
 // ---------------------------------------------------------------------------------------------
 // scan kernel geometry
@@ -1202,6 +1203,32 @@ extern "C" int sk_counts_zero(sk_ctx *c, uint32_t col)
 }
 
 extern "C" void *sk_counts_device_ptr(sk_ctx *c) { return c ? (void *)c->d_counts : NULL; }
+
+// ---- for the other translation units of the library (sk_internal.h)
+extern "C" int sk_fail_(sk_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+extern "C" int sk_ctx_device_(const sk_ctx *c) { return c->device; }
+extern "C" int sk_counts_rows_to_device_(sk_ctx *c, uint32_t col, uint32_t *d_out)
+{
+    if (!c || !d_out) return SK_E_ARG;
+    if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
+    SK_HIP(c, hipSetDevice(c->device));
+    const uint32_t *src = c->d_counts + (size_t)col * c->nrows;
+    if (c->d_perm && c->nrows)
+        hipLaunchKernelGGL(sk_gather_u32, dim3((c->nrows + 255) / 256), dim3(256), 0, c->stream, d_out, src, c->d_perm, c->nrows);
+    else
+        SK_HIP(c, hipMemcpyAsync(d_out, src, (size_t)c->nrows * 4, hipMemcpyDeviceToDevice, c->stream));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
 extern "C" uint32_t sk_table_rows(const sk_ctx *c) { return c ? c->nrows : 0; }
 extern "C" uint32_t sk_table_cols(const sk_ctx *c) { return c ? c->ncols : 0; }
 

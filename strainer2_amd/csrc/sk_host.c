@@ -738,6 +738,28 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     int device = env_int("SK_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", 0);
     const int use_comm = world > 1 || getenv("SK_FORCE_COMM") != NULL;
     uint32_t nfailed = 0;
+    double scrub_fraction = -1.0;                    /* >= 0: print the scrub filter's result instead of the table */
+    int scrub_independent = 0, j;
+
+    /* Extension (not in the reference): "--scrub <min_fraction>" [--independent] runs step 2 of the
+     * workflow (scripts/kmer_scrub_filter.py -s <table> -m <min_fraction> [-i]) on the counters while
+     * they are still on the device and prints ITS output; the 38-bytes-per-k-mer table is never written.
+     * The words are taken out of argv before getopt, which only knows the reference's letters. */
+    for (c = 1, j = 1; c < argc; c++) {
+        if (!strcmp(argv[c], "--independent")) { scrub_independent = 1; continue; }
+        if (!strncmp(argv[c], "--scrub", 7) && (argv[c][7] == 0 || argv[c][7] == '=')) {
+            const char *v = argv[c][7] ? argv[c] + 8 : (c + 1 < argc ? argv[++c] : "");
+            char *e;
+            scrub_fraction = strtod(v, &e);
+            if (e == v || *e || scrub_fraction < 0.0 || scrub_fraction > 1.0) {
+                fprintf(err, "kmer_scrub_count: --scrub needs a fraction between 0.0 and 1.0\n");
+                return 1;
+            }
+            continue;
+        }
+        argv[j++] = argv[c];
+    }
+    argc = j;
 
     optind = 1;
     while ((c = getopt(argc, argv, "A:B:C:r:p:Hhud")) != -1) {
@@ -805,6 +827,10 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
         rc = sk_counts_allreduce(ctx, NULL);
         if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: all-reduce failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
     } else if (failed) goto done;
+    if (rank == 0 && scrub_fraction >= 0.0) {
+        status = skh_scrub_filter_resident(ctx, &ks, C != NULL, scrub_fraction, scrub_independent, out, err);
+        goto done;
+    }
     if (rank == 0) {
         rc = skh_print_counts(ctx, &ks, out, C != NULL);
         if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }

@@ -48,6 +48,8 @@ ABI_SYMBOLS = [
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
     "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
     "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_decode_file",
+    "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
+    "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
 ]
 
 
@@ -111,6 +113,19 @@ lib.skh_print_counts.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_void_
 lib.skh_kmer_scrub_count_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
 lib.skh_decode_file.argtypes = [C.c_char_p, C.c_uint64, _SINK, C.c_void_p, C.POINTER(C.c_uint64)]
 lib.skh_decode_file.restype = C.c_int64
+
+lib.sk_filter_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+lib.sk_filter_destroy.argtypes = [C.c_void_p]
+lib.sk_filter_destroy.restype = None
+lib.sk_filter_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+lib.sk_filter_load_counts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32]
+lib.sk_filter_sums.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+lib.sk_filter_hist.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_void_p]
+lib.sk_filter_joint.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p]
+lib.sk_filter_above.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+lib.skh_scrub_filter_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
+lib.skh_scrub_filter_resident.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
 
 _libc = C.CDLL(None)
 _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
@@ -341,6 +356,56 @@ class KmerContext:
         return self
 
     def __exit__(self, *a):
+        self.close()
+
+
+class ScrubFilter:
+    """Device side of the scrub filter (sk_filter_*): count columns resident on the GPU."""
+
+    def __init__(self, ctx: KmerContext):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        ctx._ck(lib.sk_filter_create(ctx._h, C.byref(self._h)))
+        self.n = 0
+
+    def load(self, pan, meta, gone=None):
+        pan = np.ascontiguousarray(pan, dtype=np.int64)
+        meta = np.ascontiguousarray(meta, dtype=np.int64)
+        assert len(pan) == len(meta)
+        g = None if gone is None else np.ascontiguousarray(gone, dtype=np.uint8)
+        self._ctx._ck(lib.sk_filter_load(self._h, pan.ctypes.data, meta.ctypes.data, None if g is None else g.ctypes.data, len(pan)))
+        self.n = len(pan)
+
+    def load_counts(self, pan_col=1, meta_col=2, drug_col=-1):
+        self._ctx._ck(lib.sk_filter_load_counts(self._h, pan_col, meta_col, drug_col))
+        self.n = lib.sk_table_rows(self._ctx._h)
+
+    def sums(self):
+        v = [C.c_int64(), C.c_int64(), C.c_uint64(), C.c_uint64(), C.c_uint64()]
+        self._ctx._ck(lib.sk_filter_sums(self._h, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
+
+    def hist(self, which, lo, nbins):
+        out = np.zeros(nbins + 1, dtype=np.uint64)
+        self._ctx._ck(lib.sk_filter_hist(self._h, which, lo, nbins, out.ctypes.data))
+        return out
+
+    def joint(self, pan_sum, meta_sum, n_scrub):
+        out = np.zeros(self.n, dtype=np.uint8)
+        self._ctx._ck(lib.sk_filter_joint(self._h, pan_sum, meta_sum, n_scrub, out.ctypes.data))
+        return out
+
+    def above(self, pan_thr, meta_thr):
+        out = np.zeros(self.n, dtype=np.uint8)
+        self._ctx._ck(lib.sk_filter_above(self._h, pan_thr, meta_thr, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.sk_filter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
         self.close()
 
 

@@ -40,3 +40,30 @@ def test_oracle_under_asan_ubsan(golden, name, tmp_path):
     p = subprocess.run([exe] + argv, cwd=d, env=ENV, capture_output=True)
     assert p.returncode == meta["returncode"], p.stderr.decode()[-2000:]
     assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def filter_host_exe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("flt") / "filter_sanitize")
+    subprocess.run(["gcc"] + SAN + [os.path.join(REPO, "tests", "native", "filter_sanitize.c"),
+                                   os.path.join(REPO, "strainer2_amd", "csrc", "sk_host_filter.c"), "-lz", "-o", exe], check=True)
+    return exe
+
+
+FILTER_CASES = os.path.join(REPO, "tests", "golden", "filter_cases")
+
+
+@pytest.mark.parametrize("name", sorted(os.listdir(FILTER_CASES)))
+def test_filter_host_logic_under_asan_ubsan(filter_host_exe, name):
+    """Host half of kmer_scrub_filter (parse, dictionaries, the float cut, printing) against the reference
+    script's output, with a test double for the device calls (tests/native/filter_sanitize.c)."""
+    d = os.path.join(FILTER_CASES, name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    p = subprocess.run([filter_host_exe] + meta["argv"], cwd=d, env=ENV, capture_output=True)
+    assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
+    assert p.returncode == meta["returncode"], p.stderr.decode()[-2000:]
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+    if meta["stderr_exact"]:
+        assert p.stderr == open(os.path.join(d, "expected.stderr"), "rb").read()
+    elif meta["returncode"]:
+        assert p.stderr
