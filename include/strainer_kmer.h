@@ -269,6 +269,19 @@ int skh_scrub_filter_main(int argc, char **argv, FILE *out, FILE *err);
 int skh_scrub_filter_resident(sk_ctx *ctx, const skh_keyset *ks, int with_drug_column, double min_fraction,
                               int independent, FILE *out, FILE *err);
 
+/* ------------------------------------------------------------------------------------------------
+ * Coverage / depth: the consumer of strain_detect's hit list (reference scripts/coverage_depth.py,
+ * step 4 of test/example.sh).
+ * ---------------------------------------------------------------------------------------------- */
+/* Per sample s < nsamples: out_total[s] = number of (sample, key) pairs with that sample,
+ * out_unique[s] = number of different keys among them.  Replaces the script's unique_kmers_by_metagenome
+ * / kmer_depth_count_by_metagenome bookkeeping (:64-93).  Keys are any u64 but 2^64-1.  Synchronous. */
+int sk_distinct_count(sk_ctx *ctx, const uint64_t *keys, const uint32_t *sample, uint64_t n, uint32_t nsamples,
+                      uint64_t *out_unique, uint64_t *out_total);
+/* The script's command line (-k/--kmer_hits_file, -m/--min_kmer_hits, -b/--background_metagenomes_file):
+ * same stdout bytes and exit status. */
+int skh_coverage_depth_main(int argc, char **argv, FILE *out, FILE *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ ABI_SYMBOLS = [
     "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_decode_file",
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
+    "sk_distinct_count", "skh_coverage_depth_main",
 ]
 
 
@@ -126,6 +127,9 @@ lib.sk_filter_joint.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.
 lib.sk_filter_above.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
 lib.skh_scrub_filter_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
 lib.skh_scrub_filter_resident.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+
+lib.sk_distinct_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+lib.skh_coverage_depth_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
 
 _libc = C.CDLL(None)
 _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
@@ -333,6 +337,16 @@ class KmerContext:
         out = np.empty(nbytes, dtype=np.uint8)
         self._ck(lib.sk_dev_download(self._h, out.ctypes.data, ptr, nbytes))
         return out
+
+    def distinct_count(self, keys, sample, nsamples):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        assert len(keys) == len(sample)
+        uniq = np.zeros(nsamples, dtype=np.uint64)
+        total = np.zeros(nsamples, dtype=np.uint64)
+        self._ck(lib.sk_distinct_count(self._h, keys.ctypes.data, sample.ctypes.data, len(keys), nsamples,
+                                       uniq.ctypes.data, total.ctypes.data))
+        return uniq, total
 
     def print_counts(self, ks: Keyset, path, with_drug_column=False):
         fp = _libc.fopen(os.fsencode(path), b"w")

@@ -259,6 +259,23 @@ def make_cov_cases():
          "#x.fa\ttotal_genome_kmers\t0\n#x.fa\ttotal_genome_informative_kmers\t0\n"
     write_gz(os.path.join(CCASES, "zero_informative", "a.kmer_hits.gz"), t3)
     run(COV_REF, CCASES, "zero_informative", ["-k", "a.kmer_hits.gz"], "float division by zero: rc 1 after the header")
+    # k-mer text outside strain_detect's alphabet / of mixed length; two different (sample, k-mer) pairs
+    # that join to the same string ("s1"+"ACGTACGT" == "s1A"+"CGTACGT"): the script counts the second as seen
+    t4 = ("s1\t5\t1\t0\t0\tACGTACGT\n" "d/s1A\t5\t1\t0\t0\tCGTACGT\n" "s1A\t9\t1\t0\t0\tCGTACGT\n"
+          "s1\t5\t1\t3\t0\tacgtnnrya\n" "s1\t5\t1\t3\t0\tacgtnnrya\n" "s2\t2\t1\t0\t0\t" + kmers[3] + "\n"
+          "s2\t1\t1\t0\t0\t" + kmers[4] + "\n" "s2\t7\t1\t0\t0\t" + kmers[3] + "\textra\tfields\n")
+    for smp in ("s1", "s1A", "s2"):
+        t4 += f"#{smp}\ttotal_kmer_evaluated\t1000\n#{smp}\ttotal_reads_evaluated\t10\n#{smp}\ttotal_genome_kmers\t99\n#{smp}\ttotal_genome_informative_kmers\t7\n"
+    write_gz(os.path.join(CCASES, "general_text", "x_y_z.kmer_hits.gz"), t4)
+    run(COV_REF, CCASES, "general_text", ["-k", "x_y_z.kmer_hits.gz"], "ragged / non-ACGT k-mer text and a joined-string collision", True)
+    # trailer-only samples are listed in the order of their total_kmer_evaluated lines
+    t5 = ("#x.fa\ttotal_reads_evaluated\t5\n#y.fa\ttotal_kmer_evaluated\t50\n#x.fa\ttotal_kmer_evaluated\t40\n"
+          "#x.fa\ttotal_genome_informative_kmers\t4\n#y.fa\ttotal_genome_informative_kmers\t4\n"
+          "#x.fa\ttotal_genome_kmers\t8\n#y.fa\ttotal_genome_kmers\t8\n#z.fa\ttotal_reads_evaluated\t1\t \n")
+    write_gz(os.path.join(CCASES, "trailer_order", "g.kmer_hits.gz"), t5)
+    run(COV_REF, CCASES, "trailer_order", ["-k", "g.kmer_hits.gz"], "order of trailer-only samples; trailing blanks", True)
+    write_gz(os.path.join(CCASES, "short_line", "g.kmer_hits.gz"), "s\t1\t1\t1\t1\n")
+    run(COV_REF, CCASES, "short_line", ["-k", "g.kmer_hits.gz"], "five fields: IndexError, rc 1")
     write_gz(os.path.join(CCASES, "empty", "a_b_c.kmer_hits.gz"), "")
     run(COV_REF, CCASES, "empty", ["-k", "a_b_c.kmer_hits.gz"], "empty hits file: header only", True)
     # the real step-3 golden of the bundled example

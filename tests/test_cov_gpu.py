@@ -1,0 +1,89 @@
+"""coverage_depth on the GPU (reference scripts/coverage_depth.py): the program against the fixtures the
+reference script produced, sk_distinct_count against numpy, and the program against the oracle on a
+large synthetic hit list."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import strainer2_amd as sk
+from test_sanitizers import COV_CASES, prepare_cov_case
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(REPO, "oracle")
+
+
+def _oracle_bin(name):
+    p = os.path.join(ORACLE_DIR, name)
+    if not os.path.exists(p):
+        subprocess.run(["make", "-C", ORACLE_DIR, name], check=True, stdout=subprocess.DEVNULL)
+    return p
+
+
+@pytest.mark.parametrize("name", sorted(os.listdir(COV_CASES)))
+def test_coverage_program_matches_reference_script(name):
+    d = os.path.join(COV_CASES, name)
+    prepare_cov_case(name, d)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    p = subprocess.run([sk.cli_path("coverage_depth")] + meta["argv"], cwd=d, capture_output=True)
+    assert p.returncode == meta["returncode"], p.stderr.decode()[-500:]
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+    if meta["returncode"]:
+        assert p.stderr
+
+
+@pytest.mark.parametrize("n,nsamples,pool", [(1, 1, 1), (1000, 3, 50), (300_000, 7, 20_000), (5_000_000, 40, 400_000)])
+def test_distinct_count_vs_numpy(n, nsamples, pool):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2 ** 62, pool, dtype=np.uint64)[rng.integers(0, pool, n)]
+    sample = np.sort(rng.integers(0, nsamples, n).astype(np.uint32)) if n % 2 else rng.integers(0, nsamples, n).astype(np.uint32)
+    with sk.KmerContext(0) as ctx:
+        uniq, total = ctx.distinct_count(keys, sample, nsamples)
+    assert np.array_equal(total, np.bincount(sample, minlength=nsamples).astype(np.uint64))
+    want = np.zeros(nsamples, dtype=np.uint64)
+    for s in range(nsamples):
+        want[s] = len(np.unique(keys[sample == s]))
+    assert np.array_equal(uniq, want)
+
+
+def test_coverage_program_vs_oracle_large(tmp_path):
+    rng = np.random.default_rng(7)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    kmers = [acgt[rng.integers(0, 4, 31)].tobytes() for _ in range(30_000)]
+    path = tmp_path / "Some_strain_x1.kmer_hits.gz"
+    with gzip.GzipFile(path, "wb", compresslevel=1, mtime=0) as g:
+        for s in range(12):
+            name = b"meta/sample%d_PE1.fastq.gz" % s
+            lines = []
+            for _ in range(int(rng.integers(0, 60_000))):
+                lines.append(b"%s\t%d\t%d\t%d\t%d\t%s\n" % (name, rng.integers(0, 5), rng.integers(0, 3), rng.integers(0, 4),
+                                                            rng.integers(0, 2), kmers[int(rng.integers(0, len(kmers)) ** 0.9)]))
+            g.write(b"".join(lines))
+            g.write(b"#%s\ttotal_kmer_evaluated\t%d\n#%s\ttotal_reads_evaluated\t%d\n#%s\ttotal_genome_kmers\t5000000\n"
+                    b"#%s\ttotal_genome_informative_kmers\t30000\n" % (name, rng.integers(1, 10 ** 10), name, rng.integers(1, 10 ** 8), name, name))
+    for extra in ([], ["-m", "3"]):
+        argv = ["-k", str(path)] + extra
+        want = subprocess.run([_oracle_bin("kcd_oracle")] + argv, capture_output=True)
+        got = subprocess.run([sk.cli_path("coverage_depth")] + argv, capture_output=True)
+        assert want.returncode == 0 and want.stdout.count(b"\n") == 13
+        assert (got.returncode, got.stdout) == (0, want.stdout)
+
+
+def test_bundled_steps_3_and_4(golden, tmp_path):
+    """test/example.sh steps 3+4 on the bundled data through the GPU programs: strain_detect's hit list,
+    then coverage_depth on it, against what the reference's script printed for the reference's hit list."""
+    b = os.path.join(golden, "bundled")
+    facts = json.load(open(os.path.join(b, "step3_facts.json")))
+    nm = "Bacteroides_ovatus_1001283st1_B8_1001283B150210_160208.kmer_hits.gz"
+    argv = list(facts["argv"])
+    argv[argv.index("-o") + 1] = str(tmp_path / nm)
+    p = subprocess.run([sk.cli_path("strain_detect")] + argv, cwd=b, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    q = subprocess.run([sk.cli_path("coverage_depth"), "-k", str(tmp_path / nm)], capture_output=True)
+    want = open(os.path.join(COV_CASES, "bundled_step4", "expected.stdout"), "rb").read()
+    assert (q.returncode, q.stdout) == (0, want)

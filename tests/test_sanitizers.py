@@ -67,3 +67,36 @@ def test_filter_host_logic_under_asan_ubsan(filter_host_exe, name):
         assert p.stderr == open(os.path.join(d, "expected.stderr"), "rb").read()
     elif meta["returncode"]:
         assert p.stderr
+
+
+@pytest.fixture(scope="module")
+def cov_host_exe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("cov") / "cov_sanitize")
+    subprocess.run(["gcc"] + SAN + [os.path.join(REPO, "tests", "native", "cov_sanitize.c"),
+                                   os.path.join(REPO, "strainer2_amd", "csrc", "sk_host_cov.c"), "-lz", "-o", exe], check=True)
+    return exe
+
+
+COV_CASES = os.path.join(REPO, "tests", "golden", "cov_cases")
+
+
+def prepare_cov_case(name, d):
+    """the bundled step-4 case reads the step-3 golden, kept once under tests/golden/bundled"""
+    if name == "bundled_step4":
+        import gzip
+        dst = os.path.join(d, "Bacteroides_ovatus_1001283st1_B8_1001283B150210_160208.kmer_hits.gz")
+        if not os.path.exists(dst):
+            with open(os.path.join(REPO, "tests", "golden", "bundled", "step3_expected.hits"), "rb") as f, \
+                    gzip.GzipFile(dst, "wb", mtime=0) as g:
+                g.write(f.read())
+
+
+@pytest.mark.parametrize("name", sorted(os.listdir(COV_CASES)))
+def test_coverage_host_logic_under_asan_ubsan(cov_host_exe, name):
+    d = os.path.join(COV_CASES, name)
+    prepare_cov_case(name, d)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    p = subprocess.run([cov_host_exe] + meta["argv"], cwd=d, env=ENV, capture_output=True)
+    assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
+    assert p.returncode == meta["returncode"], p.stderr.decode()[-2000:]
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
