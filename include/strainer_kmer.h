@@ -121,6 +121,18 @@ int sk_tally_batch(sk_ctx *ctx, const uint8_t *stream, uint64_t nbytes, const ui
                    uint32_t type_col, uint32_t informative_value, uint32_t *out_tally /* 2*nrec */,
                    sk_hit *out_hits, uint64_t hits_cap, uint64_t *out_nhits);
 
+/* The same in pieces, for tallying ONE batch against MANY tables (several strains resident on one
+ * device, one context each): upload the batch once, launch on every context (each on its own HIP
+ * stream, so the launches overlap), then collect.  A batch may be refilled only after every launch on
+ * it has been collected; a context has at most one launch in flight.  New: the reference runs one
+ * strain per process and re-reads the metagenome for each. */
+typedef struct sk_batch sk_batch;
+int  sk_batch_create(sk_ctx *ctx, sk_batch **out);          /* on ctx's device; errors are reported through ctx */
+void sk_batch_destroy(sk_batch *b);
+int  sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec);
+int  sk_tally_launch(sk_ctx *ctx, const sk_batch *b, uint32_t type_col, uint32_t informative_value, uint64_t hits_cap);
+int  sk_tally_collect(sk_ctx *ctx, uint32_t *out_tally /* 2*nrec */, sk_hit *out_hits /* hits_cap */, uint64_t *out_nhits);
+
 /* Wait for all queued work of the context. */
 int sk_sync(sk_ctx *ctx);
 

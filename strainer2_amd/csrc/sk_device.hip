@@ -716,8 +716,13 @@ struct sk_ctx {
     long         bloom_bits_log2;
     long         stats;               // debug: count live windows / filter loads / table probes
     long         ablate;              // timing experiments: kernel variants that skip memory stages
-    void        *t_stream, *t_rec, *t_tally, *t_hits;          // grow-only scratch of sk_tally_batch
-    size_t       t_stream_cap, t_rec_cap, t_tally_cap, t_hits_cap;
+    void        *t_tally, *t_hits;    // grow-only device scratch of the tally path
+    size_t       t_tally_cap, t_hits_cap;
+    uint8_t     *h_tally;             // pinned landing area of the tallies (+ the hit counter)
+    size_t       h_tally_cap;
+    uint32_t     t_inflight_nrec;     // a sk_tally_launch waiting for its sk_tally_collect
+    uint64_t     t_inflight_cap;
+    struct sk_batch *own_batch;       // sk_tally_batch's private batch
     void        *comm;                // RCCL communicator from sk_comm_init (NULL: single process)
     int          comm_rank, comm_world;
     char         err[512];
@@ -802,6 +807,7 @@ static void sk_table_release(sk_ctx *c)
 }
 
 extern "C" void sk_comm_destroy(sk_ctx *c);
+extern "C" void sk_batch_destroy(struct sk_batch *b);
 
 extern "C" void sk_ctx_destroy(sk_ctx *c)
 {
@@ -817,7 +823,9 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
     }
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 64; i++) if (c->copied[i]) hipEventDestroy(c->copied[i]);
-    hipFree(c->t_stream); hipFree(c->t_rec); hipFree(c->t_tally); hipFree(c->t_hits);
+    if (c->own_batch) sk_batch_destroy(c->own_batch);
+    hipFree(c->t_tally); hipFree(c->t_hits);
+    if (c->h_tally) hipHostFree(c->h_tally);
     hipFree(c->d_flags);
     hipStreamDestroy(c->stream);
     delete c;
@@ -1007,49 +1015,153 @@ static int sk_scratch(sk_ctx *c, void **p, size_t *cap, size_t need)
     return SK_OK;
 }
 
-// Per-record tallies of one batch (strain_detect): synchronous.
+// ---------------------------------------------------------------------------------------------
+// strain_detect: a batch of records resident on the device, tallied against any number of tables
+// ---------------------------------------------------------------------------------------------
+struct sk_batch {
+    sk_ctx      *owner;
+    hipStream_t  stream;
+    hipEvent_t   ready;                 // the upload of the current contents
+    void        *d_stream, *d_rec;      // bytes; rec_start[nrec] followed by tile_first[ntiles + 2]
+    size_t       stream_cap, rec_cap;
+    uint64_t     nbytes;
+    uint32_t     nrec, ntiles;
+    std::vector<uint32_t> tile_first;
+};
+
+extern "C" int sk_batch_create(sk_ctx *c, sk_batch **out)
+{
+    if (!c || !out) return SK_E_ARG;
+    *out = NULL;
+    SK_HIP(c, hipSetDevice(c->device));
+    sk_batch *b = new (std::nothrow) sk_batch();
+    if (!b) return SK_E_NOMEM;
+    b->owner = c;
+    b->d_stream = b->d_rec = NULL; b->stream_cap = b->rec_cap = 0; b->nbytes = 0; b->nrec = b->ntiles = 0;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; return sk_fail(c, SK_E_HIP, "stream"); }
+    if (hipEventCreateWithFlags(&b->ready, hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(b->stream); delete b; return sk_fail(c, SK_E_HIP, "event"); }
+    *out = b;
+    return SK_OK;
+}
+
+extern "C" void sk_batch_destroy(sk_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->owner->device);
+    hipStreamSynchronize(b->stream);
+    hipFree(b->d_stream); hipFree(b->d_rec);
+    hipEventDestroy(b->ready);
+    hipStreamDestroy(b->stream);
+    delete b;
+}
+
+// Upload new contents.  Every tally launched on the previous contents must have been collected.
+extern "C" int sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec)
+{
+    if (!b || !stream || !rec_start) return SK_E_ARG;
+    sk_ctx *c = b->owner;
+    if (nbytes == 0 || nrec == 0 || nbytes > 0xFFFFFFF0ull) return sk_fail(c, SK_E_ARG, "bad batch size");
+    SK_HIP(c, hipSetDevice(c->device));
+    const uint32_t ntiles = (uint32_t)((nbytes + 32767u) >> 15);
+    if (nbytes + 16 > b->stream_cap) {
+        SK_HIP(c, hipStreamSynchronize(b->stream));
+        (void)hipFree(b->d_stream); b->d_stream = NULL; b->stream_cap = 0;
+        const size_t want = nbytes + nbytes / 4 + 4096;
+        SK_HIP(c, hipMalloc(&b->d_stream, want));
+        b->stream_cap = want;
+    }
+    const size_t rec_need = ((size_t)nrec + ntiles + 2) * 4;
+    if (rec_need > b->rec_cap) {
+        SK_HIP(c, hipStreamSynchronize(b->stream));
+        (void)hipFree(b->d_rec); b->d_rec = NULL; b->rec_cap = 0;
+        const size_t want = rec_need + rec_need / 4 + 4096;
+        SK_HIP(c, hipMalloc(&b->d_rec, want));
+        b->rec_cap = want;
+    }
+    SK_HIP(c, hipStreamSynchronize(b->stream));            // tile_first (host vector) of the previous upload is free again
+    b->tile_first.resize((size_t)ntiles + 2);
+    for (uint32_t t = 0, r = 0; t < ntiles + 2; t++) {     // first record starting at or after the tile's first byte
+        const uint64_t edge = (uint64_t)t << 15;
+        while (r < nrec && rec_start[r] < edge) r++;
+        b->tile_first[t] = r;
+    }
+    SK_HIP(c, hipMemcpyAsync(b->d_stream, stream, nbytes, hipMemcpyHostToDevice, b->stream));
+    SK_HIP(c, hipMemcpyAsync(b->d_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, b->stream));
+    SK_HIP(c, hipMemcpyAsync((uint32_t *)b->d_rec + nrec, b->tile_first.data(), (size_t)(ntiles + 2) * 4, hipMemcpyHostToDevice, b->stream));
+    SK_HIP(c, hipEventRecord(b->ready, b->stream));
+    b->nbytes = nbytes; b->nrec = nrec; b->ntiles = ntiles;
+    return SK_OK;
+}
+
+// Start the tallies of batch `b` against the table of context `c` (any context on the batch's device);
+// returns at once.  One launch per context may be in flight.
+extern "C" int sk_tally_launch(sk_ctx *c, const sk_batch *b, uint32_t type_col, uint32_t informative_value, uint64_t hits_cap)
+{
+    if (!c || !b) return SK_E_ARG;
+    if (!c->d_keys) return sk_fail(c, SK_E_STATE, "no table loaded");
+    if (type_col >= c->ncols) return sk_fail(c, SK_E_ARG, "column %u out of range", type_col);
+    if (b->owner->device != c->device) return sk_fail(c, SK_E_ARG, "batch lives on another device");
+    if (b->nrec == 0) return sk_fail(c, SK_E_STATE, "empty batch");
+    SK_HIP(c, hipSetDevice(c->device));
+    int rc;
+    const uint32_t nrec = b->nrec;
+    if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)nrec * 8 + 8)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
+    if ((size_t)nrec * 8 + 8 > c->h_tally_cap) {
+        if (c->h_tally) { SK_HIP(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_tally); c->h_tally = NULL; c->h_tally_cap = 0; }
+        const size_t want = (size_t)nrec * 10 + 4096;
+        SK_HIP(c, hipHostMalloc((void **)&c->h_tally, want, hipHostMallocDefault));
+        c->h_tally_cap = want;
+    }
+    unsigned long long *d_n = (unsigned long long *)((uint8_t *)c->t_tally + (size_t)nrec * 8);   // hit counter behind the tallies
+    SK_HIP(c, hipStreamWaitEvent(c->stream, b->ready, 0));
+    SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)nrec * 8 + 8, c->stream));
+    sk_sink sink;
+    memset(&sink, 0, sizeof sink);
+    sink.rec_start = (const uint32_t *)b->d_rec; sink.nrec = nrec; sink.tally = (uint32_t *)c->t_tally;
+    sink.tile_first = (const uint32_t *)b->d_rec + nrec;
+    sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
+    sink.hits = (uint2 *)c->t_hits; sink.nhits = d_n; sink.hits_cap = hits_cap; sink.inv = c->d_inv;
+    rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink);
+    if (rc) return rc;
+    SK_HIP(c, hipMemcpyAsync(c->h_tally, c->t_tally, (size_t)nrec * 8 + 8, hipMemcpyDeviceToHost, c->stream));
+    c->t_inflight_nrec = nrec;
+    c->t_inflight_cap = hits_cap;
+    return SK_OK;
+}
+
+// Wait for the launch of this context and hand out its results.  *out_nhits may exceed hits_cap (log
+// overflow): launch again with more room.
+extern "C" int sk_tally_collect(sk_ctx *c, uint32_t *out_tally, sk_hit *out_hits, uint64_t *out_nhits)
+{
+    if (!c || !out_tally || !out_nhits) return SK_E_ARG;
+    if (!c->t_inflight_nrec) return sk_fail(c, SK_E_STATE, "no tally in flight");
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t nrec = c->t_inflight_nrec;
+    c->t_inflight_nrec = 0;
+    memcpy(out_tally, c->h_tally, (size_t)nrec * 8);
+    unsigned long long nh;
+    memcpy(&nh, (uint8_t *)c->h_tally + (size_t)nrec * 8, 8);
+    const unsigned long long take = nh < c->t_inflight_cap ? nh : c->t_inflight_cap;
+    if (take && !out_hits) return SK_E_ARG;
+    if (take) SK_HIP(c, hipMemcpy(out_hits, c->t_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost));
+    *out_nhits = nh;
+    return SK_OK;
+}
+
+// Per-record tallies of one batch, synchronous: upload + launch + collect on the context's own batch.
 extern "C" int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec,
                               uint32_t type_col, uint32_t informative_value, uint32_t *out_tally,
                               sk_hit *out_hits, uint64_t hits_cap, uint64_t *out_nhits)
 {
     if (!c || !stream || !rec_start || !out_tally || !out_nhits || (hits_cap && !out_hits)) return SK_E_ARG;
     if (!c->d_keys) return sk_fail(c, SK_E_STATE, "no table loaded");
-    if (type_col >= c->ncols) return sk_fail(c, SK_E_ARG, "column %u out of range", type_col);
-    if (nbytes == 0 || nrec == 0 || nbytes > 0xFFFFFFF0ull) return sk_fail(c, SK_E_ARG, "bad batch size");
-    SK_HIP(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = sk_scratch(c, &c->t_stream, &c->t_stream_cap, nbytes + 16)) != SK_OK) return rc;
-    const uint32_t ntiles = (uint32_t)((nbytes + 32767u) >> 15);
-    if ((rc = sk_scratch(c, &c->t_rec, &c->t_rec_cap, ((size_t)nrec + ntiles + 2) * 4)) != SK_OK) return rc;
-    std::vector<uint32_t> tile_first(ntiles + 2);
-    for (uint32_t t = 0, r = 0; t < ntiles + 2; t++) {             // first record starting at or after the tile's first byte
-        const uint64_t edge = (uint64_t)t << 15;
-        while (r < nrec && rec_start[r] < edge) r++;
-        tile_first[t] = r;
-    }
-    if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)nrec * 8 + 8)) != SK_OK) return rc;
-    if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
-    unsigned long long *d_n = (unsigned long long *)((uint8_t *)c->t_tally + (size_t)nrec * 8);   // hit counter behind the tallies
-    unsigned long long nh = 0;
-    SK_HIP(c, hipMemcpyAsync(c->t_stream, stream, nbytes, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(c, hipMemcpyAsync(c->t_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(c, hipMemcpyAsync((uint32_t *)c->t_rec + nrec, tile_first.data(), (size_t)(ntiles + 2) * 4, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)nrec * 8 + 8, c->stream));
-    sk_sink sink;
-    memset(&sink, 0, sizeof sink);
-    sink.rec_start = (const uint32_t *)c->t_rec; sink.nrec = nrec; sink.tally = (uint32_t *)c->t_tally;
-    sink.tile_first = (const uint32_t *)c->t_rec + nrec;
-    sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
-    sink.hits = (uint2 *)c->t_hits; sink.nhits = d_n; sink.hits_cap = hits_cap; sink.inv = c->d_inv;
-    rc = sk_launch_scan(c, (const uint8_t *)c->t_stream, nbytes, 0, 0, &sink);
-    if (rc) return rc;
-    SK_HIP(c, hipMemcpyAsync(out_tally, c->t_tally, (size_t)nrec * 8, hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(c, hipMemcpyAsync(&nh, d_n, 8, hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(c, hipStreamSynchronize(c->stream));
-    const unsigned long long take = nh < hits_cap ? nh : hits_cap;
-    if (take) SK_HIP(c, hipMemcpy(out_hits, c->t_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost));
-    *out_nhits = nh;
-    return SK_OK;
+    if (!c->own_batch && (rc = sk_batch_create(c, &c->own_batch)) != SK_OK) return rc;
+    if ((rc = sk_batch_fill(c->own_batch, stream, nbytes, rec_start, nrec)) != SK_OK) return rc;
+    if ((rc = sk_tally_launch(c, c->own_batch, type_col, informative_value, hits_cap)) != SK_OK) return rc;
+    return sk_tally_collect(c, out_tally, out_hits, out_nhits);
 }
 
 extern "C" int sk_scan_device(sk_ctx *c, const void *dev_stream, uint64_t nbytes, uint32_t col)

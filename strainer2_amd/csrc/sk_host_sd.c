@@ -15,6 +15,7 @@
  */
 #define _GNU_SOURCE
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,24 +31,159 @@ enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
 #define SD_BATCH_BYTES (32u << 20)
 
 /* ---------------------------------------------------------------------------------------------
- * one metagenome file, decoded and tallied on the device
+ * program state: one per strain (table on the device, type column, output, replay state)
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
-    uint64_t len;           /* sequence length as the reference sees it                          */
-    uint32_t hits, inf;     /* tallies (meaningful when len >= k)                                */
-    uint64_t hit_begin;     /* its informative hits, in window order: hit_rows[hit_begin .. +inf) */
-} sd_rec;
+    sk_ctx     *ctx;
+    skh_keyset  ks;
+    uint32_t   *type;          /* host copy of the type column */
+    FILE       *out, *err;
+    /* quantification */
+    gzFile      gz;            /* -o */
+    unsigned    genome_inf;    /* informative rows after -a / -g */
+    int         h1, i1, h2, i2;            /* tallies carried from read to read (src/strain_detect.c:444-454,497-500) */
+    uint32_t   *copy_rows; uint32_t copy_n, copy_cap;   /* informative rows of the PE1 read last copied (:451) */
+    sk_hit     *hitbuf; uint64_t hitcap;   /* landing area of the hit log */
+    uint32_t   *tallybuf; uint32_t tallycap;
+} sd_prog;
+
+/* ---------------------------------------------------------------------------------------------
+ * one metagenome file as a stream of chunks: a decode thread parses ahead, the main thread tallies
+ * each chunk against every strain and walks its records
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sd_chunk {
+    uint8_t  *buf; uint64_t blen, bcap;      /* record stream: the records of length >= k, '\n' after each */
+    uint32_t *pstart, *prec; uint32_t np, pcap;   /* those records: offset in buf, index in len[] */
+    uint64_t *len; uint32_t nrec, rcap;      /* every record, length as the reference sees it */
+    int       last, end_kind; size_t end_len;/* last chunk of the file: how the parser ended */
+    /* per strain, filled by sd_tally_chunk: tallies per record and the informative rows per record (CSR) */
+    uint32_t **hits, **inf, **hbeg, **rows;
+    uint32_t  nstrains;
+} sd_chunk;
 
 typedef struct {
-    sd_rec   *rec; size_t n, cap;
-    uint32_t *hit_rows; size_t nh, hcap;
-    int       end_kind; size_t end_len;
-    /* batch under construction */
-    sk_ctx   *ctx;
-    uint8_t  *buf; uint64_t blen;
-    uint32_t *bstart; uint64_t *bindex; uint32_t bn, bcap;
-    int       rc;
-} sd_file;
+    const char *path;
+    gzFile      g;
+    pthread_t   th; int started;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    sd_chunk   *q[3]; int qn, cancel;        /* decoded chunks waiting for the main thread */
+    sd_chunk   *cur;                         /* producer: chunk under construction */
+    /* consumer */
+    sd_chunk   *c; uint32_t ci;
+    int         eof, end_kind; size_t end_len;
+} sd_stream;
+
+static void chunk_free(sd_chunk *c)
+{
+    uint32_t s;
+    if (!c) return;
+    for (s = 0; s < c->nstrains; s++) { free(c->hits[s]); free(c->inf[s]); free(c->hbeg[s]); free(c->rows[s]); }
+    free(c->hits); free(c->inf); free(c->hbeg); free(c->rows);
+    free(c->buf); free(c->pstart); free(c->prec); free(c->len);
+    free(c);
+}
+
+static void stream_push(sd_stream *st, sd_chunk *c)
+{
+    pthread_mutex_lock(&st->mu);
+    while (st->qn == 3 && !st->cancel) pthread_cond_wait(&st->cv, &st->mu);
+    if (st->cancel) { pthread_mutex_unlock(&st->mu); chunk_free(c); return; }
+    st->q[st->qn++] = c;
+    pthread_cond_broadcast(&st->cv);
+    pthread_mutex_unlock(&st->mu);
+}
+
+/* parser callback (decode thread): one record */
+static int sd_on_record(void *user, char *seq, size_t len)
+{
+    sd_stream *st = (sd_stream *)user;
+    sd_chunk *c = st->cur;
+    if (st->cancel) return 1;
+    if (c && c->nrec && (c->blen + len + 1 > SD_BATCH_BYTES || c->nrec >= (1u << 22))) { stream_push(st, c); c = NULL; }
+    if (!c) c = st->cur = (sd_chunk *)calloc(1, sizeof *c);
+    if (c->nrec == c->rcap) {
+        c->rcap = c->rcap ? c->rcap * 2 : 1u << 16;
+        c->len = (uint64_t *)realloc(c->len, (size_t)c->rcap * sizeof *c->len);
+    }
+    c->len[c->nrec] = len;
+    if (len >= SK_K) {
+        if (c->np == c->pcap) {
+            c->pcap = c->pcap ? c->pcap * 2 : 1u << 16;
+            c->pstart = (uint32_t *)realloc(c->pstart, (size_t)c->pcap * sizeof *c->pstart);
+            c->prec = (uint32_t *)realloc(c->prec, (size_t)c->pcap * sizeof *c->prec);
+        }
+        if (c->blen + len + 1 > c->bcap) {                 /* a record never straddles chunks: grow instead */
+            uint64_t cap = c->bcap ? c->bcap : 1u << 20;
+            while (cap < c->blen + len + 1) cap *= 2;
+            c->buf = (uint8_t *)realloc(c->buf, cap);
+            c->bcap = cap;
+        }
+        c->pstart[c->np] = (uint32_t)c->blen;
+        c->prec[c->np++] = c->nrec;
+        memcpy(c->buf + c->blen, seq, len);
+        c->blen += len;
+        c->buf[c->blen++] = '\n';
+    }
+    c->nrec++;
+    return 0;
+}
+
+static void *sd_decode_thread(void *arg)
+{
+    enum { BLK = 1 << 20 };
+    sd_stream *st = (sd_stream *)arg;
+    unsigned char *blk = (unsigned char *)malloc(BLK);
+    parser ps;
+    int got;
+    sd_chunk *c;
+    parser_init(&ps, sd_on_record, st);
+    while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
+    parser_eof(&ps);
+    c = st->cur ? st->cur : (sd_chunk *)calloc(1, sizeof *c);
+    st->cur = NULL;
+    c->last = 1;
+    c->end_kind = ps.end_kind;
+    c->end_len = ps.end_len;
+    stream_push(st, c);
+    parser_free(&ps);
+    free(blk);
+    return NULL;
+}
+
+/* SK_E_OPEN if the file cannot be opened (nothing started) */
+static int stream_open(sd_stream *st, const char *path)
+{
+    memset(st, 0, sizeof *st);
+    st->path = path;
+    st->g = gzopen(path, "r");
+    if (!st->g) return SK_E_OPEN;
+    gzbuffer(st->g, 1 << 18);
+    pthread_mutex_init(&st->mu, NULL);
+    pthread_cond_init(&st->cv, NULL);
+    if (pthread_create(&st->th, NULL, sd_decode_thread, st)) { gzclose(st->g); st->g = NULL; return SK_E_NOMEM; }
+    st->started = 1;
+    return SK_OK;
+}
+
+static void stream_close(sd_stream *st)
+{
+    int i;
+    if (!st->g) return;
+    if (st->started) {
+        pthread_mutex_lock(&st->mu);
+        st->cancel = 1;
+        pthread_cond_broadcast(&st->cv);
+        pthread_mutex_unlock(&st->mu);
+        pthread_join(st->th, NULL);
+        pthread_mutex_destroy(&st->mu);
+        pthread_cond_destroy(&st->cv);
+    }
+    for (i = 0; i < st->qn; i++) chunk_free(st->q[i]);
+    chunk_free(st->c);
+    chunk_free(st->cur);
+    gzclose(st->g);
+    memset(st, 0, sizeof *st);
+}
 
 static int hit_cmp(const void *a, const void *b)
 {
@@ -55,203 +191,173 @@ static int hit_cmp(const void *a, const void *b)
     return x->pos < y->pos ? -1 : x->pos > y->pos;
 }
 
-static int sd_flush(sd_file *f)
+/* tally one chunk against every strain: one upload, one launch per strain (they overlap on the device),
+ * then the per-record tallies and per-record lists of informative rows, in window order */
+static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
 {
-    uint32_t *tally;
-    sk_hit *hits = NULL;
-    uint64_t cap = 1u << 20, nh = 0;
-    uint32_t r;
-    size_t h = 0;
-    if (f->bn == 0 || f->rc) { f->blen = 0; f->bn = 0; return f->rc; }
-    tally = (uint32_t *)malloc((size_t)f->bn * 8);
+    uint32_t s, r, k;
+    int rc;
+    c->nstrains = ns;
+    c->hits = (uint32_t **)calloc(ns, sizeof *c->hits);
+    c->inf = (uint32_t **)calloc(ns, sizeof *c->inf);
+    c->hbeg = (uint32_t **)calloc(ns, sizeof *c->hbeg);
+    c->rows = (uint32_t **)calloc(ns, sizeof *c->rows);
+    for (s = 0; s < ns; s++) {
+        c->hits[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
+        c->inf[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
+        c->hbeg[s] = (uint32_t *)calloc((size_t)c->nrec + 2, sizeof(uint32_t));
+    }
+    if (c->np == 0) return SK_OK;
+    if ((rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
+    for (s = 0; s < ns; s++) {
+        if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
+        if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
+    }
+    for (s = 0; s < ns; s++) {
+        uint64_t nh = 0, h = 0;
+        uint32_t *tally, n = 0;
+        if (p[s].tallycap < c->np) {
+            p[s].tallycap = c->np + c->np / 4 + 1024;
+            p[s].tallybuf = (uint32_t *)realloc(p[s].tallybuf, (size_t)p[s].tallycap * 8);
+        }
+        tally = p[s].tallybuf;
+        if ((rc = sk_tally_collect(p[s].ctx, tally, p[s].hitbuf, &nh)) != SK_OK) return rc;
+        if (nh > p[s].hitcap) {                           /* the log overflowed: once more with room */
+            p[s].hitcap = nh + nh / 4;
+            p[s].hitbuf = (sk_hit *)realloc(p[s].hitbuf, (size_t)p[s].hitcap * sizeof(sk_hit));
+            if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
+            if ((rc = sk_tally_collect(p[s].ctx, tally, p[s].hitbuf, &nh)) != SK_OK) return rc;
+        }
+        qsort(p[s].hitbuf, (size_t)nh, sizeof(sk_hit), hit_cmp);
+        c->rows[s] = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
+        for (k = 0, r = 0; k < c->np; k++) {
+            const uint32_t rec = c->prec[k], end = k + 1 < c->np ? c->pstart[k + 1] : 0xFFFFFFFFu;
+            for (; r <= rec; r++) c->hbeg[s][r] = n;      /* records without a piece own an empty range */
+            c->hits[s][rec] = tally[2 * k];
+            c->inf[s][rec] = tally[2 * k + 1];
+            while (h < nh && p[s].hitbuf[h].pos < end) c->rows[s][n++] = p[s].hitbuf[h++].row;
+        }
+        for (; r <= c->nrec; r++) c->hbeg[s][r] = n;
+    }
+    return SK_OK;
+}
+
+/* next record of the stream: 1 = (*chunk, *idx) valid, 0 = end of file (end_kind, end_len set), < 0 device error */
+static int stream_next(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk **chunk, uint32_t *idx)
+{
     for (;;) {
-        hits = (sk_hit *)realloc(hits, (size_t)cap * sizeof *hits);
-        f->rc = sk_tally_batch(f->ctx, f->buf, f->blen, f->bstart, f->bn, SD_TYPE, SD_INFORMATIVE, tally, hits, cap, &nh);
-        if (f->rc || nh <= cap) break;
-        cap = nh;                                        /* the log overflowed: once more with room */
-    }
-    if (!f->rc) {
-        qsort(hits, (size_t)nh, sizeof *hits, hit_cmp);
-        if (f->nh + nh > f->hcap) {
-            f->hcap = (f->nh + nh) * 2 + 1024;
-            f->hit_rows = (uint32_t *)realloc(f->hit_rows, f->hcap * sizeof(uint32_t));
+        sd_chunk *c;
+        int rc, i;
+        if (st->c && st->ci < st->c->nrec) { *chunk = st->c; *idx = st->ci++; return 1; }
+        if (st->eof) return 0;
+        if (st->c) {
+            if (st->c->last) { st->eof = 1; st->end_kind = st->c->end_kind; st->end_len = st->c->end_len; chunk_free(st->c); st->c = NULL; return 0; }
+            chunk_free(st->c);
+            st->c = NULL;
         }
-        for (r = 0; r < f->bn; r++) {
-            sd_rec *rec = &f->rec[f->bindex[r]];
-            const uint32_t end = r + 1 < f->bn ? f->bstart[r + 1] : 0xFFFFFFFFu;
-            if (rec->hits == 0 && rec->inf == 0) rec->hit_begin = f->nh;    /* first piece of this record */
-            rec->hits += tally[2 * r];
-            rec->inf += tally[2 * r + 1];
-            while (h < nh && hits[h].pos < end) f->hit_rows[f->nh++] = hits[h++].row;
-        }
+        pthread_mutex_lock(&st->mu);
+        while (st->qn == 0) pthread_cond_wait(&st->cv, &st->mu);
+        c = st->q[0];
+        for (i = 1; i < st->qn; i++) st->q[i - 1] = st->q[i];
+        st->qn--;
+        pthread_cond_broadcast(&st->cv);
+        pthread_mutex_unlock(&st->mu);
+        if ((rc = sd_tally_chunk(p, ns, batch, c)) != SK_OK) { chunk_free(c); return rc; }
+        st->c = c;
+        st->ci = 0;
     }
-    free(hits);
-    free(tally);
-    f->blen = 0;
-    f->bn = 0;
-    return f->rc;
 }
 
-static void sd_batch_add(sd_file *f, uint64_t index, const char *seq, size_t len)
-{
-    if (f->bn == f->bcap) {
-        f->bcap = f->bcap ? f->bcap * 2 : 1 << 16;
-        f->bstart = (uint32_t *)realloc(f->bstart, (size_t)f->bcap * sizeof(uint32_t));
-        f->bindex = (uint64_t *)realloc(f->bindex, (size_t)f->bcap * sizeof(uint64_t));
-    }
-    f->bstart[f->bn] = (uint32_t)f->blen;
-    f->bindex[f->bn++] = index;
-    memcpy(f->buf + f->blen, seq, len);
-    f->blen += len;
-    f->buf[f->blen++] = '\n';
-}
-
-static int sd_on_record(void *user, char *seq, size_t len)
-{
-    sd_file *f = (sd_file *)user;
-    size_t off = 0;
-    if (f->n == f->cap) {
-        f->cap = f->cap ? f->cap * 2 : 1 << 16;
-        f->rec = (sd_rec *)realloc(f->rec, f->cap * sizeof(sd_rec));
-    }
-    memset(&f->rec[f->n], 0, sizeof(sd_rec));
-    f->rec[f->n].len = len;
-    f->rec[f->n].hit_begin = f->nh;
-    if (len >= SK_K) {
-        while (off < len) {                              /* pieces of at most one batch, k-1 overlap */
-            size_t room, take;
-            if (SD_BATCH_BYTES - f->blen < 4096 && sd_flush(f)) return f->rc;
-            room = SD_BATCH_BYTES - f->blen - 1;
-            take = len - off < room ? len - off : room;
-            sd_batch_add(f, f->n, seq + off, take);
-            off += take;
-            if (off < len) { off -= SK_OVERLAP; if (sd_flush(f)) return f->rc; }
-        }
-    }
-    f->n++;
-    return 0;
-}
-
-static void sd_file_free(sd_file *f)
-{
-    free(f->rec); free(f->hit_rows); free(f->buf); free(f->bstart); free(f->bindex);
-    memset(f, 0, sizeof *f);
-}
-
-/* decode + tally a whole file; SK_E_OPEN if it cannot be opened */
-static int sd_file_load(sk_ctx *ctx, const char *path, sd_file *f)
-{
-    enum { BLK = 1 << 20 };
-    gzFile g;
-    unsigned char *blk;
-    parser ps;
-    int got;
-    memset(f, 0, sizeof *f);
-    g = gzopen(path, "r");
-    if (!g) return SK_E_OPEN;
-    gzbuffer(g, 1 << 18);
-    f->ctx = ctx;
-    f->buf = (uint8_t *)malloc(SD_BATCH_BYTES);
-    blk = (unsigned char *)malloc(BLK);
-    parser_init(&ps, sd_on_record, f);
-    while (ps.state != P_STOP && (got = gzread(g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
-    parser_eof(&ps);
-    f->end_kind = ps.end_kind;
-    f->end_len = ps.end_len;
-    if (!f->rc) sd_flush(f);
-    parser_free(&ps);
-    free(blk);
-    gzclose(g);
-    return f->rc;
-}
-
-/* ---------------------------------------------------------------------------------------------
- * program state
- * ------------------------------------------------------------------------------------------- */
-typedef struct {
-    sk_ctx     *ctx;
-    skh_keyset  ks;
-    uint32_t   *type;          /* host copy of the type column */
-    FILE       *out, *err;
-} sd_prog;
-
-static void emit_hits(sd_prog *p, gzFile gz, const sd_file *f, const sd_rec *rec, const char *name,
-                      int h1, int i1, int h2, int i2)
+static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *name)
 {
     uint32_t j;
     char key[32];
-    for (j = 0; j < rec->inf; j++) {
-        skh_keyset_key(&p->ks, f->hit_rows[rec->hit_begin + j], key);
-        gzprintf(gz, "%s\t%d\t%d\t%d\t%d\t%s\n", name, h1, i1, h2, i2, key);
+    for (j = 0; j < n; j++) {
+        skh_keyset_key(&p->ks, rows[j], key);
+        gzprintf(p->gz, "%s\t%d\t%d\t%d\t%d\t%s\n", name, p->h1, p->i1, p->h2, p->i2, key);
     }
 }
 
 /* one metagenome (pair): the reference's read loop, src/strain_detect.c:443-626, replayed over the
- * device tallies.  A read shorter than k refreshes nothing, so it re-uses (and may re-emit) the
- * previous read's tallies and sequence -- as the reference does. */
-static int sd_quantify(sd_prog *p, gzFile gz, const char *f1, const char *f2, int mode,
-                       unsigned genome_kmers, unsigned genome_inf)
+ * device tallies, for every strain at once (the read lengths, hence the bookkeeping of which read
+ * refreshes what, are the same for all of them).  A read shorter than k refreshes nothing, so it
+ * re-uses (and may re-emit) the previous read's tallies and sequence -- as the reference does. */
+static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, const char *f1, const char *f2, int mode)
 {
-    sd_file A, B, *pb = NULL;
-    size_t ia = 0, ib = 0, *cursor_b;
-    const sd_rec *copy = NULL, *cur_b = NULL;
-    int h1 = 0, i1 = 0, h2 = 0, i2 = 0, rc;
+    sd_stream A, B, *pb;
+    sd_chunk *ca = NULL, *cb = NULL;
+    uint32_t ra = 0, rb = 0, s;
+    int have_copy = 0, rc, got, status = 1;
     unsigned long long evaluated = 0, reads = 0;
+    FILE *err = p[0].err;
 
-    rc = sd_file_load(p->ctx, f1, &A);
-    if (rc == SK_E_OPEN) { fprintf(p->err, "could not read file (read1) %s in quantify_hits_PE() (error: %s)\n", f1, strerror(errno)); return 1; }
-    if (rc) { fprintf(p->err, "strain_detect: device error on %s: %s (%s)\n", f1, sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
     memset(&B, 0, sizeof B);
+    rc = stream_open(&A, f1);
+    if (rc == SK_E_OPEN) { fprintf(err, "could not read file (read1) %s in quantify_hits_PE() (error: %s)\n", f1, strerror(errno)); return 1; }
+    if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f1); return 1; }
     if (mode == SD_PE) {
-        rc = sd_file_load(p->ctx, f2, &B);
-        if (rc == SK_E_OPEN) { fprintf(p->err, "could not read file (read2) is_PE %s in quantify_hits_PE() (error: (null))\n", f2); sd_file_free(&A); return 1; }
-        if (rc) { fprintf(p->err, "strain_detect: device error on %s: %s (%s)\n", f2, sk_strerror(rc), sk_last_error(p->ctx)); sd_file_free(&A); return 1; }
+        rc = stream_open(&B, f2);
+        if (rc == SK_E_OPEN) { fprintf(err, "could not read file (read2) is_PE %s in quantify_hits_PE() (error: (null))\n", f2); stream_close(&A); return 1; }
+        if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f2); stream_close(&A); return 1; }
         pb = &B;
-        cursor_b = &ib;
-    } else {
-        pb = &A;                                         /* PEI: the mate is the next record of the same file */
-        cursor_b = &ia;
-    }
+    } else pb = &A;                                      /* PEI: the mate is the next record of the same file */
+    for (s = 0; s < ns; s++) { p[s].h1 = p[s].i1 = p[s].h2 = p[s].i2 = 0; p[s].copy_n = 0; }
 
-    while (ia < A.n) {
-        const sd_rec *a = &A.rec[ia++];
-        if (a->len >= SK_K) {
+    while ((got = stream_next(&A, p, ns, batch, &ca, &ra)) == 1) {
+        const uint64_t la = ca->len[ra];
+        uint64_t len2 = 0;
+        int b_valid = 0;
+        if (la >= SK_K) {
             reads++;
-            h1 = (int)a->hits;
-            i1 = (int)a->inf;
-            copy = a;
-            evaluated += a->len - (SK_K - 1);
-        }
-        if (mode != SD_SE) {
-            uint64_t len2;
-            int failed = 0;
-            if (*cursor_b < pb->n) { cur_b = &pb->rec[(*cursor_b)++]; len2 = cur_b->len; }
-            else { cur_b = NULL; failed = 1; len2 = pb->end_kind == SKP_END_RESET ? 0 : pb->end_len; }
-            if (len2 >= SK_K) {
-                h2 = i2 = 0;
-                if (failed) {
-                    fprintf(p->err, "reached end of PE2 (%s) before end of PE1 (%s), check that file names are correct\n",
-                            f2 ? f2 : "(null)", f1);
-                    sd_file_free(&A); sd_file_free(&B);
-                    return 1;
-                }
-                h2 = (int)cur_b->hits;
-                i2 = (int)cur_b->inf;
-                evaluated += cur_b->len - (SK_K - 1);
+            evaluated += la - (SK_K - 1);
+            have_copy = 1;
+            for (s = 0; s < ns; s++) {
+                const uint32_t n = ca->hbeg[s][ra + 1] - ca->hbeg[s][ra];
+                p[s].h1 = (int)ca->hits[s][ra];
+                p[s].i1 = (int)ca->inf[s][ra];
+                if (n > p[s].copy_cap) { p[s].copy_cap = n * 2 + 16; p[s].copy_rows = (uint32_t *)realloc(p[s].copy_rows, (size_t)p[s].copy_cap * 4); }
+                if (n) memcpy(p[s].copy_rows, ca->rows[s] + ca->hbeg[s][ra], (size_t)n * 4);
+                p[s].copy_n = n;
             }
         }
-        if (h1 + h2 >= 1 && i1 + i2 >= 1) {
-            if (copy) emit_hits(p, gz, &A, copy, f1, h1, i1, h2, i2);
-            if (mode != SD_SE && cur_b && cur_b->len >= SK_K) emit_hits(p, gz, pb, cur_b, f1, h1, i1, h2, i2);
+        if (mode != SD_SE) {
+            int failed = 0;
+            got = stream_next(pb, p, ns, batch, &cb, &rb);
+            if (got < 0) break;
+            if (got == 1) len2 = cb->len[rb];
+            else { failed = 1; len2 = pb->end_kind == SKP_END_RESET ? 0 : pb->end_len; }
+            if (len2 >= SK_K) {
+                if (failed) {
+                    fprintf(err, "reached end of PE2 (%s) before end of PE1 (%s), check that file names are correct\n",
+                            f2 ? f2 : "(null)", f1);
+                    goto done;
+                }
+                b_valid = 1;
+                for (s = 0; s < ns; s++) { p[s].h2 = (int)cb->hits[s][rb]; p[s].i2 = (int)cb->inf[s][rb]; }
+                evaluated += len2 - (SK_K - 1);
+            }
         }
+        for (s = 0; s < ns; s++)
+            if (p[s].h1 + p[s].h2 >= 1 && p[s].i1 + p[s].i2 >= 1) {
+                if (have_copy) emit_rows(&p[s], p[s].copy_rows, p[s].copy_n, f1);
+                if (b_valid) emit_rows(&p[s], cb->rows[s] + cb->hbeg[s][rb], cb->hbeg[s][rb + 1] - cb->hbeg[s][rb], f1);
+            }
     }
-    gzprintf(gz, "#%s\ttotal_kmer_evaluated\t%lld\n", f1, evaluated);
-    gzprintf(gz, "#%s\ttotal_reads_evaluated\t%lld\n", f1, reads);
-    gzprintf(gz, "#%s\ttotal_genome_kmers\t%lld\n", f1, (long long)genome_kmers);
-    gzprintf(gz, "#%s\ttotal_genome_informative_kmers\t%lld\n", f1, (long long)genome_inf);
-    sd_file_free(&A);
-    sd_file_free(&B);
-    return 0;
+    if (got < 0) {
+        fprintf(err, "strain_detect: device error on %s: %s (%s)\n", f1, sk_strerror(got), sk_last_error(p[0].ctx));
+        goto done;
+    }
+    for (s = 0; s < ns; s++) {
+        gzprintf(p[s].gz, "#%s\ttotal_kmer_evaluated\t%lld\n", f1, evaluated);
+        gzprintf(p[s].gz, "#%s\ttotal_reads_evaluated\t%lld\n", f1, reads);
+        gzprintf(p[s].gz, "#%s\ttotal_genome_kmers\t%lld\n", f1, (long long)p[s].ks.nrows);
+        gzprintf(p[s].gz, "#%s\ttotal_genome_informative_kmers\t%lld\n", f1, (long long)p[s].genome_inf);
+    }
+    status = 0;
+done:
+    stream_close(&A);
+    stream_close(&B);
+    return status;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -392,17 +498,86 @@ static void usage(FILE *err)
     fputs("\ninformative kmer file is a list of all of the kmers left in the reference genome post scrubbing\n", err);
 }
 
+/* build one strain's state: key set, table on the device, -a flags, optional -g filter, -o file */
+static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *g, const char *o, int device, FILE *out, FILE *err)
+{
+    unsigned n_inform = 0, i;
+    int rc;
+    memset(p, 0, sizeof *p);
+    p->out = out;
+    p->err = err;
+    rc = skh_keyset_from_file(&p->ks, r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0);
+    if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", r); return 1; }
+    if (rc != SK_OK) { fprintf(err, "strain_detect: %s\n", sk_strerror(rc)); return 1; }
+    if (p->ks.short_records)
+        fprintf(err, "strain_detect: skipped %llu reference record(s) shorter than %d bases "
+                     "(the original program crashes on these)\n", (unsigned long long)p->ks.short_records, SK_K - 1);
+    rc = sk_ctx_create(&p->ctx, device);
+    if (rc != SK_OK) { fprintf(err, "strain_detect: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); return 1; }
+    rc = skh_keyset_load(p->ctx, &p->ks, SD_NCOLS);
+    if (rc != SK_OK) { fprintf(err, "strain_detect: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
+    p->type = (uint32_t *)malloc((size_t)(p->ks.nrows ? p->ks.nrows : 1) * sizeof(uint32_t));
+    for (i = 0; i < p->ks.nrows; i++) p->type[i] = SD_PLAIN;
+    if (sd_flag_informative(p, a, &n_inform)) return 1;
+    if (g && sd_background_filter(p, g, 0.5, n_inform)) return 1;
+    for (i = 0; i < p->ks.nrows; i++) if (p->type[i] == SD_INFORMATIVE) p->genome_inf++;
+    p->gz = gzopen(o, "wb9");
+    if (!p->gz) { fprintf(err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
+    return 0;
+}
+
+static void sd_strain_close(sd_prog *p)
+{
+    if (p->gz) gzclose(p->gz);
+    if (p->ctx) sk_ctx_destroy(p->ctx);
+    skh_keyset_free(&p->ks);
+    free(p->type); free(p->copy_rows); free(p->hitbuf); free(p->tallybuf);
+    memset(p, 0, sizeof *p);
+}
+
+/* the metagenome side of main (src/strain_detect.c:263-384), for ns strains at once */
+static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const char *b2, int mode, FILE *out, FILE *err)
+{
+    sk_batch *batch = NULL;
+    int bad = 0, rc;
+    if ((rc = sk_batch_create(p[0].ctx, &batch)) != SK_OK) {
+        fprintf(err, "strain_detect: %s (%s)\n", sk_strerror(rc), sk_last_error(p[0].ctx));
+        return 1;
+    }
+    if (B) {
+        FILE *fp = fopen(B, "r");
+        char *line = NULL, *nl, *tok, *f1, *f2;
+        size_t cap = 0;
+        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); sk_batch_destroy(batch); return 1; }
+        while (!bad && getline(&line, &cap, fp) != -1) {
+            int m;
+            if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
+            tok = strtok(line, "\t");
+            if (!tok) { fprintf(err, "strain_detect: empty line in %s (the original program crashes here)\n", B); bad = 1; break; }
+            m = file_type(tok);
+            if (m == SD_UNKNOWN) { fprintf(out, "unknown file type skipping line (%s)\n", tok); continue; }
+            f1 = strtok(NULL, "\t");
+            if (!f1) { fprintf(out, "ERROR: no first file specified for %s\n", line); continue; }
+            if (m == SD_PE) {
+                f2 = strtok(NULL, "\t");
+                if (!f2) { fprintf(out, "ERROR: no second file specified for PE: %s\n", line); continue; }
+                bad = sd_quantify(p, ns, batch, f1, f2, m);
+            } else bad = sd_quantify(p, ns, batch, f1, NULL, m);
+        }
+        free(line);
+        fclose(fp);
+    } else bad = sd_quantify(p, ns, batch, b, b2, mode);
+    sk_batch_destroy(batch);
+    return bad;
+}
+
 int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
 {
-    const char *a = NULL, *r = NULL, *b = NULL, *b2 = NULL, *B = NULL, *tt = NULL, *g = NULL, *o = NULL, *env;
-    int c, mode = SD_SE, rc, status = 1, device = 0;
-    unsigned n_inform = 0, i, genome_inf = 0;
-    sd_prog p;
-    gzFile gz = NULL;
+    const char *a = NULL, *r = NULL, *b = NULL, *b2 = NULL, *B = NULL, *tt = NULL, *g = NULL, *o = NULL, *S = NULL, *env;
+    int c, mode = SD_SE, status = 1, device = 0, n_S = 0;
+    sd_prog *p = NULL;
+    uint32_t ns = 0, s;
 
-    memset(&p, 0, sizeof p);
-    p.out = out;
-    p.err = err;
     optind = 1;
     while ((c = getopt(argc, argv, "g:r:a:A:b:c:B:S:M:o:t:Hhuspn")) != -1) {
         switch (c) {
@@ -416,11 +591,22 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
         case 'o': o = optarg; break;
         case 'n': mode = SD_SE; break;
         case 't': tt = optarg; break;
+        case 'S': S = optarg; n_S++; break;              /* the reference prints its usage for -S and carries on; see below */
         default:  usage(err); break;
         }
     }
-    if (!a || !o || !r) { usage(err); return 1; }
-    if (!b && !B) { usage(err); return 1; }
+    /* Extension: "-S <file>" with NO -r/-a/-o runs several strains in one pass over the metagenomes.  Each
+     * line of the file is  <reference genome> TAB <informative k-mer file> TAB <outfile> [TAB <-g list>];
+     * every outfile gets exactly what a separate run with that line's -r/-a/-o[/-g] would write.  All
+     * tables stay resident on the device; each metagenome is decoded and uploaded once. */
+    if (S && !a && !o && !r) {
+        if (!b && !B) { usage(err); return 1; }
+    } else {
+        S = NULL;
+        while (n_S-- > 0) usage(err);
+        if (!a || !o || !r) { usage(err); return 1; }
+        if (!b && !B) { usage(err); return 1; }
+    }
     if (tt) {
         mode = file_type(tt);
         if (mode == SD_UNKNOWN) { fputs("unknown filetype specification. allowed are SE, PE, PEI\n\n", out); usage(err); return 1; }
@@ -435,55 +621,37 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
     }
     if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
 
-    rc = skh_keyset_from_file(&p.ks, r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0);
-    if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", r); goto done; }
-    if (rc != SK_OK) { fprintf(err, "strain_detect: %s\n", sk_strerror(rc)); goto done; }
-    if (p.ks.short_records)
-        fprintf(err, "strain_detect: skipped %llu reference record(s) shorter than %d bases "
-                     "(the original program crashes on these)\n", (unsigned long long)p.ks.short_records, SK_K - 1);
-    rc = sk_ctx_create(&p.ctx, device);
-    if (rc != SK_OK) { fprintf(err, "strain_detect: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); goto done; }
-    rc = skh_keyset_load(p.ctx, &p.ks, SD_NCOLS);
-    if (rc != SK_OK) { fprintf(err, "strain_detect: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(p.ctx)); goto done; }
-    p.type = (uint32_t *)malloc((size_t)(p.ks.nrows ? p.ks.nrows : 1) * sizeof(uint32_t));
-    for (i = 0; i < p.ks.nrows; i++) p.type[i] = SD_PLAIN;
-
-    if (sd_flag_informative(&p, a, &n_inform)) goto done;
-    if (g && sd_background_filter(&p, g, 0.5, n_inform)) goto done;
-    for (i = 0; i < p.ks.nrows; i++) if (p.type[i] == SD_INFORMATIVE) genome_inf++;
-
-    gz = gzopen(o, "wb9");
-    if (!gz) { fprintf(err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); goto done; }
-    if (B) {
-        FILE *fp = fopen(B, "r");
-        char *line = NULL, *nl, *tok, *f1, *f2;
+    if (S) {
+        FILE *fp = fopen(S, "r");
+        char *line = NULL;
         size_t cap = 0;
-        int bad = 0;
-        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); goto done; }
-        while (!bad && getline(&line, &cap, fp) != -1) {
-            int m;
+        const int world = getenv("SK_WORLD_SIZE") ? atoi(getenv("SK_WORLD_SIZE")) : (getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1);
+        const int rank = getenv("SK_RANK") ? atoi(getenv("SK_RANK")) : (getenv("RANK") ? atoi(getenv("RANK")) : 0);
+        unsigned lineno = 0;
+        if (!fp) { fprintf(err, "strain_detect: could not read the strain list %s\n", S); return 1; }
+        if (!getenv("SK_DEVICE") && (env = getenv("SK_LOCAL_RANK") ? getenv("SK_LOCAL_RANK") : getenv("LOCAL_RANK")) != NULL) device = atoi(env);
+        while (getline(&line, &cap, fp) != -1) {
+            char *nl, *fr, *fa, *fo, *fg;
             if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
-            tok = strtok(line, "\t");
-            if (!tok) { fprintf(err, "strain_detect: empty line in %s (the original program crashes here)\n", B); bad = 1; break; }
-            m = file_type(tok);
-            if (m == SD_UNKNOWN) { fprintf(out, "unknown file type skipping line (%s)\n", tok); continue; }
-            f1 = strtok(NULL, "\t");
-            if (!f1) { fprintf(out, "ERROR: no first file specified for %s\n", line); continue; }
-            if (m == SD_PE) {
-                f2 = strtok(NULL, "\t");
-                if (!f2) { fprintf(out, "ERROR: no second file specified for PE: %s\n", line); continue; }
-                bad = sd_quantify(&p, gz, f1, f2, m, p.ks.nrows, genome_inf);
-            } else bad = sd_quantify(&p, gz, f1, NULL, m, p.ks.nrows, genome_inf);
+            if (line[0] == '#' || line[0] == '\0') continue;
+            if (world > 1 && (int)(lineno++ % (unsigned)world) != rank) continue;     /* strains are dealt to the ranks; no collective */
+            fr = strtok(line, "\t"); fa = strtok(NULL, "\t"); fo = strtok(NULL, "\t"); fg = strtok(NULL, "\t");
+            if (!fr || !fa || !fo) { fprintf(err, "strain_detect: %s: a line needs <genome> TAB <informative k-mers> TAB <outfile>\n", S); free(line); fclose(fp); goto done; }
+            p = (sd_prog *)realloc(p, ((size_t)ns + 1) * sizeof *p);
+            if (sd_strain_open(&p[ns++], fr, fa, fg, fo, device, out, err)) { free(line); fclose(fp); goto done; }
         }
         free(line);
         fclose(fp);
-        if (bad) goto done;
-    } else if (sd_quantify(&p, gz, b, b2, mode, p.ks.nrows, genome_inf)) goto done;
+        if (ns == 0) { status = 0; goto done; }          /* nothing dealt to this rank */
+    } else {
+        p = (sd_prog *)malloc(sizeof *p);
+        ns = 1;
+        if (sd_strain_open(&p[0], r, a, g, o, device, out, err)) goto done;
+    }
+    if (sd_run(p, ns, B, b, b2, mode, out, err)) goto done;
     status = 0;
 done:
-    if (gz) gzclose(gz);
-    if (p.ctx) sk_ctx_destroy(p.ctx);
-    skh_keyset_free(&p.ks);
-    free(p.type);
+    for (s = 0; s < ns; s++) sd_strain_close(&p[s]);
+    free(p);
     return status;
 }

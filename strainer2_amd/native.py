@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
     "sk_distinct_count", "skh_coverage_depth_main",
+    "sk_batch_create", "sk_batch_destroy", "sk_batch_fill", "sk_tally_launch", "sk_tally_collect",
 ]
 
 
@@ -130,6 +131,13 @@ lib.skh_scrub_filter_resident.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), 
 
 lib.sk_distinct_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
 lib.skh_coverage_depth_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
+
+lib.sk_batch_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+lib.sk_batch_destroy.argtypes = [C.c_void_p]
+lib.sk_batch_destroy.restype = None
+lib.sk_batch_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+lib.sk_tally_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+lib.sk_tally_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
 
 _libc = C.CDLL(None)
 _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]

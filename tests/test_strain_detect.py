@@ -128,3 +128,90 @@ def test_tally_batch_vs_python_count():
                 n += c in inf_keys
         assert (int(tally[i, 0]), int(tally[i, 1])) == (h, n), i
     assert len(hits) == int(tally[:, 1].sum()) > 0
+
+
+def _canon(k):
+    r = _synth.revcomp(k)
+    return k if k >= r else r
+
+
+def _make_multi_inputs(tmp_path, nstrains=3, strain_len=60_000, nreads=320_000):
+    """nstrains synthetic strains with their informative lists, and a -B list with an SE (.gz), a PE pair and
+    an interleaved file whose decoded size spans more than one 32 MiB chunk; short reads mixed in."""
+    rng = random.Random(4242)
+    strains = [_synth.rand_dna(rng, strain_len) for _ in range(nstrains)]
+    lines = []
+    for s, g in enumerate(strains):
+        (tmp_path / f"s{s}.fa").write_bytes(b">s%d\n" % s + g + b"\n")
+        kms = sorted({_canon(g[i:i + 31]) for i in range(0, strain_len - 31, 17)})
+        with gzip.open(tmp_path / f"s{s}.inf.gz", "wb") as f:
+            f.write(b"#informative\n" + b"\n".join(kms) + b"\n")
+        lines.append(f"{tmp_path}/s{s}.fa\t{tmp_path}/s{s}.inf.gz\t{tmp_path}/multi{s}.gz\n")
+    (tmp_path / "strains.txt").write_text("# genome\tinformative\tout\n" + "".join(lines))
+
+    def reads(n, seed):
+        r = random.Random(seed)
+        out = []
+        for i in range(n):
+            if r.random() < 0.03:
+                g = strains[r.randrange(nstrains)]
+                a = r.randrange(0, strain_len - 150)
+                rd = g[a:a + 150]
+                if r.random() < 0.5:
+                    rd = _synth.revcomp(rd)
+            else:
+                rd = _synth.rand_dna(r, 150)
+            if r.random() < 0.01:
+                rd = rd[:r.randrange(0, 31)]                  # shorter than k: inherits the previous read's tallies
+            out.append(rd)
+        return out
+
+    def fasta(rs):
+        return b"".join(b">r%d\n%s\n" % (i, x) for i, x in enumerate(rs))
+
+    with gzip.open(tmp_path / "se.fa.gz", "wb", compresslevel=1) as f:
+        f.write(fasta(reads(nreads, 1)))
+    (tmp_path / "pe_1.fa").write_bytes(fasta(reads(60_000, 2)))
+    (tmp_path / "pe_2.fa").write_bytes(fasta(reads(60_000, 3)))
+    (tmp_path / "il.fa").write_bytes(fasta(reads(50_001, 4)))          # odd count: the last mate is missing
+    (tmp_path / "B.txt").write_text(f"SE\t{tmp_path}/se.fa.gz\n#comment\nPE\t{tmp_path}/pe_1.fa\t{tmp_path}/pe_2.fa\n"
+                                    f"XX\tnope\nPEI\t{tmp_path}/il.fa\n")
+    return nstrains
+
+
+@pytest.mark.gpu
+def test_sd_many_strains_in_one_pass_equal_separate_runs(tmp_path):
+    """-S <list>: every strain's output is byte-identical (decompressed) to a separate run with its -r/-a/-o,
+    and one of the separate runs is checked against the oracle."""
+    n = _make_multi_inputs(tmp_path)
+    exe = sk.cli_path("strain_detect")
+    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt")], capture_output=True)
+    assert multi.returncode == 0, multi.stderr.decode()[-500:]
+    assert multi.stdout == b"unknown file type skipping line (#comment)\nunknown file type skipping line (XX)\n"
+    for s in range(n):
+        one = subprocess.run([exe, "-r", str(tmp_path / f"s{s}.fa"), "-a", str(tmp_path / f"s{s}.inf.gz"), "-B", str(tmp_path / "B.txt"),
+                              "-o", str(tmp_path / f"single{s}.gz")], capture_output=True)
+        assert one.returncode == 0 and one.stdout == multi.stdout
+        a = gzip.open(tmp_path / f"single{s}.gz", "rb").read()
+        b = gzip.open(tmp_path / f"multi{s}.gz", "rb").read()
+        assert a == b and a.count(b"\n") > 1000
+    ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / "s1.fa"), "-a", str(tmp_path / "s1.inf.gz"), "-B", str(tmp_path / "B.txt"),
+                                     "-o", str(tmp_path / "oracle1.gz")], str(tmp_path))
+    assert ora.returncode == 0
+    assert gzip.open(tmp_path / "oracle1.gz", "rb").read() == gzip.open(tmp_path / "multi1.gz", "rb").read()
+
+
+@pytest.mark.gpu
+def test_sd_many_strains_golden_strain_plus_another(golden, tmp_path):
+    """two different strains against the `batch` golden's metagenome list: the golden strain's file equals the
+    reference's output, the other equals its own separate run."""
+    d = os.path.join(golden, "sd_cases", "batch")
+    other = os.path.join(golden, "sd_cases", "background")
+    (tmp_path / "strains.txt").write_text(f"strain.fa\tinf.txt.gz\t{tmp_path}/a.gz\n{other}/strain.fa\t{other}/inf.txt\t{tmp_path}/b.gz\n")
+    exe = sk.cli_path("strain_detect")
+    p = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", "B.txt"], cwd=d, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    assert gzip.open(tmp_path / "a.gz", "rb").read() == open(os.path.join(d, "expected.hits"), "rb").read()
+    q = subprocess.run([exe, "-r", f"{other}/strain.fa", "-a", f"{other}/inf.txt", "-B", "B.txt", "-o", str(tmp_path / "b1.gz")], cwd=d, capture_output=True)
+    assert q.returncode == 0
+    assert gzip.open(tmp_path / "b.gz", "rb").read() == gzip.open(tmp_path / "b1.gz", "rb").read()
