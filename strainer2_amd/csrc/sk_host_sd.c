@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -185,6 +186,10 @@ static void stream_close(sd_stream *st)
     memset(st, 0, sizeof *st);
 }
 
+/* SK_SD_TIMING=1: where the wall clock went, on stderr at exit */
+static double t_wait, t_tally, t_setup;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
 static int hit_cmp(const void *a, const void *b)
 {
     const sk_hit *x = (const sk_hit *)a, *y = (const sk_hit *)b;
@@ -242,30 +247,49 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
     return SK_OK;
 }
 
-/* next record of the stream: 1 = (*chunk, *idx) valid, 0 = end of file (end_kind, end_len set), < 0 device error */
-static int stream_next(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk **chunk, uint32_t *idx)
+/* make sure the stream's current chunk has an unread record: 1 = st->c->...[st->ci] is it, 0 = end of
+ * file (end_kind, end_len set), < 0 device error */
+static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch)
 {
     for (;;) {
         sd_chunk *c;
         int rc, i;
-        if (st->c && st->ci < st->c->nrec) { *chunk = st->c; *idx = st->ci++; return 1; }
+        if (st->c && st->ci < st->c->nrec) return 1;
         if (st->eof) return 0;
         if (st->c) {
             if (st->c->last) { st->eof = 1; st->end_kind = st->c->end_kind; st->end_len = st->c->end_len; chunk_free(st->c); st->c = NULL; return 0; }
             chunk_free(st->c);
             st->c = NULL;
         }
-        pthread_mutex_lock(&st->mu);
-        while (st->qn == 0) pthread_cond_wait(&st->cv, &st->mu);
+        {
+            const double t0 = now_s();
+            pthread_mutex_lock(&st->mu);
+            while (st->qn == 0) pthread_cond_wait(&st->cv, &st->mu);
+            t_wait += now_s() - t0;
+        }
         c = st->q[0];
         for (i = 1; i < st->qn; i++) st->q[i - 1] = st->q[i];
         st->qn--;
         pthread_cond_broadcast(&st->cv);
         pthread_mutex_unlock(&st->mu);
-        if ((rc = sd_tally_chunk(p, ns, batch, c)) != SK_OK) { chunk_free(c); return rc; }
+        {
+            const double t0 = now_s();
+            rc = sd_tally_chunk(p, ns, batch, c);
+            t_tally += now_s() - t0;
+        }
+        if (rc != SK_OK) { chunk_free(c); return rc; }
         st->c = c;
         st->ci = 0;
     }
+}
+
+/* take the current, fully read chunk away from the stream so that it survives the next stream_fill */
+static sd_chunk *stream_steal(sd_stream *st)
+{
+    sd_chunk *c = st->c;
+    if (c->last) { st->eof = 1; st->end_kind = c->end_kind; st->end_len = c->end_len; }
+    st->c = NULL;
+    return c;
 }
 
 static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *name)
@@ -278,15 +302,140 @@ static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *
     }
 }
 
-/* one metagenome (pair): the reference's read loop, src/strain_detect.c:443-626, replayed over the
- * device tallies, for every strain at once (the read lengths, hence the bookkeeping of which read
- * refreshes what, are the same for all of them).  A read shorter than k refreshes nothing, so it
- * re-uses (and may re-emit) the previous read's tallies and sequence -- as the reference does. */
-static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, const char *f1, const char *f2, int mode)
+/* One strain over a run of n read pairs whose records sit in the current chunks: PE1 reads are records
+ * a0, a0 + astep, ... of chunk ca; their mates (cb != NULL) records b0, b0 + astep, ... of chunk cb.
+ * This is the body of the reference's read loop (src/strain_detect.c:443-626) for that strain. */
+static void sd_replay_run(sd_prog *p, uint32_t s, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb, uint32_t b0,
+                          uint32_t astep, uint32_t n, int *have_copy_io)
 {
-    sd_stream A, B, *pb;
-    sd_chunk *ca = NULL, *cb = NULL;
-    uint32_t ra = 0, rb = 0, s;
+    const uint32_t *ah = ca->hits[s], *ai = ca->inf[s], *ab = ca->hbeg[s];
+    const uint32_t *bh = cb ? cb->hits[s] : NULL, *bi = cb ? cb->inf[s] : NULL, *bb = cb ? cb->hbeg[s] : NULL;
+    int have_copy = *have_copy_io;
+    uint32_t j;
+    for (j = 0; j < n; j++) {
+        const uint32_t ra = a0 + j * astep, rb = b0 + j * astep;
+        int b_valid = 0;
+        if (ca->len[ra] >= SK_K) {                       /* a read shorter than k refreshes nothing (:444) */
+            const uint32_t nrows = ab[ra + 1] - ab[ra];
+            p->h1 = (int)ah[ra];
+            p->i1 = (int)ai[ra];
+            have_copy = 1;
+            if (nrows) {
+                if (nrows > p->copy_cap) { p->copy_cap = nrows * 2 + 16; p->copy_rows = (uint32_t *)realloc(p->copy_rows, (size_t)p->copy_cap * 4); }
+                memcpy(p->copy_rows, ca->rows[s] + ab[ra], (size_t)nrows * 4);
+            }
+            p->copy_n = nrows;
+        }
+        if (cb && cb->len[rb] >= SK_K) { p->h2 = (int)bh[rb]; p->i2 = (int)bi[rb]; b_valid = 1; }
+        if (p->h1 + p->h2 >= 1 && p->i1 + p->i2 >= 1) {
+            if (have_copy) emit_rows(p, p->copy_rows, p->copy_n, f1);
+            if (b_valid) emit_rows(p, cb->rows[s] + bb[rb], bb[rb + 1] - bb[rb], f1);
+        }
+    }
+    *have_copy_io = have_copy;
+}
+
+/* The strains are independent once a run's tallies are in: with several strains, sd_replay_run (and with
+ * it the gz compression of each strain's own output) is spread over a few threads, strain by strain. */
+typedef struct {
+    pthread_t th[16]; int nth;
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+    unsigned long gen; int quit;
+    sd_prog *p; uint32_t ns; const char *f1; const sd_chunk *ca, *cb; uint32_t a0, b0, astep, n; int have_copy_in, have_copy_out;
+    uint32_t next, done;
+} sd_pool;
+
+static void pool_drain(sd_pool *pl)
+{
+    uint32_t mine = 0;
+    int hc = pl->have_copy_in;
+    for (;;) {
+        const uint32_t s = __atomic_fetch_add(&pl->next, 1u, __ATOMIC_ACQ_REL);   /* pairs with the release store that opens a job */
+        if (s >= pl->ns) break;
+        hc = pl->have_copy_in;
+        sd_replay_run(&pl->p[s], s, pl->f1, pl->ca, pl->a0, pl->cb, pl->b0, pl->astep, pl->n, &hc);
+        mine++;
+    }
+    pthread_mutex_lock(&pl->mu);
+    if (mine) pl->have_copy_out = hc;
+    pl->done += mine;
+    if (pl->done == pl->ns) pthread_cond_broadcast(&pl->cv_done);
+    pthread_mutex_unlock(&pl->mu);
+}
+
+static void *pool_worker_sd(void *arg)
+{
+    sd_pool *pl = (sd_pool *)arg;
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&pl->mu);
+        while (pl->gen == seen && !pl->quit) pthread_cond_wait(&pl->cv_work, &pl->mu);
+        if (pl->quit) { pthread_mutex_unlock(&pl->mu); return NULL; }
+        seen = pl->gen;
+        pthread_mutex_unlock(&pl->mu);
+        pool_drain(pl);
+    }
+}
+
+static void pool_start(sd_pool *pl, uint32_t ns)
+{
+    int want = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : 8, i;
+    memset(pl, 0, sizeof *pl);
+    if (want > 16) want = 16;
+    if ((uint32_t)want > ns) want = (int)ns;
+    pthread_mutex_init(&pl->mu, NULL);
+    pthread_cond_init(&pl->cv_work, NULL);
+    pthread_cond_init(&pl->cv_done, NULL);
+    for (i = 0; i + 1 < want; i++)                       /* the calling thread is one of the workers */
+        if (pthread_create(&pl->th[pl->nth], NULL, pool_worker_sd, pl) == 0) pl->nth++;
+}
+
+static void pool_stop(sd_pool *pl)
+{
+    int i;
+    pthread_mutex_lock(&pl->mu);
+    pl->quit = 1;
+    pthread_cond_broadcast(&pl->cv_work);
+    pthread_mutex_unlock(&pl->mu);
+    for (i = 0; i < pl->nth; i++) pthread_join(pl->th[i], NULL);
+    pthread_mutex_destroy(&pl->mu);
+    pthread_cond_destroy(&pl->cv_work);
+    pthread_cond_destroy(&pl->cv_done);
+}
+
+/* replay one run for every strain; returns the (strain-independent) have_copy afterwards */
+static int pool_replay(sd_pool *pl, sd_prog *p, uint32_t ns, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb,
+                       uint32_t b0, uint32_t astep, uint32_t n, int have_copy)
+{
+    if (pl->nth == 0 || n < 64) {
+        uint32_t s;
+        int hc = have_copy;
+        for (s = 0; s < ns; s++) { hc = have_copy; sd_replay_run(&p[s], s, f1, ca, a0, cb, b0, astep, n, &hc); }
+        return hc;
+    }
+    pthread_mutex_lock(&pl->mu);
+    pl->p = p; pl->ns = ns; pl->f1 = f1; pl->ca = ca; pl->cb = cb; pl->a0 = a0; pl->b0 = b0; pl->astep = astep; pl->n = n;
+    pl->have_copy_in = pl->have_copy_out = have_copy;
+    pl->done = 0;
+    __atomic_store_n(&pl->next, 0u, __ATOMIC_RELEASE);   /* a worker still leaving the previous job may pick up this one's strains */
+    pl->gen++;
+    pthread_cond_broadcast(&pl->cv_work);
+    pthread_mutex_unlock(&pl->mu);
+    pool_drain(pl);
+    pthread_mutex_lock(&pl->mu);
+    while (pl->done != pl->ns) pthread_cond_wait(&pl->cv_done, &pl->mu);
+    pthread_mutex_unlock(&pl->mu);
+    return pl->have_copy_out;
+}
+
+/* one metagenome (pair), for every strain at once.  The read lengths -- hence which read refreshes which
+ * tallies, the totals and the "PE2 ended early" failure -- are the same for all strains and are handled
+ * here, run by run; the per-strain part is sd_replay_run.  A read shorter than k refreshes nothing, so it
+ * re-uses (and may re-emit) the previous read's tallies and sequence, as in the reference. */
+static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, const char *f1, const char *f2, int mode)
+{
+    sd_stream A, B;
+    uint32_t s, j;
     int have_copy = 0, rc, got, status = 1;
     unsigned long long evaluated = 0, reads = 0;
     FILE *err = p[0].err;
@@ -299,49 +448,46 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, const char *f1,
         rc = stream_open(&B, f2);
         if (rc == SK_E_OPEN) { fprintf(err, "could not read file (read2) is_PE %s in quantify_hits_PE() (error: (null))\n", f2); stream_close(&A); return 1; }
         if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f2); stream_close(&A); return 1; }
-        pb = &B;
-    } else pb = &A;                                      /* PEI: the mate is the next record of the same file */
+    }
     for (s = 0; s < ns; s++) { p[s].h1 = p[s].i1 = p[s].h2 = p[s].i2 = 0; p[s].copy_n = 0; }
 
-    while ((got = stream_next(&A, p, ns, batch, &ca, &ra)) == 1) {
-        const uint64_t la = ca->len[ra];
-        uint64_t len2 = 0;
-        int b_valid = 0;
-        if (la >= SK_K) {
-            reads++;
-            evaluated += la - (SK_K - 1);
-            have_copy = 1;
-            for (s = 0; s < ns; s++) {
-                const uint32_t n = ca->hbeg[s][ra + 1] - ca->hbeg[s][ra];
-                p[s].h1 = (int)ca->hits[s][ra];
-                p[s].i1 = (int)ca->inf[s][ra];
-                if (n > p[s].copy_cap) { p[s].copy_cap = n * 2 + 16; p[s].copy_rows = (uint32_t *)realloc(p[s].copy_rows, (size_t)p[s].copy_cap * 4); }
-                if (n) memcpy(p[s].copy_rows, ca->rows[s] + ca->hbeg[s][ra], (size_t)n * 4);
-                p[s].copy_n = n;
-            }
-        }
-        if (mode != SD_SE) {
-            int failed = 0;
-            got = stream_next(pb, p, ns, batch, &cb, &rb);
+    while ((got = stream_fill(&A, p, ns, batch)) == 1) {
+        sd_chunk *ca = A.c, *cb = NULL, *held = NULL;
+        uint32_t a0 = A.ci, b0 = 0, n = ca->nrec - a0, astep = 1;
+        int mate_missing = 0;
+        uint64_t stale_len2 = 0;
+        if (mode == SD_PE) {
+            got = stream_fill(&B, p, ns, batch);
             if (got < 0) break;
-            if (got == 1) len2 = cb->len[rb];
-            else { failed = 1; len2 = pb->end_kind == SKP_END_RESET ? 0 : pb->end_len; }
-            if (len2 >= SK_K) {
-                if (failed) {
-                    fprintf(err, "reached end of PE2 (%s) before end of PE1 (%s), check that file names are correct\n",
-                            f2 ? f2 : "(null)", f1);
-                    goto done;
-                }
-                b_valid = 1;
-                for (s = 0; s < ns; s++) { p[s].h2 = (int)cb->hits[s][rb]; p[s].i2 = (int)cb->inf[s][rb]; }
-                evaluated += len2 - (SK_K - 1);
+            if (got == 1) { cb = B.c; b0 = B.ci; if (cb->nrec - b0 < n) n = cb->nrec - b0; }
+            else { mate_missing = 1; stale_len2 = B.end_kind == SKP_END_RESET ? 0 : B.end_len; }   /* PE2 is exhausted for good */
+        } else if (mode == SD_PEI) {
+            if (n >= 2) { cb = ca; b0 = a0 + 1; astep = 2; n /= 2; }
+            else {                                       /* the mate is the first record of the next chunk, or missing */
+                held = stream_steal(&A);
+                got = stream_fill(&A, p, ns, batch);
+                if (got < 0) { chunk_free(held); break; }
+                if (got == 1) { cb = A.c; b0 = A.ci; }
+                else { mate_missing = 1; stale_len2 = A.end_kind == SKP_END_RESET ? 0 : A.end_len; }
             }
         }
-        for (s = 0; s < ns; s++)
-            if (p[s].h1 + p[s].h2 >= 1 && p[s].i1 + p[s].i2 >= 1) {
-                if (have_copy) emit_rows(&p[s], p[s].copy_rows, p[s].copy_n, f1);
-                if (b_valid) emit_rows(&p[s], cb->rows[s] + cb->hbeg[s][rb], cb->hbeg[s][rb + 1] - cb->hbeg[s][rb], f1);
-            }
+        /* strain-independent part of the run (:444-450,489-512) */
+        for (j = 0; j < n; j++) {
+            const uint64_t la = ca->len[a0 + j * astep];
+            if (la >= SK_K) { reads++; evaluated += la - (SK_K - 1); }
+            if (cb) { const uint64_t lb = cb->len[b0 + j * astep]; if (lb >= SK_K) evaluated += lb - (SK_K - 1); }
+        }
+        if (mate_missing && stale_len2 >= SK_K) {        /* the mate file ended first and its last length still reads as a read (:505-512) */
+            fprintf(err, "reached end of PE2 (%s) before end of PE1 (%s), check that file names are correct\n", f2 ? f2 : "(null)", f1);
+            chunk_free(held);
+            goto done;
+        }
+        have_copy = pool_replay(pool, p, ns, f1, ca, a0, cb, b0, astep, n, have_copy);
+        if (held) { chunk_free(held); if (cb) A.ci++; }  /* PEI across a chunk boundary: the mate was A's next record */
+        else {
+            A.ci += n * astep;
+            if (mode == SD_PE && cb) B.ci += n;
+        }
     }
     if (got < 0) {
         fprintf(err, "strain_detect: device error on %s: %s (%s)\n", f1, sk_strerror(got), sk_last_error(p[0].ctx));
@@ -498,15 +644,30 @@ static void usage(FILE *err)
     fputs("\ninformative kmer file is a list of all of the kmers left in the reference genome post scrubbing\n", err);
 }
 
-/* build one strain's state: key set, table on the device, -a flags, optional -g filter, -o file */
-static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *g, const char *o, int device, FILE *out, FILE *err)
+/* build one strain's state in two steps: the key set (host only; several strains build theirs at the
+ * same time on separate threads), then the table on the device, -a flags, optional -g filter, -o file */
+typedef struct { sd_prog *p; const char *r; int rc, done; } ks_job;
+typedef struct { ks_job *jobs; uint32_t njobs, next; pthread_mutex_t mu; pthread_cond_t cv; } ks_pool;
+
+static void *sd_keyset_pool_thread(void *arg)
+{
+    ks_pool *kp = (ks_pool *)arg;
+    for (;;) {
+        const uint32_t k = __atomic_fetch_add(&kp->next, 1u, __ATOMIC_RELAXED);
+        if (k >= kp->njobs) return NULL;
+        kp->jobs[k].rc = skh_keyset_from_file(&kp->jobs[k].p->ks, kp->jobs[k].r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0);
+        pthread_mutex_lock(&kp->mu);
+        kp->jobs[k].done = 1;
+        pthread_cond_broadcast(&kp->cv);
+        pthread_mutex_unlock(&kp->mu);
+    }
+}
+
+static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a, const char *g, const char *o, int device)
 {
     unsigned n_inform = 0, i;
-    int rc;
-    memset(p, 0, sizeof *p);
-    p->out = out;
-    p->err = err;
-    rc = skh_keyset_from_file(&p->ks, r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0);
+    int rc = ks_rc;
+    FILE *err = p->err;
     if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", r); return 1; }
     if (rc != SK_OK) { fprintf(err, "strain_detect: %s\n", sk_strerror(rc)); return 1; }
     if (p->ks.short_records)
@@ -526,6 +687,14 @@ static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *
     return 0;
 }
 
+static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *g, const char *o, int device, FILE *out, FILE *err)
+{
+    memset(p, 0, sizeof *p);
+    p->out = out;
+    p->err = err;
+    return sd_strain_finish(p, skh_keyset_from_file(&p->ks, r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0), r, a, g, o, device);
+}
+
 static void sd_strain_close(sd_prog *p)
 {
     if (p->gz) gzclose(p->gz);
@@ -539,16 +708,18 @@ static void sd_strain_close(sd_prog *p)
 static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const char *b2, int mode, FILE *out, FILE *err)
 {
     sk_batch *batch = NULL;
+    sd_pool pool;
     int bad = 0, rc;
     if ((rc = sk_batch_create(p[0].ctx, &batch)) != SK_OK) {
         fprintf(err, "strain_detect: %s (%s)\n", sk_strerror(rc), sk_last_error(p[0].ctx));
         return 1;
     }
+    pool_start(&pool, ns);
     if (B) {
         FILE *fp = fopen(B, "r");
         char *line = NULL, *nl, *tok, *f1, *f2;
         size_t cap = 0;
-        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); sk_batch_destroy(batch); return 1; }
+        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); pool_stop(&pool); sk_batch_destroy(batch); return 1; }
         while (!bad && getline(&line, &cap, fp) != -1) {
             int m;
             if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
@@ -561,12 +732,13 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
             if (m == SD_PE) {
                 f2 = strtok(NULL, "\t");
                 if (!f2) { fprintf(out, "ERROR: no second file specified for PE: %s\n", line); continue; }
-                bad = sd_quantify(p, ns, batch, f1, f2, m);
-            } else bad = sd_quantify(p, ns, batch, f1, NULL, m);
+                bad = sd_quantify(p, ns, batch, &pool, f1, f2, m);
+            } else bad = sd_quantify(p, ns, batch, &pool, f1, NULL, m);
         }
         free(line);
         fclose(fp);
-    } else bad = sd_quantify(p, ns, batch, b, b2, mode);
+    } else bad = sd_quantify(p, ns, batch, &pool, b, b2, mode);
+    pool_stop(&pool);
     sk_batch_destroy(batch);
     return bad;
 }
@@ -575,7 +747,9 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
 {
     const char *a = NULL, *r = NULL, *b = NULL, *b2 = NULL, *B = NULL, *tt = NULL, *g = NULL, *o = NULL, *S = NULL, *env;
     int c, mode = SD_SE, status = 1, device = 0, n_S = 0;
+    double t_begin = 0;
     sd_prog *p = NULL;
+    char **paths = NULL;
     uint32_t ns = 0, s;
 
     optind = 1;
@@ -620,6 +794,7 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
         usage(err); return 1;
     }
     if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
+    t_begin = now_s();
 
     if (S) {
         FILE *fp = fopen(S, "r");
@@ -638,20 +813,61 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
             fr = strtok(line, "\t"); fa = strtok(NULL, "\t"); fo = strtok(NULL, "\t"); fg = strtok(NULL, "\t");
             if (!fr || !fa || !fo) { fprintf(err, "strain_detect: %s: a line needs <genome> TAB <informative k-mers> TAB <outfile>\n", S); free(line); fclose(fp); goto done; }
             p = (sd_prog *)realloc(p, ((size_t)ns + 1) * sizeof *p);
-            if (sd_strain_open(&p[ns++], fr, fa, fg, fo, device, out, err)) { free(line); fclose(fp); goto done; }
+            paths = (char **)realloc(paths, ((size_t)ns + 1) * 4 * sizeof *paths);
+            memset(&p[ns], 0, sizeof *p);
+            p[ns].out = out; p[ns].err = err;
+            paths[4 * ns] = strdup(fr); paths[4 * ns + 1] = strdup(fa); paths[4 * ns + 2] = strdup(fo); paths[4 * ns + 3] = fg ? strdup(fg) : NULL;
+            ns++;
         }
         free(line);
         fclose(fp);
+        {   /* key sets are built by SK_THREADS (default 8) host threads; the device work of strain k
+             * (table load, -a, -g) starts as soon as its key set is there and overlaps the later builds */
+            int nth = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : 8, t;
+            ks_pool kp;
+            pthread_t th[16];
+            uint32_t k, failed = 0;
+            memset(&kp, 0, sizeof kp);
+            kp.jobs = (ks_job *)calloc(ns ? ns : 1, sizeof *kp.jobs);
+            kp.njobs = ns;
+            pthread_mutex_init(&kp.mu, NULL);
+            pthread_cond_init(&kp.cv, NULL);
+            for (k = 0; k < ns; k++) { kp.jobs[k].p = &p[k]; kp.jobs[k].r = paths[4 * k]; kp.jobs[k].rc = SK_E_NOMEM; }
+            if (nth > 16) nth = 16;
+            if (nth < 1) nth = 1;
+            if ((uint32_t)nth > ns) nth = (int)ns;
+            for (t = 0; t < nth; t++) if (pthread_create(&th[t], NULL, sd_keyset_pool_thread, &kp)) break;
+            nth = t;
+            if (nth == 0) sd_keyset_pool_thread(&kp);     /* no thread could be started: build them here */
+            for (k = 0; k < ns; k++) {
+                pthread_mutex_lock(&kp.mu);
+                while (!kp.jobs[k].done) pthread_cond_wait(&kp.cv, &kp.mu);
+                pthread_mutex_unlock(&kp.mu);
+                if (!failed)
+                    failed = (uint32_t)sd_strain_finish(&p[k], kp.jobs[k].rc, paths[4 * k], paths[4 * k + 1], paths[4 * k + 3], paths[4 * k + 2], device);
+            }
+            for (t = 0; t < nth; t++) pthread_join(th[t], NULL);
+            pthread_mutex_destroy(&kp.mu);
+            pthread_cond_destroy(&kp.cv);
+            free(kp.jobs);
+            if (failed) goto done;
+        }
         if (ns == 0) { status = 0; goto done; }          /* nothing dealt to this rank */
     } else {
         p = (sd_prog *)malloc(sizeof *p);
         ns = 1;
         if (sd_strain_open(&p[0], r, a, g, o, device, out, err)) goto done;
     }
+    t_setup = now_s() - t_begin;
     if (sd_run(p, ns, B, b, b2, mode, out, err)) goto done;
     status = 0;
 done:
+    if (getenv("SK_SD_TIMING"))
+        fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally (upload+kernels+collect+sort) %.2f s, "
+                     "total before close %.2f s\n", t_setup, t_wait, t_tally, now_s() - t_begin);
     for (s = 0; s < ns; s++) sd_strain_close(&p[s]);
+    for (s = 0; paths && s < 4 * ns; s++) free(paths[s]);
+    free(paths);
     free(p);
     return status;
 }

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""strain_detect with many strains resident (cfg 5 shape, scaled): NSTRAINS synthetic strains of STRAIN_BP
+each, 1 % of their k-mers informative, one SE FASTA of READS x 150 bp reads with 2 % of the reads drawn
+from the strains.  Wall clock of ONE `strain_detect -S list` pass against NSTRAINS separate runs of the
+same program (what the reference workflow does), outputs compared.  Prints one JSON line."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from strainer2_amd import synth  # noqa: E402
+import strainer2_amd as sk  # noqa: E402
+
+NSTRAINS = int(os.environ.get("NSTRAINS", "8"))
+STRAIN_BP = int(os.environ.get("STRAIN_BP", "5000000"))
+READS = int(os.environ.get("READS", "2000000"))
+SEPARATE = int(os.environ.get("SEPARATE", str(NSTRAINS)))       # how many of the separate runs to time
+work = os.environ.get("WORK", "/tmp/sk_sdm")
+os.makedirs(work, exist_ok=True)
+rng = np.random.default_rng(11)
+acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+t0 = time.time()
+strains = []
+with open(os.path.join(work, "strains.txt"), "w") as lst:
+    for s in range(NSTRAINS):
+        g = acgt[rng.integers(0, 4, STRAIN_BP)]
+        strains.append(g)
+        with open(os.path.join(work, f"s{s}.fa"), "wb") as f:
+            f.write(b">s%d\n" % s + g.tobytes() + b"\n")
+        ks = sk.Keyset.from_stream(g.tobytes() + b"\n")
+        keys = ks.keys()
+        pick = rng.choice(len(keys), size=len(keys) // 100, replace=False)
+        with open(os.path.join(work, f"s{s}.inf"), "wb") as f:
+            f.write(b"\n".join(keys[i] for i in sorted(pick)) + b"\n")
+        ks.close()
+        lst.write(f"{work}/s{s}.fa\t{work}/s{s}.inf\t{work}/multi{s}.gz\n")
+reads = acgt[rng.integers(0, 4, (READS, 150))]
+from_strain = np.flatnonzero(rng.random(READS) < 0.02)
+for i in from_strain:
+    g = strains[int(rng.integers(0, NSTRAINS))]
+    a = int(rng.integers(0, STRAIN_BP - 150))
+    reads[i] = g[a:a + 150]
+with open(os.path.join(work, "reads.fa"), "wb") as f:
+    f.write(b"".join(b">r%d\n%s\n" % (j, reads[j].tobytes()) for j in range(READS)))
+print(f"inputs ready in {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
+
+exe = os.path.join(REPO, "strainer2_amd", "bin", "strain_detect")
+t = time.time()
+subprocess.run([exe, "-S", os.path.join(work, "strains.txt"), "-b", os.path.join(work, "reads.fa"), "-t", "SE"], check=True)
+t_multi = time.time() - t
+t_sep = []
+same = True
+for s in range(SEPARATE):
+    t = time.time()
+    subprocess.run([exe, "-r", f"{work}/s{s}.fa", "-a", f"{work}/s{s}.inf", "-b", os.path.join(work, "reads.fa"), "-t", "SE",
+                    "-o", f"{work}/single{s}.gz"], check=True)
+    t_sep.append(time.time() - t)
+    same = same and gzip.open(f"{work}/single{s}.gz").read() == gzip.open(f"{work}/multi{s}.gz").read()
+lines = sum(1 for s in range(NSTRAINS) for _ in gzip.open(f"{work}/multi{s}.gz"))
+bases = READS * 150
+print(json.dumps({
+    "workload": f"{NSTRAINS} strains x {STRAIN_BP} bp, 1 % informative; {READS} x 150 bp SE reads ({bases / 1e9:.2f} Gbase), 2 % from the strains",
+    "one_pass_all_strains_s": round(t_multi, 2),
+    "separate_runs_timed": SEPARATE,
+    "separate_run_mean_s": round(float(np.mean(t_sep)), 2) if t_sep else None,
+    "separate_runs_total_s_extrapolated": round(float(np.mean(t_sep)) * NSTRAINS, 2) if t_sep else None,
+    "strain_x_bases_per_s_one_pass": round(NSTRAINS * bases / t_multi),
+    "output_lines": lines, "outputs_identical_to_separate_runs": same}))
