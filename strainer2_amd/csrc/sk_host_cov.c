@@ -18,6 +18,7 @@
 #include "../../include/strainer_kmer.h"
 #include "sk_common.h"
 #include "sk_pyfmt.h"
+#include "sk_internal.h"
 
 /* ------------------------------------------------------------------ a small insertion-ordered name table */
 typedef struct {
@@ -156,6 +157,37 @@ static int to_general(hitlist *h)
     return COV_OK;
 }
 
+/* one hit that passed the read filter: sample = basename of the metagenome, key = packed k-mer or row */
+static int64_t cov_sample(hitlist *h, const char *sn, size_t slen)
+{
+    const int64_t g = name_get(&h->smp, sn, slen);
+    if (g >= 0 && !h->smp.in_depth[g]) {
+        uint32_t *o = realloc(h->depth_order, ((size_t)h->ndepth + 1) * sizeof *o);
+        if (!o) return -1;
+        h->depth_order = o;
+        o[h->ndepth++] = (uint32_t)g;
+        h->smp.in_depth[g] = 1;
+    }
+    return g;
+}
+
+static int cov_push(hitlist *h, uint32_t g, uint64_t key)
+{
+    if (h->n == h->cap) {
+        const uint64_t cap = h->cap ? h->cap * 2 : 1u << 16;
+        uint64_t *k2 = realloc(h->key, cap * sizeof *k2);
+        uint32_t *s2;
+        if (!k2) return COV_NOMEM;
+        h->key = k2;
+        if (!(s2 = realloc(h->sample, cap * sizeof *s2))) return COV_NOMEM;
+        h->sample = s2;
+        h->cap = cap;
+    }
+    h->key[h->n] = key;
+    h->sample[h->n++] = g;
+    return COV_OK;
+}
+
 static int hit_line(hitlist *h, char *s, size_t len, int64_t min_hits)
 {
     char *f[7], *end = s + len, *p;
@@ -172,60 +204,29 @@ static int hit_line(hitlist *h, char *s, size_t len, int64_t min_hits)
         return COV_INT;
     if (!(a + c > min_hits)) return COV_OK;           /* hits of the read pair, informative or not (:83-86) */
     sn = base_of(f[0], f[1] - 1);
-    if ((g = name_get(&h->smp, sn, (size_t)(f[1] - 1 - sn))) < 0) return COV_NOMEM;
-    if (!h->smp.in_depth[g]) {
-        uint32_t *o = realloc(h->depth_order, ((size_t)h->ndepth + 1) * sizeof *o);
-        if (!o) return COV_NOMEM;
-        h->depth_order = o;
-        o[h->ndepth++] = (uint32_t)g;
-        h->smp.in_depth[g] = 1;
-    }
+    if ((g = cov_sample(h, sn, (size_t)(f[1] - 1 - sn))) < 0) return COV_NOMEM;
     kend = nf > 6 ? f[6] - 1 : end;
     klen = (size_t)(kend - f[5]);
     if (!h->general) {
         int plain = klen >= 1 && klen <= 31 && (h->klen == 0 || h->klen == klen);
         for (j = 0; plain && j < klen; j++) {
             const unsigned cde = sk_code((uint8_t)f[5][j]);
-            if (cde > 3 || f[5][j] != "ACGT"[cde]) plain = 0;     /* upper-case A/C/G/T only */
+            if (f[5][j] != "ACGT"[cde]) plain = 0;     /* upper-case A/C/G/T only */
             key = (key << 2) | (cde & 3u);
         }
         if (plain) h->klen = klen;
         else { int rc = to_general(h); if (rc) return rc; }
     }
     if (h->general) return general_count(h, (uint32_t)g, f[5], klen);
-    if (h->n == h->cap) {
-        const uint64_t cap = h->cap ? h->cap * 2 : 1u << 16;
-        uint64_t *k2 = realloc(h->key, cap * sizeof *k2);
-        uint32_t *s2;
-        if (!k2) return COV_NOMEM;
-        h->key = k2;
-        if (!(s2 = realloc(h->sample, cap * sizeof *s2))) return COV_NOMEM;
-        h->sample = s2;
-        h->cap = cap;
-    }
-    h->key[h->n] = key;
-    h->sample[h->n++] = (uint32_t)g;
-    return COV_OK;
+    return cov_push(h, (uint32_t)g, key);
 }
 
-/* "#<metagenome>\t<name>\t<value>" (:101-116) */
-static int trailer_line(hitlist *h, char *s, size_t len)
+/* one trailer value of a sample (:104-116) */
+static int cov_trailer(hitlist *h, const char *sn, size_t slen, const char *var, size_t vlen, int64_t v)
 {
-    char *f[4], *end, *p;
-    int nf = 1;
-    int64_t v, g;
-    const char *sn;
-    while (len && isspace((unsigned char)s[len - 1])) len--;      /* line.rstrip() */
-    end = s + len;
-    f[0] = s;
-    for (p = s; p < end; p++)
-        if (*p == '\t') { if (nf < 4) f[nf] = p + 1; nf++; }
-    if (nf < 3) return COV_FIELDS;
-    sn = base_of(f[0], f[1] - 1);
-    if (sn < f[1] - 1 && *sn == '#') sn++;
-    if (!skp_int(f[2], nf > 3 ? f[3] - 1 : end, &v)) return COV_INT;
-    if ((g = name_get(&h->smp, sn, (size_t)(f[1] - 1 - sn))) < 0) return COV_NOMEM;
-#define IS(word) ((size_t)(f[2] - 1 - f[1]) == sizeof(word) - 1 && !memcmp(f[1], word, sizeof(word) - 1))
+    const int64_t g = name_get(&h->smp, sn, slen);
+    if (g < 0) return COV_NOMEM;
+#define IS(word) (vlen == sizeof(word) - 1 && !memcmp(var, word, sizeof(word) - 1))
     if (IS("total_kmer_evaluated")) {
         if (!h->smp.have_eval[g]) {
             uint32_t *o = realloc(h->eval_order, ((size_t)h->neval + 1) * sizeof *o);
@@ -240,6 +241,25 @@ static int trailer_line(hitlist *h, char *s, size_t len)
     else if (IS("total_genome_informative_kmers")) { h->smp.g_inf[g] = v; h->smp.have_inf[g] = 1; }
 #undef IS
     return COV_OK;
+}
+
+/* "#<metagenome>\t<name>\t<value>" (:101-116) */
+static int trailer_line(hitlist *h, char *s, size_t len)
+{
+    char *f[4], *end, *p;
+    int nf = 1;
+    int64_t v;
+    const char *sn;
+    while (len && isspace((unsigned char)s[len - 1])) len--;      /* line.rstrip() */
+    end = s + len;
+    f[0] = s;
+    for (p = s; p < end; p++)
+        if (*p == '\t') { if (nf < 4) f[nf] = p + 1; nf++; }
+    if (nf < 3) return COV_FIELDS;
+    sn = base_of(f[0], f[1] - 1);
+    if (sn < f[1] - 1 && *sn == '#') sn++;
+    if (!skp_int(f[2], nf > 3 ? f[3] - 1 : end, &v)) return COV_INT;
+    return cov_trailer(h, sn, (size_t)(f[1] - 1 - sn), f[1], (size_t)(f[2] - 1 - f[1]), v);
 }
 
 static int read_hits(hitlist *h, const char *path, int64_t min_hits)
@@ -295,66 +315,35 @@ static int cov_opt(int argc, char **argv, int *i, const char *shortn, const char
     return 0;
 }
 
-int skh_coverage_depth_main(int argc, char **argv, FILE *out, FILE *err)
+/* everything after the hit list is read: trailer-only samples, the counts (device), the table (:121-124,200-271).
+ * `kfile` only names the strain.  Returns the exit status. */
+static int cov_report(hitlist *h, sk_ctx *ctx, const char *kfile, const char *bfile, FILE *out, FILE *err)
 {
-    const char *kfile = NULL, *mtext = NULL, *bfile = NULL, *env;
-    int64_t min_hits = 1;
-    int i, bad = 0, rc, status = 1, device = 0;
-    hitlist h;
     names bg;
-    sk_ctx *ctx = NULL;
     uint64_t *uniq = NULL, *total = NULL;
     char *strain = NULL, *species = NULL, *genus = NULL, *us;
     size_t sl;
     uint32_t s, k;
-
-    for (i = 1; i < argc; i++) {                     /* :27-41 */
-        if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
-            fprintf(out, "usage: coverage_depth [-h] --kmer_hits_file FILE [--min_kmer_hits N] [--background_metagenomes_file FILE]\n");
-            return 0;
-        }
-        if (cov_opt(argc, argv, &i, "-k", "--kmer_hits_file", &kfile, err, &bad)) { if (bad) return 2; continue; }
-        if (cov_opt(argc, argv, &i, "-m", "--min_kmer_hits", &mtext, err, &bad)) { if (bad) return 2; continue; }
-        if (cov_opt(argc, argv, &i, "-b", "--background_metagenomes_file", &bfile, err, &bad)) { if (bad) return 2; continue; }
-        fprintf(err, "coverage_depth: error: unrecognized arguments: %s\n", argv[i]);
-        return 2;
-    }
-    if (!kfile) { fprintf(err, "coverage_depth: error: the following arguments are required: --kmer_hits_file/-k\n"); return 2; }
-    if (mtext && !skp_int(mtext, mtext + strlen(mtext), &min_hits)) {
-        fprintf(err, "coverage_depth: error: argument --min_kmer_hits/-m: invalid int value: '%s'\n", mtext);
-        return 2;
-    }
-    memset(&h, 0, sizeof h);
+    int rc, status = 1;
     memset(&bg, 0, sizeof bg);
-    rc = read_hits(&h, kfile, min_hits);
-    if (rc == COV_OPEN) { fprintf(err, "coverage_depth: could not read %s\n", kfile); goto done; }
-    if (rc == COV_FIELDS) { fprintf(err, "coverage_depth: %s: a line has too few tab-separated fields\n", kfile); goto done; }
-    if (rc == COV_INT) { fprintf(err, "coverage_depth: %s: a count field is not an integer\n", kfile); goto done; }
-    if (rc == COV_NOMEM) { fprintf(err, "coverage_depth: out of memory\n"); goto done; }
     /* metagenomes that only have trailer lines come after those with passing hits (:121-124) */
-    for (k = 0; k < h.neval; k++)
-        if (!h.smp.in_depth[s = h.eval_order[k]]) {
-            uint32_t *o = realloc(h.depth_order, ((size_t)h.ndepth + 1) * sizeof *o);
+    for (k = 0; k < h->neval; k++)
+        if (!h->smp.in_depth[s = h->eval_order[k]]) {
+            uint32_t *o = realloc(h->depth_order, ((size_t)h->ndepth + 1) * sizeof *o);
             if (!o) { fprintf(err, "coverage_depth: out of memory\n"); goto done; }
-            h.depth_order = o;
-            o[h.ndepth++] = s;
-            h.smp.in_depth[s] = 1;
+            h->depth_order = o;
+            o[h->ndepth++] = s;
+            h->smp.in_depth[s] = 1;
         }
-
-    /* counts on the device */
-    if (h.smp.n) {
-        if (!(uniq = calloc(h.smp.n, sizeof *uniq)) || !(total = calloc(h.smp.n, sizeof *total))) { fprintf(err, "coverage_depth: out of memory\n"); goto done; }
-        if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
-        rc = sk_ctx_create(&ctx, device);
-        if (rc != SK_OK) { fprintf(err, "coverage_depth: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); goto done; }
-        if (h.general) {                             /* out-of-domain k-mer text: counted while reading (see to_general) */
-            for (s = 0; s < h.smp.n && s < h.gen_cap; s++) { uniq[s] = h.gen_unique[s]; total[s] = h.gen_total[s]; }
+    if (h->smp.n) {
+        if (!(uniq = calloc(h->smp.n, sizeof *uniq)) || !(total = calloc(h->smp.n, sizeof *total))) { fprintf(err, "coverage_depth: out of memory\n"); goto done; }
+        if (h->general) {                            /* out-of-domain k-mer text: counted while reading (see to_general) */
+            for (s = 0; s < h->smp.n && s < h->gen_cap; s++) { uniq[s] = h->gen_unique[s]; total[s] = h->gen_total[s]; }
         } else {
-            rc = sk_distinct_count(ctx, h.key, h.sample, h.n, h.smp.n, uniq, total);
+            rc = sk_distinct_count(ctx, h->key, h->sample, h->n, h->smp.n, uniq, total);
             if (rc != SK_OK) { fprintf(err, "coverage_depth: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
         }
     }
-
     /* names derived from the file name (:203-213): strip "<any>kmer_hits<any>gz" at the end, split at '_' */
     strain = strdup(base_of(kfile, kfile + strlen(kfile)));
     sl = strlen(strain);
@@ -381,19 +370,19 @@ int skh_coverage_depth_main(int argc, char **argv, FILE *out, FILE *err)
     fputs("strain_name\tspecies_name\tgenus_name\tgenome_num_total_kmers\tgenome_num_informative_kmers\tmetagenome\t"
           "num_metagenomic_reads\tnum_metagenome_kmers\tunique_observed_informative_kmers\ttotal_observed_informative_kmers\t"
           "kmer_coverage\tkmer_depth\tkmer_depth_per_20B_kmer\tbackground\n", out);
-    for (k = 0; k < h.ndepth; k++) {                 /* :227-271 */
-        const names *t = &h.smp;
+    for (k = 0; k < h->ndepth; k++) {                /* :227-271 */
+        const names *t = &h->smp;
         const char *m;
         int64_t observed, unique, evaluated, reads, gt, gi;
         int in_bg = 0;
         uint32_t j;
         char c1[32], c2[32], c3[32];
-        s = h.depth_order[k];
+        s = h->depth_order[k];
         m = t->name[s];
         observed = (int64_t)total[s];
         /* general mode only: a sample all of whose joined strings were first seen under another sample
          * never enters the script's coverage dictionary and prints the -1 placeholder (:236-243) */
-        unique = (h.general && total[s] && !uniq[s]) ? -1 : (int64_t)uniq[s];
+        unique = (h->general && total[s] && !uniq[s]) ? -1 : (int64_t)uniq[s];
         evaluated = t->have_eval[s] ? t->kmer_eval[s] : -1;
         reads = t->have_eval[s] ? (t->have_reads[s] ? t->read_eval[s] : 0) : -1;
         gt = t->have_total[s] ? t->g_total[s] : -1;
@@ -410,9 +399,90 @@ int skh_coverage_depth_main(int argc, char **argv, FILE *out, FILE *err)
     status = 0;
 done:
     fflush(out);
-    sk_ctx_destroy(ctx);
     free(uniq); free(total); free(strain); free(species); free(genus);
-    free(h.key); free(h.sample); free(h.depth_order); free(h.eval_order); free(h.gen_unique); free(h.gen_total);
-    names_free(&h.smp); names_free(&h.text); names_free(&bg);
+    names_free(&bg);
+    return status;
+}
+
+static void hitlist_free(hitlist *h)
+{
+    free(h->key); free(h->sample); free(h->depth_order); free(h->eval_order); free(h->gen_unique); free(h->gen_total);
+    names_free(&h->smp); names_free(&h->text);
+    memset(h, 0, sizeof *h);
+}
+
+/* ---- the same accumulator fed directly by strain_detect (fused steps 3 -> 4; sk_internal.h) ---- */
+struct skc_acc { hitlist h; int64_t min_hits; };
+
+skc_acc *skc_create(int64_t min_hits)
+{
+    skc_acc *a = calloc(1, sizeof *a);
+    if (a) a->min_hits = min_hits;
+    return a;
+}
+
+void skc_destroy(skc_acc *a) { if (a) { hitlist_free(&a->h); free(a); } }
+
+/* what one hit line of the -o file would contribute: metagenome path, the pair's hit counts of PE1 and PE2
+ * (fields 2 and 4), and the k-mer named by its row */
+int skc_add_hit(skc_acc *a, const char *metagenome, int64_t hits_pe1, int64_t hits_pe2, uint32_t row)
+{
+    const char *sn;
+    int64_t g;
+    if (!(hits_pe1 + hits_pe2 > a->min_hits)) return 0;
+    sn = base_of(metagenome, metagenome + strlen(metagenome));
+    if ((g = cov_sample(&a->h, sn, strlen(sn))) < 0) return -1;
+    return cov_push(&a->h, (uint32_t)g, (uint64_t)row) == COV_OK ? 0 : -1;
+}
+
+int skc_add_trailer(skc_acc *a, const char *metagenome, const char *name, int64_t value)
+{
+    const char *sn = base_of(metagenome, metagenome + strlen(metagenome));
+    return cov_trailer(&a->h, sn, strlen(sn), name, strlen(name), value) == COV_OK ? 0 : -1;
+}
+
+int skc_report(skc_acc *a, sk_ctx *ctx, const char *hits_file_name, FILE *out, FILE *err)
+{
+    return cov_report(&a->h, ctx, hits_file_name, NULL, out, err);
+}
+
+int skh_coverage_depth_main(int argc, char **argv, FILE *out, FILE *err)
+{
+    const char *kfile = NULL, *mtext = NULL, *bfile = NULL, *env;
+    int64_t min_hits = 1;
+    int i, bad = 0, rc, status = 1, device = 0;
+    hitlist h;
+    sk_ctx *ctx = NULL;
+
+    for (i = 1; i < argc; i++) {                     /* :27-41 */
+        if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
+            fprintf(out, "usage: coverage_depth [-h] --kmer_hits_file FILE [--min_kmer_hits N] [--background_metagenomes_file FILE]\n");
+            return 0;
+        }
+        if (cov_opt(argc, argv, &i, "-k", "--kmer_hits_file", &kfile, err, &bad)) { if (bad) return 2; continue; }
+        if (cov_opt(argc, argv, &i, "-m", "--min_kmer_hits", &mtext, err, &bad)) { if (bad) return 2; continue; }
+        if (cov_opt(argc, argv, &i, "-b", "--background_metagenomes_file", &bfile, err, &bad)) { if (bad) return 2; continue; }
+        fprintf(err, "coverage_depth: error: unrecognized arguments: %s\n", argv[i]);
+        return 2;
+    }
+    if (!kfile) { fprintf(err, "coverage_depth: error: the following arguments are required: --kmer_hits_file/-k\n"); return 2; }
+    if (mtext && !skp_int(mtext, mtext + strlen(mtext), &min_hits)) {
+        fprintf(err, "coverage_depth: error: argument --min_kmer_hits/-m: invalid int value: '%s'\n", mtext);
+        return 2;
+    }
+    memset(&h, 0, sizeof h);
+    rc = read_hits(&h, kfile, min_hits);
+    if (rc == COV_OPEN) { fprintf(err, "coverage_depth: could not read %s\n", kfile); goto done; }
+    if (rc == COV_FIELDS) { fprintf(err, "coverage_depth: %s: a line has too few tab-separated fields\n", kfile); goto done; }
+    if (rc == COV_INT) { fprintf(err, "coverage_depth: %s: a count field is not an integer\n", kfile); goto done; }
+    if (rc == COV_NOMEM) { fprintf(err, "coverage_depth: out of memory\n"); goto done; }
+    if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
+    rc = sk_ctx_create(&ctx, device);
+    if (rc != SK_OK) { fprintf(err, "coverage_depth: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); goto done; }
+    status = cov_report(&h, ctx, kfile, bfile, out, err);
+done:
+    fflush(out);
+    sk_ctx_destroy(ctx);
+    hitlist_free(&h);
     return status;
 }

@@ -26,6 +26,7 @@
 #include "../../include/strainer_kmer.h"
 #include "sk_common.h"
 #include "sk_parser.h"
+#include "sk_internal.h"
 
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
 enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
@@ -44,6 +45,7 @@ typedef struct {
     unsigned    genome_inf;    /* informative rows after -a / -g */
     int         h1, i1, h2, i2;            /* tallies carried from read to read (src/strain_detect.c:444-454,497-500) */
     uint32_t   *copy_rows; uint32_t copy_n, copy_cap;   /* informative rows of the PE1 read last copied (:451) */
+    skc_acc    *cov; char *cov_path, *o_path;           /* --coverage-depth: step 4 of the workflow, fed at emission */
     sk_hit     *hitbuf; uint64_t hitcap;   /* landing area of the hit log */
     uint32_t   *tallybuf; uint32_t tallycap;
 } sd_prog;
@@ -299,6 +301,7 @@ static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *
     for (j = 0; j < n; j++) {
         skh_keyset_key(&p->ks, rows[j], key);
         gzprintf(p->gz, "%s\t%d\t%d\t%d\t%d\t%s\n", name, p->h1, p->i1, p->h2, p->i2, key);
+        if (p->cov) skc_add_hit(p->cov, name, p->h1, p->h2, rows[j]);
     }
 }
 
@@ -498,6 +501,12 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
         gzprintf(p[s].gz, "#%s\ttotal_reads_evaluated\t%lld\n", f1, reads);
         gzprintf(p[s].gz, "#%s\ttotal_genome_kmers\t%lld\n", f1, (long long)p[s].ks.nrows);
         gzprintf(p[s].gz, "#%s\ttotal_genome_informative_kmers\t%lld\n", f1, (long long)p[s].genome_inf);
+        if (p[s].cov) {
+            skc_add_trailer(p[s].cov, f1, "total_kmer_evaluated", (int64_t)evaluated);
+            skc_add_trailer(p[s].cov, f1, "total_reads_evaluated", (int64_t)reads);
+            skc_add_trailer(p[s].cov, f1, "total_genome_kmers", (int64_t)p[s].ks.nrows);
+            skc_add_trailer(p[s].cov, f1, "total_genome_informative_kmers", (int64_t)p[s].genome_inf);
+        }
     }
     status = 0;
 done:
@@ -684,7 +693,34 @@ static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a,
     for (i = 0; i < p->ks.nrows; i++) if (p->type[i] == SD_INFORMATIVE) p->genome_inf++;
     p->gz = gzopen(o, "wb9");
     if (!p->gz) { fprintf(err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
+    p->o_path = strdup(o);
     return 0;
+}
+
+/* --coverage-depth: where the table of strain p goes, and the accumulator that collects it */
+static int sd_coverage_open(sd_prog *p, const char *explicit_path, int64_t min_hits)
+{
+    if (explicit_path && *explicit_path) p->cov_path = strdup(explicit_path);
+    else {
+        const size_t n = strlen(p->o_path);
+        p->cov_path = (char *)malloc(n + 32);
+        strcpy(p->cov_path, p->o_path);
+        if (n >= 13 && !strcmp(p->cov_path + n - 13, ".kmer_hits.gz")) p->cov_path[n - 13] = 0;
+        strcat(p->cov_path, ".coverage_depth");
+    }
+    p->cov = skc_create(min_hits);
+    return p->cov ? 0 : 1;
+}
+
+static int sd_coverage_write(sd_prog *p)
+{
+    FILE *f;
+    int rc;
+    if (!p->cov) return 0;
+    if (!(f = fopen(p->cov_path, "w"))) { fprintf(p->err, "strain_detect: could not write %s\n", p->cov_path); return 1; }
+    rc = skc_report(p->cov, p->ctx, p->o_path, f, p->err);
+    fclose(f);
+    return rc;
 }
 
 static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *g, const char *o, int device, FILE *out, FILE *err)
@@ -700,7 +736,8 @@ static void sd_strain_close(sd_prog *p)
     if (p->gz) gzclose(p->gz);
     if (p->ctx) sk_ctx_destroy(p->ctx);
     skh_keyset_free(&p->ks);
-    free(p->type); free(p->copy_rows); free(p->hitbuf); free(p->tallybuf);
+    free(p->type); free(p->copy_rows); free(p->hitbuf); free(p->tallybuf); free(p->cov_path); free(p->o_path);
+    skc_destroy(p->cov);
     memset(p, 0, sizeof *p);
 }
 
@@ -746,11 +783,28 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
 int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
 {
     const char *a = NULL, *r = NULL, *b = NULL, *b2 = NULL, *B = NULL, *tt = NULL, *g = NULL, *o = NULL, *S = NULL, *env;
-    int c, mode = SD_SE, status = 1, device = 0, n_S = 0;
+    int c, j, mode = SD_SE, status = 1, device = 0, n_S = 0, want_cov = 0;
+    const char *cov_file = NULL;
+    long long cov_min = 1;
     double t_begin = 0;
     sd_prog *p = NULL;
     char **paths = NULL;
     uint32_t ns = 0, s;
+
+    /* Extension (not in the reference): "--coverage-depth[=FILE]" also writes the table that
+     * scripts/coverage_depth.py -k <outfile> [-m N] would print (step 4 of the workflow), collected while the
+     * hits are emitted; default FILE = outfile with ".kmer_hits.gz" replaced by ".coverage_depth".
+     * "--min-kmer-hits N" is that script's -m.  Taken out of argv before getopt. */
+    for (c = 1, j = 1; c < argc; c++) {
+        if (!strncmp(argv[c], "--coverage-depth", 16) && (argv[c][16] == 0 || argv[c][16] == '=')) {
+            want_cov = 1;
+            cov_file = argv[c][16] ? argv[c] + 17 : NULL;
+            continue;
+        }
+        if (!strcmp(argv[c], "--min-kmer-hits") && c + 1 < argc) { cov_min = atoll(argv[++c]); continue; }
+        argv[j++] = argv[c];
+    }
+    argc = j;
 
     optind = 1;
     while ((c = getopt(argc, argv, "g:r:a:A:b:c:B:S:M:o:t:Hhuspn")) != -1) {
@@ -859,7 +913,11 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
         if (sd_strain_open(&p[0], r, a, g, o, device, out, err)) goto done;
     }
     t_setup = now_s() - t_begin;
+    for (s = 0; want_cov && s < ns; s++)
+        if (sd_coverage_open(&p[s], S ? NULL : cov_file, cov_min)) goto done;
     if (sd_run(p, ns, B, b, b2, mode, out, err)) goto done;
+    for (s = 0; s < ns; s++)
+        if (sd_coverage_write(&p[s])) goto done;
     status = 0;
 done:
     if (getenv("SK_SD_TIMING"))

@@ -3,6 +3,7 @@
 #ifndef SK_INTERNAL_H
 #define SK_INTERNAL_H
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/strainer_kmer.h"
 #ifdef __cplusplus
 extern "C" {
@@ -13,6 +14,13 @@ int sk_ctx_device_(const sk_ctx *ctx);
 /* column `col` of the resident counters, in the caller's row order, into a device buffer of nrows u32;
  * complete on return */
 int sk_counts_rows_to_device_(sk_ctx *ctx, uint32_t col, uint32_t *d_out);
+/* coverage/depth accumulator of sk_host_cov.c, fed by strain_detect when steps 3 and 4 are fused */
+typedef struct skc_acc skc_acc;
+skc_acc *skc_create(int64_t min_hits);
+void skc_destroy(skc_acc *a);
+int skc_add_hit(skc_acc *a, const char *metagenome, int64_t hits_pe1, int64_t hits_pe2, uint32_t row);
+int skc_add_trailer(skc_acc *a, const char *metagenome, const char *name, int64_t value);
+int skc_report(skc_acc *a, sk_ctx *ctx, const char *hits_file_name, FILE *out, FILE *err);
 #ifdef __cplusplus
 }
 #endif

@@ -82,8 +82,28 @@ def test_bundled_steps_3_and_4(golden, tmp_path):
     nm = "Bacteroides_ovatus_1001283st1_B8_1001283B150210_160208.kmer_hits.gz"
     argv = list(facts["argv"])
     argv[argv.index("-o") + 1] = str(tmp_path / nm)
-    p = subprocess.run([sk.cli_path("strain_detect")] + argv, cwd=b, capture_output=True)
+    p = subprocess.run([sk.cli_path("strain_detect")] + argv + ["--coverage-depth"], cwd=b, capture_output=True)
     assert p.returncode == 0, p.stderr.decode()[-500:]
     q = subprocess.run([sk.cli_path("coverage_depth"), "-k", str(tmp_path / nm)], capture_output=True)
     want = open(os.path.join(COV_CASES, "bundled_step4", "expected.stdout"), "rb").read()
     assert (q.returncode, q.stdout) == (0, want)
+    # fused 3 -> 4: the table written next to the hit list while the hits were emitted
+    assert open(tmp_path / nm.replace(".kmer_hits.gz", ".coverage_depth"), "rb").read() == want
+
+
+@pytest.mark.parametrize("name,extra", [("batch", []), ("batch", ["--min-kmer-hits", "3"]), ("cli_pe", []), ("background", [])])
+def test_fused_coverage_equals_separate_step(golden, tmp_path, name, extra):
+    """strain_detect --coverage-depth == coverage_depth -k <its own -o file> on the strain_detect goldens
+    (short reads that re-emit hits, PE/PEI, the same metagenome listed under two paths)."""
+    d = os.path.join(golden, "sd_cases", name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    argv = list(meta["argv"])
+    hits = str(tmp_path / "Genus_species_st1.kmer_hits.gz")
+    argv[argv.index("-o") + 1] = hits
+    cov = str(tmp_path / "fused.tsv")
+    p = subprocess.run([sk.cli_path("strain_detect")] + argv + ["--coverage-depth=" + cov] + extra, cwd=d, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    m = ["-m", extra[1]] if extra else []
+    q = subprocess.run([sk.cli_path("coverage_depth"), "-k", hits] + m, capture_output=True)
+    assert q.returncode == 0 and q.stdout.count(b"\n") >= 2
+    assert open(cov, "rb").read() == q.stdout

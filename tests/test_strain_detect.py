@@ -185,7 +185,7 @@ def test_sd_many_strains_in_one_pass_equal_separate_runs(tmp_path):
     and one of the separate runs is checked against the oracle."""
     n = _make_multi_inputs(tmp_path)
     exe = sk.cli_path("strain_detect")
-    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt")], capture_output=True)
+    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt"), "--coverage-depth"], capture_output=True)
     assert multi.returncode == 0, multi.stderr.decode()[-500:]
     assert multi.stdout == b"unknown file type skipping line (#comment)\nunknown file type skipping line (XX)\n"
     for s in range(n):
@@ -195,6 +195,8 @@ def test_sd_many_strains_in_one_pass_equal_separate_runs(tmp_path):
         a = gzip.open(tmp_path / f"single{s}.gz", "rb").read()
         b = gzip.open(tmp_path / f"multi{s}.gz", "rb").read()
         assert a == b and a.count(b"\n") > 1000
+        cov = subprocess.run([sk.cli_path("coverage_depth"), "-k", str(tmp_path / f"multi{s}.gz")], capture_output=True)
+        assert cov.returncode == 0 and cov.stdout == open(tmp_path / f"multi{s}.gz.coverage_depth", "rb").read()
     ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / "s1.fa"), "-a", str(tmp_path / "s1.inf.gz"), "-B", str(tmp_path / "B.txt"),
                                      "-o", str(tmp_path / "oracle1.gz")], str(tmp_path))
     assert ora.returncode == 0

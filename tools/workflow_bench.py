@@ -66,7 +66,12 @@ def run_set(tag, step1, step2, step3, step4, work, out, fused=None):
         f2 = os.path.join(work, tag, "fused.gz")
         r["steps1+2_fused_s"] = pipe_gz([step1, "-r", STRAIN, "-A", "genomes_to_scrub.txt", "-B", "metagenomes_to_scrub.txt", "--scrub", "0.01"], f2)
         r["md5_fused"] = md5_gz(f2)
-        r["total_fused_s"] = r["steps1+2_fused_s"] + r["step3_detect_s"] + r["step4_coverage_s"]
+        cov2 = os.path.join(work, tag, NM + ".coverage_depth")
+        hits2 = os.path.join(work, tag, "f", NM + ".kmer_hits.gz")
+        os.makedirs(os.path.dirname(hits2))
+        r["steps3+4_fused_s"] = timed([step3, "-r", STRAIN, "-a", f2, "-B", "target_metagenomes.txt", "-o", hits2, "--coverage-depth=" + cov2])
+        r["md5_fused_coverage"] = hashlib.md5(open(cov2, "rb").read()).hexdigest()
+        r["total_fused_s"] = r["steps1+2_fused_s"] + r["steps3+4_fused_s"]
     out[tag] = r
 
 
@@ -86,7 +91,7 @@ def main():
     for tag, r in out.items():
         if isinstance(r, dict):
             r["outputs_match_reference"] = all(r[k] == v for k, v in want.items()) and r["md5_coverage"] == want_cov and \
-                r.get("md5_fused", want["md5_scrubbed"]) == want["md5_scrubbed"]
+                r.get("md5_fused", want["md5_scrubbed"]) == want["md5_scrubbed"] and r.get("md5_fused_coverage", want_cov) == want_cov
     print(json.dumps(out, indent=1))
 
 
