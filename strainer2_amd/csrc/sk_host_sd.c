@@ -410,7 +410,7 @@ static void pool_stop(sd_pool *pl)
 static int pool_replay(sd_pool *pl, sd_prog *p, uint32_t ns, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb,
                        uint32_t b0, uint32_t astep, uint32_t n, int have_copy)
 {
-    if (pl->nth == 0 || n < 64) {
+    if (pl->nth == 0 || n < 2) {
         uint32_t s;
         int hc = have_copy;
         for (s = 0; s < ns; s++) { hc = have_copy; sd_replay_run(&p[s], s, f1, ca, a0, cb, b0, astep, n, &hc); }

@@ -1,0 +1,130 @@
+/* sd_sanitize.c -- runs the HOST side of strain_detect (strainer2_amd/csrc/sk_host_sd.c: reader threads,
+ * chunk queue, the replay of the reference's read-pair bookkeeping, the per-strain thread pool, the fused
+ * coverage table; plus sk_host.c and sk_host_cov.c underneath) under AddressSanitizer/UBSan and under
+ * ThreadSanitizer on the CPU.  The device entry points are not linked; a plain-C test double stands in
+ * for them: a sorted array of the packed keys and a byte-wise window walk.  TEST CODE only -- the product's
+ * lookups are the HIP kernels.  Wide (non-ACGT) strain keys and the -g background scan are outside the
+ * double.  Built and run by tests/test_sanitizers.py on the strain_detect goldens. */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/strainer_kmer.h"
+#include "../../strainer2_amd/csrc/sk_common.h"
+
+struct sk_ctx { uint64_t *key; uint32_t *row; uint32_t n, ncols; uint32_t *cols; const struct sk_batch *inflight; uint32_t type_col, inf_value; uint64_t cap; };
+struct sk_batch { uint8_t *bytes; uint64_t nbytes; uint32_t *start; uint32_t nrec; };
+
+static int die(const char *what) { fprintf(stderr, "device call %s is outside the test double\n", what); abort(); return -1; }
+const char *sk_strerror(int c) { (void)c; return "stub"; }
+const char *sk_last_error(const sk_ctx *c) { (void)c; return "stub"; }
+int sk_ctx_create(sk_ctx **o, int d) { (void)d; *o = calloc(1, sizeof **o); return *o ? SK_OK : SK_E_NOMEM; }
+void sk_ctx_destroy(sk_ctx *c) { if (c) { free(c->key); free(c->row); free(c->cols); free(c); } }
+uint32_t sk_table_rows(const sk_ctx *c) { return c->n; }
+uint32_t sk_table_cols(const sk_ctx *c) { return c->ncols; }
+
+typedef struct { uint64_t k; uint32_t r; } kr;
+static int kr_cmp(const void *a, const void *b) { const kr *x = a, *y = b; return x->k < y->k ? -1 : x->k > y->k; }
+int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t n, uint32_t ncols, const uint32_t *loc)
+{
+    kr *t = malloc((n + 1) * sizeof *t);
+    uint32_t i;
+    (void)loc;
+    for (i = 0; i < n; i++) { t[i].k = keys[i]; t[i].r = i; }
+    qsort(t, n, sizeof *t, kr_cmp);
+    c->key = malloc((n + 1) * 8); c->row = malloc((n + 1) * 4); c->cols = calloc((size_t)n * ncols + 1, 4);
+    for (i = 0; i < n; i++) { c->key[i] = t[i].k; c->row[i] = t[i].r; }
+    c->n = n; c->ncols = ncols;
+    free(t);
+    return SK_OK;
+}
+int sk_table_load_wide(sk_ctx *c, const char *k, const uint32_t *r, uint32_t n) { (void)c; (void)k; (void)r; return n ? die("sk_table_load_wide") : SK_OK; }
+int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in) { memcpy(c->cols + (size_t)col * c->n, in, (size_t)c->n * 4); return SK_OK; }
+int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out) { memcpy(out, c->cols + (size_t)col * c->n, (size_t)c->n * 4); return SK_OK; }
+
+static int64_t find(const sk_ctx *c, uint64_t k)
+{
+    uint32_t lo = 0, hi = c->n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (c->key[mid] < k) lo = mid + 1; else hi = mid; }
+    return lo < c->n && c->key[lo] == k ? (int64_t)c->row[lo] : -1;
+}
+
+int sk_batch_create(sk_ctx *c, sk_batch **out) { (void)c; *out = calloc(1, sizeof **out); return *out ? SK_OK : SK_E_NOMEM; }
+void sk_batch_destroy(sk_batch *b) { if (b) { free(b->bytes); free(b->start); free(b); } }
+int sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec)
+{
+    free(b->bytes); free(b->start);
+    b->bytes = malloc(nbytes); memcpy(b->bytes, stream, nbytes);
+    b->start = malloc((size_t)nrec * 4); memcpy(b->start, rec_start, (size_t)nrec * 4);
+    b->nbytes = nbytes; b->nrec = nrec;
+    return SK_OK;
+}
+int sk_tally_launch(sk_ctx *c, const sk_batch *b, uint32_t type_col, uint32_t inf_value, uint64_t cap)
+{
+    c->inflight = b; c->type_col = type_col; c->inf_value = inf_value; c->cap = cap;
+    return SK_OK;
+}
+int sk_tally_collect(sk_ctx *c, uint32_t *tally, sk_hit *hits, uint64_t *nhits)
+{
+    const sk_batch *b = c->inflight;
+    uint64_t nh = 0;
+    uint32_t r;
+    const uint32_t *type = c->cols + (size_t)c->type_col * c->n;
+    for (r = 0; r < b->nrec; r++) {
+        const uint64_t beg = b->start[r], end = r + 1 < b->nrec ? b->start[r + 1] : b->nbytes;
+        uint64_t f = 0, i;
+        uint32_t run = 0, h = 0, inf = 0;
+        for (i = beg; i < end; i++) {
+            const uint8_t ch = b->bytes[i];
+            if (!sk_is_acgt(ch)) { run = 0; continue; }
+            f = ((f << 2) | sk_code(ch)) & ((1ull << 62) - 1);
+            if (++run >= 31) {
+                const uint64_t rc = sk_revcomp62(f);
+                const int64_t row = find(c, f > rc ? f : rc);
+                if (row >= 0) {
+                    h++;
+                    if (type[row] == c->inf_value) { if (nh < c->cap) { hits[nh].pos = (uint32_t)(i - 30); hits[nh].row = (uint32_t)row; } nh++; inf++; }
+                }
+            }
+        }
+        tally[2 * r] = h; tally[2 * r + 1] = inf;
+    }
+    *nhits = nh;
+    return SK_OK;
+}
+int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec, uint32_t type_col,
+                   uint32_t inf_value, uint32_t *tally, sk_hit *hits, uint64_t cap, uint64_t *nhits)
+{
+    sk_batch b;
+    int rc;
+    b.bytes = (uint8_t *)stream; b.nbytes = nbytes; b.start = (uint32_t *)rec_start; b.nrec = nrec;
+    sk_tally_launch(c, &b, type_col, inf_value, cap);
+    rc = sk_tally_collect(c, tally, hits, nhits);
+    return rc;
+}
+int sk_distinct_count(sk_ctx *ctx, const uint64_t *keys, const uint32_t *sample, uint64_t n, uint32_t ns, uint64_t *uniq, uint64_t *total)
+{
+    uint64_t i, j;
+    (void)ctx;
+    memset(uniq, 0, (size_t)ns * 8); memset(total, 0, (size_t)ns * 8);
+    for (i = 0; i < n; i++) {
+        int seen = 0;
+        total[sample[i]]++;
+        for (j = 0; j < i && !seen; j++) seen = keys[j] == keys[i] && sample[j] == sample[i];
+        uniq[sample[i]] += !seen;
+    }
+    return SK_OK;
+}
+/* parts of the ABI that sk_host.c references but strain_detect without -g never reaches */
+int sk_scan_stream(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col) { (void)c; (void)s; (void)n; (void)col; return die("sk_scan_stream"); }
+int sk_comm_init(sk_ctx *c, int r, int w, const char *f, int t) { (void)c; (void)r; (void)w; (void)f; (void)t; return die("sk_comm_init"); }
+int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s) { (void)c; (void)v; (void)s; return die("sk_comm_sum_u32"); }
+int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return die("sk_counts_zero"); }
+int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return die("sk_counts_allreduce"); }
+int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t n) { (void)c; (void)p; (void)n; return die("sk_pinned_alloc"); }
+int sk_pinned_free(sk_ctx *c, void *p) { (void)c; (void)p; return die("sk_pinned_free"); }
+int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64_t *t) { (void)c; (void)s; (void)n; (void)col; (void)t; return die("sk_scan_pinned"); }
+int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return die("sk_ticket_wait"); }
+int skh_scrub_filter_resident(sk_ctx *c, const skh_keyset *k, int d, double m, int i, FILE *o, FILE *e) { (void)c; (void)k; (void)d; (void)m; (void)i; (void)o; (void)e; return die("skh_scrub_filter_resident"); }
+
+int main(int argc, char **argv) { return skh_strain_detect_main(argc, argv, stdout, stderr); }

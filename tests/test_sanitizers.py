@@ -100,3 +100,60 @@ def test_coverage_host_logic_under_asan_ubsan(cov_host_exe, name):
     assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
     assert p.returncode == meta["returncode"], p.stderr.decode()[-2000:]
     assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+
+
+SD_DIR = os.path.join(REPO, "tests", "golden", "sd_cases")
+SD_SOURCES = [os.path.join(REPO, "tests", "native", "sd_sanitize.c")] + \
+    [os.path.join(REPO, "strainer2_amd", "csrc", f) for f in ("sk_host.c", "sk_host_sd.c", "sk_host_cov.c")]
+
+
+@pytest.fixture(scope="module", params=["address,undefined", "thread"])
+def sd_host_exe(request, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("sd") / ("sd_" + request.param.split(",")[0]))
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=" + request.param, "-fno-omit-frame-pointer"] + SD_SOURCES +
+                   ["-lz", "-lpthread", "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("name", ["batch", "cli_se", "cli_pe", "cli_pei", "cli_default", "err_missing", "err_type",
+                                  "err_pe_one_file", "err_b_and_B", "err_no_inf", "err_no_read1"])
+def test_strain_detect_host_logic_under_sanitizers(sd_host_exe, name, tmp_path):
+    """reader threads, chunk queue, replay, thread pool and the fused coverage table of strain_detect under
+    ASan+UBSan and under TSan, with a CPU test double for the device calls; outputs against the reference's."""
+    import gzip
+    d = os.path.join(SD_DIR, name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    argv = list(meta["argv"])
+    if "-o" in argv:
+        argv[argv.index("-o") + 1] = str(tmp_path / "a_b_c.kmer_hits.gz")
+        argv += ["--coverage-depth"]
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4")
+    p = subprocess.run([sd_host_exe] + argv, cwd=d, env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in p.stderr, p.stderr.decode()[-3000:]
+    assert p.returncode == meta["returncode"], p.stderr.decode()[-2000:]
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+    assert p.stderr == open(os.path.join(d, "expected.stderr"), "rb").read()
+    if meta["returncode"] == 0:
+        assert gzip.open(tmp_path / "a_b_c.kmer_hits.gz", "rb").read() == open(os.path.join(d, "expected.hits"), "rb").read()
+        assert open(tmp_path / "a_b_c.coverage_depth", "rb").read().startswith(b"strain_name\t")
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_strain_detect_many_strains_host_logic_under_sanitizers(san, tmp_path):
+    """-S with four strains (the thread pool is in use): every output equals the single-strain golden"""
+    import gzip
+    exe = str(tmp_path / "sd_multi")
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=" + san, "-fno-omit-frame-pointer"] + SD_SOURCES + ["-lz", "-lpthread", "-o", exe], check=True)
+    d = os.path.join(SD_DIR, "batch")
+    with open(tmp_path / "strains.txt", "w") as f:
+        for s in range(4):
+            f.write(f"strain.fa\tinf.txt.gz\t{tmp_path}/o{s}.gz\n")
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4")
+    p = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", "B.txt", "--coverage-depth"], cwd=d, env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in p.stderr, p.stderr.decode()[-3000:]
+    assert p.returncode == 0
+    want = open(os.path.join(d, "expected.hits"), "rb").read()
+    for s in range(4):
+        assert gzip.open(tmp_path / f"o{s}.gz", "rb").read() == want
