@@ -1,10 +1,14 @@
-/* sd_sanitize.c -- runs the HOST side of strain_detect (strainer2_amd/csrc/sk_host_sd.c: reader threads,
- * chunk queue, the replay of the reference's read-pair bookkeeping, the per-strain thread pool, the fused
- * coverage table; plus sk_host.c and sk_host_cov.c underneath) under AddressSanitizer/UBSan and under
- * ThreadSanitizer on the CPU.  The device entry points are not linked; a plain-C test double stands in
- * for them: a sorted array of the packed keys and a byte-wise window walk.  TEST CODE only -- the product's
- * lookups are the HIP kernels.  Wide (non-ACGT) strain keys and the -g background scan are outside the
- * double.  Built and run by tests/test_sanitizers.py on the strain_detect goldens. */
+/* device_double.c -- runs the HOST side of the programs under AddressSanitizer/UBSan and under
+ * ThreadSanitizer on the CPU:
+ *   -DDOUBLE_MAIN=skh_strain_detect_main     sk_host_sd.c: reader threads, chunk queue, the replay of the
+ *                                            reference's read-pair bookkeeping, the per-strain thread pool,
+ *                                            the fused coverage table (+ sk_host.c, sk_host_cov.c)
+ *   -DDOUBLE_MAIN=skh_kmer_scrub_count_main  sk_host.c: key-set build, order replay, the decode thread pool
+ *                                            with its pinned double buffers and tickets, the table print
+ * The device entry points are not linked; a plain-C test double stands in for them: a sorted array of the
+ * packed keys and a byte-wise window walk.  TEST CODE only -- the product's lookups are the HIP kernels.
+ * Wide (non-ACGT) strain keys, reads with U, RCCL and the scrub filter are outside the double.
+ * Built and run by tests/test_sanitizers.py. */
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -115,16 +119,37 @@ int sk_distinct_count(sk_ctx *ctx, const uint64_t *keys, const uint32_t *sample,
     }
     return SK_OK;
 }
-/* parts of the ABI that sk_host.c references but strain_detect without -g never reaches */
-int sk_scan_stream(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col) { (void)c; (void)s; (void)n; (void)col; return die("sk_scan_stream"); }
+/* the counting scan: every window of the record stream that is a key bumps counts[col][row] */
+static pthread_mutex_t scan_mu = PTHREAD_MUTEX_INITIALIZER;
+int sk_scan_stream(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col)
+{
+    uint64_t f = 0, i;
+    uint32_t run = 0, *cnt = c->cols + (size_t)col * c->n;
+    pthread_mutex_lock(&scan_mu);
+    for (i = 0; i < n; i++) {
+        if (!sk_is_acgt(s[i])) { run = 0; continue; }
+        f = ((f << 2) | sk_code(s[i])) & ((1ull << 62) - 1);
+        if (++run >= 31) {
+            const uint64_t rc = sk_revcomp62(f);
+            const int64_t row = find(c, f > rc ? f : rc);
+            if (row >= 0) cnt[row]++;
+        }
+    }
+    pthread_mutex_unlock(&scan_mu);
+    return SK_OK;
+}
+int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t n) { (void)c; *p = malloc(n); return *p ? SK_OK : SK_E_NOMEM; }
+int sk_pinned_free(sk_ctx *c, void *p) { (void)c; free(p); return SK_OK; }
+int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64_t *t) { if (t) *t = 1; return sk_scan_stream(c, s, n, col); }
+int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return SK_OK; }
+int sk_sync(sk_ctx *c) { (void)c; return SK_OK; }
 int sk_comm_init(sk_ctx *c, int r, int w, const char *f, int t) { (void)c; (void)r; (void)w; (void)f; (void)t; return die("sk_comm_init"); }
 int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s) { (void)c; (void)v; (void)s; return die("sk_comm_sum_u32"); }
 int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return die("sk_counts_zero"); }
 int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return die("sk_counts_allreduce"); }
-int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t n) { (void)c; (void)p; (void)n; return die("sk_pinned_alloc"); }
-int sk_pinned_free(sk_ctx *c, void *p) { (void)c; (void)p; return die("sk_pinned_free"); }
-int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64_t *t) { (void)c; (void)s; (void)n; (void)col; (void)t; return die("sk_scan_pinned"); }
-int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return die("sk_ticket_wait"); }
 int skh_scrub_filter_resident(sk_ctx *c, const skh_keyset *k, int d, double m, int i, FILE *o, FILE *e) { (void)c; (void)k; (void)d; (void)m; (void)i; (void)o; (void)e; return die("skh_scrub_filter_resident"); }
 
-int main(int argc, char **argv) { return skh_strain_detect_main(argc, argv, stdout, stderr); }
+#ifndef DOUBLE_MAIN
+#define DOUBLE_MAIN skh_strain_detect_main
+#endif
+int main(int argc, char **argv) { return DOUBLE_MAIN(argc, argv, stdout, stderr); }

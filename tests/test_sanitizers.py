@@ -103,7 +103,7 @@ def test_coverage_host_logic_under_asan_ubsan(cov_host_exe, name):
 
 
 SD_DIR = os.path.join(REPO, "tests", "golden", "sd_cases")
-SD_SOURCES = [os.path.join(REPO, "tests", "native", "sd_sanitize.c")] + \
+SD_SOURCES = [os.path.join(REPO, "tests", "native", "device_double.c")] + \
     [os.path.join(REPO, "strainer2_amd", "csrc", f) for f in ("sk_host.c", "sk_host_sd.c", "sk_host_cov.c")]
 
 
@@ -157,3 +157,54 @@ def test_strain_detect_many_strains_host_logic_under_sanitizers(san, tmp_path):
     want = open(os.path.join(d, "expected.hits"), "rb").read()
     for s in range(4):
         assert gzip.open(tmp_path / f"o{s}.gz", "rb").read() == want
+
+
+@pytest.fixture(scope="module", params=["address,undefined", "thread"])
+def ks_host_exe(request, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("ks") / ("ks_" + request.param.split(",")[0]))
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=" + request.param, "-fno-omit-frame-pointer", "-DDOUBLE_MAIN=skh_kmer_scrub_count_main"] +
+                   SD_SOURCES + ["-lz", "-lpthread", "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("name", ["truncated_fastq", "contig30", "missing_in_list", "missing_flag"])
+def test_kmer_scrub_count_host_logic_under_sanitizers(ks_host_exe, golden, name, tmp_path):
+    """kmer_scrub_count's host half (key-set build, order replay, decode thread pool with its double buffers,
+    table print) under ASan+UBSan and TSan with the CPU test double, against the reference's output"""
+    d = os.path.join(golden, "cases", name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4")
+    p = subprocess.run([ks_host_exe] + meta["argv"], cwd=d, env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in p.stderr, p.stderr.decode()[-3000:]
+    assert p.returncode == meta["returncode"]
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+    assert p.stderr == open(os.path.join(d, "expected.stderr"), "rb").read()
+
+
+def test_kmer_scrub_count_thread_pool_under_sanitizers(ks_host_exe, tmp_path):
+    """24 list files over 4 decode threads: same table as the oracle program"""
+    import random
+    rng = random.Random(5)
+    strain = "".join(rng.choice("ACGT") for _ in range(20000))
+    (tmp_path / "s.fa").write_text(">s\n" + strain + "\n")
+    names = []
+    for i in range(24):
+        recs = []
+        for j in range(rng.randrange(1, 400)):
+            a = rng.randrange(0, len(strain) - 200)
+            recs.append(f">r{j}\n{strain[a:a + rng.randrange(20, 200)]}\n")
+        (tmp_path / f"m{i}.fa").write_text("".join(recs))
+        names.append(f"m{i}.fa")
+    (tmp_path / "A.txt").write_text("\n".join(names[:5]) + "\n")
+    (tmp_path / "B.txt").write_text("\n".join(names) + "\n")
+    argv = ["-r", "s.fa", "-A", "A.txt", "-B", "B.txt"]
+    oracle = os.path.join(REPO, "oracle", "kso_oracle")
+    if not os.path.exists(oracle):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "kso_oracle"], check=True, stdout=subprocess.DEVNULL)
+    want = subprocess.run([oracle] + argv, cwd=tmp_path, capture_output=True)
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4")
+    p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in p.stderr, p.stderr.decode()[-3000:]
+    assert (p.returncode, p.stdout) == (want.returncode, want.stdout) and want.returncode == 0
