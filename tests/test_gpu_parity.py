@@ -5,6 +5,7 @@ import json
 import os
 import random
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -372,3 +373,11 @@ def test_scan_pinned_equals_scan_stream(ctx):
     assert len(tickets) > 5
     assert np.array_equal(ctx.counts(1), ctx.counts(2)) and int(ctx.counts(1).sum()) > 10000
     ctx.pinned_free(buf)
+
+
+def test_rccl_allreduce_on_the_counter_block_single_rank(repo):
+    """torch.distributed (backend nccl = RCCL) all-reduce running directly on the library's device counters,
+    as bench.py --gpus N does: world of one, counts unchanged (tools/nccl_single_rank_check.py)"""
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "nccl_single_rank_check.py")], cwd=repo,
+                       capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT="29561"))
+    assert p.returncode == 0 and b"all-reduce on the library's counter block: ok" in p.stdout, p.stderr.decode()[-800:]
