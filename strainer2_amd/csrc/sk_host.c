@@ -28,6 +28,7 @@
 #include "sk_common.h"
 
 #include "sk_parser.h"
+#include "sk_ctxjob.h"
 
 /* run a whole (possibly gzipped) file through the parser */
 static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords, int *sink_rc)
@@ -738,6 +739,8 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     int device = env_int("SK_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", 0);
     const int use_comm = world > 1 || getenv("SK_FORCE_COMM") != NULL;
     uint32_t nfailed = 0;
+    sk_ctxjob cj;
+    int crc;
     double scrub_fraction = -1.0;                    /* >= 0: print the scrub filter's result instead of the table */
     int scrub_independent = 0, j;
 
@@ -783,15 +786,16 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
 
     memset(&ks, 0, sizeof ks);
+    sk_ctxjob_start(&cj, device);                      /* the HIP runtime comes up while the key set is built */
     rc = skh_keyset_from_file(&ks, R, SK_REF_TABLE_SLOTS, 1, 1);
+    crc = sk_ctxjob_join(&cj, &ctx);
     if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", R); goto done; }
     if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s\n", sk_strerror(rc)); goto done; }
     if (ks.short_records && rank == 0)
         fprintf(err, "kmer_scrub_count: skipped %llu reference record(s) shorter than %d bases "
                      "(the original program crashes on these)\n", (unsigned long long)ks.short_records, SK_K - 1);
 
-    rc = sk_ctx_create(&ctx, device);
-    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); goto done; }
+    if (crc != SK_OK) { fprintf(err, "kmer_scrub_count: cannot use HIP device %d: %s\n", device, sk_strerror(crc)); goto done; }
     if (use_comm) {
         char path[256];
         if ((env = getenv("SK_RCCL_ID_FILE")) != NULL) snprintf(path, sizeof path, "%s", env);

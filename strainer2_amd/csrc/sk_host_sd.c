@@ -27,6 +27,7 @@
 #include "sk_common.h"
 #include "sk_parser.h"
 #include "sk_internal.h"
+#include "sk_ctxjob.h"
 
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
 enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
@@ -37,6 +38,7 @@ enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     sk_ctx     *ctx;
+    int         ctx_rc;        /* status of a context opened in the background (0 = fine or not tried) */
     skh_keyset  ks;
     uint32_t   *type;          /* host copy of the type column */
     FILE       *out, *err;
@@ -673,7 +675,7 @@ static void *sd_keyset_pool_thread(void *arg)
 }
 
 static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a, const char *g, const char *o, int device)
-{
+{   /* p->ctx may already hold a context opened in the background (single-strain start-up) */
     unsigned n_inform = 0, i;
     int rc = ks_rc;
     FILE *err = p->err;
@@ -682,7 +684,7 @@ static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a,
     if (p->ks.short_records)
         fprintf(err, "strain_detect: skipped %llu reference record(s) shorter than %d bases "
                      "(the original program crashes on these)\n", (unsigned long long)p->ks.short_records, SK_K - 1);
-    rc = sk_ctx_create(&p->ctx, device);
+    rc = p->ctx ? SK_OK : (p->ctx_rc ? p->ctx_rc : sk_ctx_create(&p->ctx, device));
     if (rc != SK_OK) { fprintf(err, "strain_detect: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); return 1; }
     rc = skh_keyset_load(p->ctx, &p->ks, SD_NCOLS);
     if (rc != SK_OK) { fprintf(err, "strain_detect: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
@@ -725,10 +727,15 @@ static int sd_coverage_write(sd_prog *p)
 
 static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *g, const char *o, int device, FILE *out, FILE *err)
 {
+    sk_ctxjob cj;
+    int ks_rc;
     memset(p, 0, sizeof *p);
     p->out = out;
     p->err = err;
-    return sd_strain_finish(p, skh_keyset_from_file(&p->ks, r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0), r, a, g, o, device);
+    sk_ctxjob_start(&cj, device);                        /* the HIP runtime comes up while the key set is built */
+    ks_rc = skh_keyset_from_file(&p->ks, r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0);
+    p->ctx_rc = sk_ctxjob_join(&cj, &p->ctx);
+    return sd_strain_finish(p, ks_rc, r, a, g, o, device);
 }
 
 static void sd_strain_close(sd_prog *p)
