@@ -78,6 +78,28 @@ SK_HD uint32_t sk_khash(uint64_t key)
 SK_HD uint32_t sk_filter_block(uint32_t mz, uint32_t shift) { return (mz * 0x9E3779B1u) >> shift; }
 SK_HD uint32_t sk_filter_bits(uint32_t mz) { return mz * 0x85EBCA77u; }
 
+/* ---- grid 16-mers (prefilter of the grid kernel) ----------------------------------------------
+ * Cut the stream into 16-base chunks at multiples of 16.  Every 31-base window contains exactly one
+ * whole chunk (the one starting in its first 16 bases), so the windows are partitioned by "their"
+ * chunk, 16 windows each.  If a window is a strain k-mer, its chunk is a 16-mer of the strain (in one
+ * orientation or the other).  The filter therefore holds the canonical form (min of the packed 16-mer
+ * and its reverse complement) of EVERY 16-mer of every strain key; a chunk that is not in it rules out
+ * its 16 windows with one lookup per 16 bases and no per-base work at all. */
+SK_HD uint32_t sk_revcomp16(uint32_t x)                /* 16 packed bases */
+{
+    uint32_t y = 0;
+    for (int i = 0; i < 16; i++) { y = (y << 2) | (3u - (x & 3u)); x >>= 2; }
+    return y;
+}
+SK_HD uint32_t sk_gmix(uint32_t canon16) { return canon16 ^ (canon16 >> 15); }
+/* level 1 (L2-resident) and level 2 (large) filters: 64-bit blocks, two bits in each 32-bit half */
+/* level 1 may have any number of blocks (it is sized to what the L2 keeps, not to a power of two):
+ * block = high word of hash x nblocks */
+SK_HD uint32_t sk_grid1_block(uint32_t g, uint32_t nblocks) { return (uint32_t)(((uint64_t)(g * 0x9E3779B1u) * nblocks) >> 32); }
+SK_HD uint32_t sk_grid1_bits(uint32_t g) { return g * 0x85EBCA77u; }
+SK_HD uint32_t sk_grid2_block(uint32_t g, uint32_t shift) { return (g * 0xC2B2AE3Du) >> shift; }
+SK_HD uint32_t sk_grid2_bits(uint32_t g) { return g * 0x27D4EB2Fu; }
+
 /* reverse complement of a packed 31-mer */
 SK_HD uint64_t sk_revcomp62(uint64_t key)
 {

@@ -50,6 +50,10 @@
 #define SK_REC_DW       12                  // per record: 8 code words (u32) + 8 invalid masks (u16) = 48 B;
                                             // 12-dword lane stride keeps ds_read_b128 conflict-free
 #define SK_NCHUNK       (SK_NREC * SK_SPAN_CH)
+#ifndef SK_STREAM_POLICY
+#define SK_STREAM_POLICY 0
+#endif
+#define SK_NCHUNK_GRID  (SK_NCHUNK + 1)     // grid kernel: plus the chunk after the tile
 #ifndef SK_PUMP_EVERY
 #define SK_PUMP_EVERY   2                   // windows between two drain sites (power of two <= 16)
 #endif
@@ -75,6 +79,10 @@ struct sk_table_view {
     // two bits in each 32-bit half.
     const uint2    *bloom;
     uint32_t        bloom_shift;     // 32 - log2(number of 64-bit blocks)
+    // grid kernel: Bloom sets of the canonical 16-mers of the strain, a small one for the L2 and a
+    // large one that settles what the small one lets through
+    const uint2    *grid1, *grid2;
+    uint32_t        grid1_blocks, grid2_shift;
 };
 
 __device__ __forceinline__ uint64_t sk_slot_key(const sk_u4 e) { return ((uint64_t)e.y << 32) | e.x; }
@@ -534,6 +542,224 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// THE hot kernel, second generation ("grid"): no per-base work after the decode.
+//
+// The stream is cut into 16-base chunks at multiples of 16.  A 31-base window contains exactly one
+// whole chunk, so the windows are partitioned by chunk, 16 each (the windows ENDING at chunk start
+// + 15 .. + 30).  A workgroup owns the SK_TILE/16 chunks of its tile and all their windows.
+//
+//   phase 1  as before: 16 stream bytes -> one packed code word + a 16-bit "not ACGT" mask in LDS.
+//            A chunk's code word IS its packed 16-mer.
+//   phase 2  per chunk (8 per thread, their filter loads issued together): canonical 16-mer
+//            (min of the word and its reverse complement), one 8-byte load from the L2-resident
+//            level-1 filter "is this 16-mer in the strain at all, in either orientation?".  Reads
+//            unrelated to the strain stop here (~5 % false positives), having cost ~1.5 VALU
+//            operations per base.  Survivors ask the large level-2 filter (false positives ~1e-5).
+//   stage 2  the live windows of the surviving chunks (<= 16 each; liveness from the masks of the
+//            chunk's two neighbours) are queued as tile positions, one thread's chunks after the
+//            other so that consecutive windows sit in consecutive queue slots, and probed 64 at a
+//            time exactly as in sk_scan_main: anchors through the hash, followers through their
+//            anchor's neighbour in strain order, every hit a full 62-bit compare.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sk_grid_test(const uint2 blk, uint32_t bits)
+{
+    const uint32_t t = (blk.x >> (bits >> 27)) & (blk.x >> ((bits >> 22) & 31u)) &
+                       (blk.y >> ((bits >> 17) & 31u)) & (blk.y >> ((bits >> 12) & 31u));
+    return (t & 1u) != 0u;
+}
+
+// invalid mask of chunk c (index into the LDS records: record 0 = the 8 chunks before the tile)
+__device__ __forceinline__ uint32_t sk_chunk_inv(const uint32_t *rec, uint32_t c)
+{
+    return ((const uint16_t *)rec)[(c >> 3) * (2 * SK_REC_DW) + 16 + (c & 7u)];
+}
+
+// the read bases are touched once: keep them from pushing the filter out of the L2
+__device__ __forceinline__ sk_u4 sk_stream_load(const sk_u4 *p)
+{
+#if SK_STREAM_POLICY == 0
+    return __builtin_nontemporal_load(p);
+#elif SK_STREAM_POLICY == 1
+    return *p;
+#else
+    sk_u4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#endif
+}
+
+template <bool TALLY, int ABLATE>
+__global__ __launch_bounds__(SK_THREADS)
+void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
+                  sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t rec[(SK_NREC + 1) * SK_REC_DW];
+    __shared__ uint16_t wq_all[SK_WAVES][SK_WQ];
+
+    const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+
+    // ================= phase 1: bytes -> packed codes + invalid masks ==========================
+    // All of a thread's 16-byte loads are issued before the first is decoded (nine HBM latencies in
+    // flight instead of one after the other); tiles at the ends of the batch take the byte-wise path.
+    uint32_t bad = 0;
+    constexpr int NIT = (SK_NCHUNK_GRID + SK_THREADS - 1) / SK_THREADS;
+    sk_u4 vv[NIT];
+    const bool inside = tile0 >= SK_SPAN && tile0 + SK_TILE + 16u <= nbytes;      // (workgroup-uniform)
+    if (inside) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+            vv[it] = (sk_u4){0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+            if (c < SK_NCHUNK_GRID) vv[it] = sk_stream_load((const sk_u4 *)(stream + (tile0 - SK_SPAN) + (uint64_t)c * 16u));
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {                         // (unrolled: vv must stay in registers)
+            const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+            const int64_t off = (int64_t)tile0 - SK_SPAN + (int64_t)c * 16;
+            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};       // '\n' fill
+            if (c < SK_NCHUNK_GRID)
+                for (int i = 0; i < 16; i++) {
+                    const int64_t p = off + i;
+                    if (p >= 0 && (uint64_t)p < nbytes)
+                        w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
+                }
+            vv[it] = (sk_u4){w[0], w[1], w[2], w[3]};
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+        if (c < SK_NCHUNK_GRID) {
+            const sk_u4 v = vv[it];
+            uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+            sk_decode4(v.x, c0, i0);
+            sk_decode4(v.y, c1, i1);
+            sk_decode4(v.z, c2, i2);
+            sk_decode4(v.w, c3, i3);
+            const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+            // bytes of the chunk after the tile belong to the next tile, which reports them itself
+            if (c < SK_NCHUNK) bad |= sk_chunk_has_odd_byte(v, inv16);
+            const uint32_t r = c >> 3, sl = c & 7u;
+            rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+            ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
+        }
+    }
+    __syncthreads();
+
+    // ================= phase 2: one filter lookup per chunk ======================================
+    uint16_t *const wq = wq_all[tid >> 6];
+    uint32_t qw = 0;                                              // queue fill (wave-uniform)
+    const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;            // this thread's 8 chunks
+
+    uint32_t g[SK_SPAN_CH];
+    uint2    b1[SK_SPAN_CH];
+    uint32_t okm = 0;                                             // chunks without a non-ACGT byte
+#pragma unroll
+    for (int i = 0; i < SK_SPAN_CH; i++) {
+        const uint32_t cw = my[i];
+        const uint32_t ipair = my[8 + (i >> 1)];
+        const uint32_t inv = (i & 1) ? ipair >> 16 : ipair & 0xFFFFu;
+        const uint32_t rc = sk_revcomp32(cw);
+        g[i] = sk_gmix(cw < rc ? cw : rc);
+        okm |= (uint32_t)(inv == 0u) << i;
+        b1[i] = make_uint2(0u, 0u);
+        if (ABLATE != 1 && inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)];
+    }
+    uint32_t m = 0;                                               // chunks that may be in the strain
+#pragma unroll
+    for (int i = 0; i < SK_SPAN_CH; i++)
+        m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i]))) << i;
+    if (m) {                                                      // level 2 (rare for unrelated reads)
+        uint32_t m2 = 0;
+#pragma unroll
+        for (int i = 0; i < SK_SPAN_CH; i++)
+            if ((m >> i) & 1u) {
+                const uint2 b2 = table.grid2[sk_grid2_block(g[i], table.grid2_shift)];
+                m2 |= (uint32_t)sk_grid_test(b2, sk_grid2_bits(g[i])) << i;
+            }
+        m = m2;
+    }
+
+    // ================= stage 2: the windows of the surviving chunks ==============================
+    auto probe_some = [&](uint32_t n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        qw -= n;
+        const bool act = lane < n;
+        const uint32_t e = act ? wq[qw + lane] : 0xFFFF0000u + lane * 2u;     // inactive: never consecutive
+        bool w_fwd = false;
+        const uint64_t cn = act ? sk_window_canon(rec, e, w_fwd) : 0ull;
+        const uint32_t pos = (uint32_t)tile0 + e;
+        if (ABLATE == 2) { __builtin_amdgcn_wave_barrier(); return; }
+        const uint32_t e_prev = (uint32_t)__shfl_up((int)e, 1);
+        const bool first = (lane == 0u) | (e != e_prev + 1u);                  // first window of a stretch
+        const unsigned long long fm = __ballot(first);
+        const uint32_t first_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
+        const uint32_t k = lane - first_lane;                                  // offset inside the stretch
+        const bool anchor = act & ((k & (SK_ANCHOR - 1u)) == 0u);
+        uint32_t hit = 0xFFFFFFFFu, a_dir = 0u;
+        if (anchor) {
+            uint32_t is_text = 0u;
+            hit = sk_find(cn, table, &is_text);
+            a_dir = (uint32_t)w_fwd ^ is_text;
+        }
+        const uint32_t my_anchor = lane - (k & (SK_ANCHOR - 1u));
+        const uint32_t n_idx = (uint32_t)__shfl((int)hit, (int)my_anchor);
+        const uint32_t n_dir = (uint32_t)__shfl((int)a_dir, (int)my_anchor);
+        if (act & !anchor) {
+            if (n_idx != 0xFFFFFFFFu && table.keys_by_loc) {
+                const uint32_t d = k & (SK_ANCHOR - 1u);
+                const uint32_t idx = n_dir ? n_idx - d : n_idx + d;
+                if (idx < table.nrows && table.keys_by_loc[idx] == cn) hit = idx;
+            }
+            if (hit == 0xFFFFFFFFu) { uint32_t unused; hit = sk_find(cn, table, &unused); }
+        }
+        if (TALLY) sk_tally_wave(sink, act ? hit : 0xFFFFFFFFu, pos, lane);
+        else if (hit != 0xFFFFFFFFu) sk_on_hit<false, ABLATE == 3>(sink, hit, pos);
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    unsigned long long lanes = __ballot(m != 0u);
+    while (lanes) {                                               // one thread's chunks after the other
+        const int l = __builtin_ctzll(lanes);
+        lanes &= lanes - 1ull;
+        uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
+        const uint32_t t0 = (tid & ~63u) + (uint32_t)l;           // the thread whose chunks these are
+        while (mm) {
+            const uint32_t i = (uint32_t)__builtin_ctz(mm);
+            mm &= mm - 1u;
+            const uint32_t c = (t0 + 1u) * SK_SPAN_CH + i;        // chunk index in the LDS records
+            // live windows: bit o <=> the 31 bases ending at chunk start + 15 + o are all ACGT
+            const uint64_t v = ~((uint64_t)sk_chunk_inv(rec, c - 1u) | ((uint64_t)sk_chunk_inv(rec, c + 1u) << 32)) &
+                               0x0000FFFFFFFFFFFFull;              // (the chunk itself is clean)
+            uint64_t rr = v & (v << 1);
+            rr &= rr << 2;
+            rr &= rr << 4;
+            rr &= rr << 8;
+            rr &= rr << 15;                                        // runs of >= 31
+            uint32_t live16 = (uint32_t)(rr >> 31) & 0xFFFFu;
+            const uint32_t e0 = t0 * SK_SPAN + i * 16u + 15u;     // tile-relative END of the chunk's first window
+            const uint64_t p0 = tile0 + e0;
+            if (p0 < emit_begin) {
+                const uint64_t dlt = emit_begin - p0;
+                live16 = dlt >= 16u ? 0u : live16 & (0xFFFFu << (uint32_t)dlt);
+            }
+            if (lane < 16u && ((live16 >> lane) & 1u))
+                wq[qw + (uint32_t)__popc(live16 & ((1u << lane) - 1u))] = (uint16_t)(e0 + lane);
+            qw += (uint32_t)__popc(live16);
+            if (qw >= 64u) probe_some(64u);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (qw) probe_some(qw);
+    if (bad) atomicAdd(&flags[0], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // wide (byte-string) path
 // ---------------------------------------------------------------------------------------------
 __constant__ signed char sk_comp_dev[256];
@@ -672,6 +898,28 @@ __global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uin
     }
 }
 
+// grid filters: the canonical form of every 16-mer of every key, into both levels
+__global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ w1, uint32_t nblocks1,
+                               uint32_t *__restrict__ w2, uint32_t shift2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = in[i];
+    if (k == SK_EMPTY64) return;
+    for (int off = 0; off < 16; off++) {
+        const uint32_t f = (uint32_t)(k >> (2 * (15 - off)));
+        const uint32_t r = sk_revcomp16(f);
+        const uint32_t g = sk_gmix(f < r ? f : r);
+        const uint32_t a = sk_grid1_bits(g), b = sk_grid2_bits(g);
+        uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
+        atomicOr(&blk[0], (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)));
+        atomicOr(&blk[1], (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u)));
+        blk = w2 + 2u * (size_t)sk_grid2_block(g, shift2);
+        atomicOr(&blk[0], (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)));
+        atomicOr(&blk[1], (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u)));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
@@ -686,6 +934,10 @@ struct sk_ctx {
     uint32_t     slots_log2;
     uint2       *d_bloom;
     uint32_t     bloom_blocks_log2;       // 0 = no prefilter
+    uint2       *d_grid1, *d_grid2;       // grid kernel's two filter levels
+    uint32_t     grid1_blocks, grid2_blocks_log2;
+    long         grid_kib;                // option: size of level 1 in KiB (-1 = automatic)
+    long         kernel;                  // option: 0 = grid kernel (default), 1 = minimizer kernel
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
     uint32_t    *d_perm, *d_inv;      // locality order of the counters (NULL = caller's row order)
@@ -778,6 +1030,7 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     c->device = device;
     c->table_load_pct = 50;
     c->bloom_bits_log2 = -1;          // -1 = automatic (sized for the L2), 0 = off
+    c->grid_kib = -1;
     c->err[0] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SK_E_NODEVICE; }
     if (hipMalloc((void **)&c->d_flags, 16 * sizeof(uint32_t)) != hipSuccess) { delete c; return SK_E_NOMEM; }
@@ -793,6 +1046,8 @@ static void sk_table_release(sk_ctx *c)
 {
     hipFree(c->d_keys); c->d_keys = NULL;
     hipFree(c->d_bloom); c->d_bloom = NULL;
+    hipFree(c->d_grid1); c->d_grid1 = NULL;
+    hipFree(c->d_grid2); c->d_grid2 = NULL;
     hipFree(c->d_counts); c->d_counts = NULL;
     hipFree(c->d_perm); c->d_perm = NULL;
     c->h_perm.clear();
@@ -836,6 +1091,8 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
     if (!c || !name) return SK_E_ARG;
     if (!strcmp(name, "table_load_pct")) { if (value < 5 || value > 90) return SK_E_ARG; c->table_load_pct = value; return SK_OK; }
     if (!strcmp(name, "bloom_bits_log2")) { if (value < -1 || value > 34 || (value > 0 && value < 10)) return SK_E_ARG; c->bloom_bits_log2 = value; return SK_OK; }
+    if (!strcmp(name, "grid_kib")) { if (value < -1 || value == 0 || value > (1 << 22)) return SK_E_ARG; c->grid_kib = value; return SK_OK; }
+    if (!strcmp(name, "kernel")) { if (value < 0 || value > 1) return SK_E_ARG; c->kernel = value; return SK_OK; }
     if (!strcmp(name, "stats")) { c->stats = value != 0; return SK_OK; }
     if (!strcmp(name, "ablate")) { c->ablate = value; return SK_OK; }
     return sk_fail(c, SK_E_ARG, "unknown option %s", name);
@@ -904,6 +1161,24 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
                                d_in, nrows, (uint32_t *)c->d_bloom, 32u - blocks_log2);
             c->bloom_blocks_log2 = blocks_log2;
         }
+        {   // grid filters.  Level 1 is meant to stay in the L2 (4 MiB per XCD, shared with everything else):
+            // ~5 bits per key, capped at 3 MiB (measured: a 4 MiB filter only hits 60 % of the time).
+            // Level 2 settles what level 1 lets through: >= 32 bits per key, false positives ~1e-5.
+            uint64_t kib = c->grid_kib > 0 ? (uint64_t)c->grid_kib : ((uint64_t)nrows * 5ull / 8ull + 1023ull) / 1024ull;
+            if (c->grid_kib <= 0 && kib > 3072ull) kib = 3072ull;
+            if (kib < 4ull) kib = 4ull;
+            c->grid1_blocks = (uint32_t)(kib * 1024ull / sizeof(uint2));
+            uint32_t g2 = 12;
+            while (g2 < 34 && ((uint64_t)1 << g2) < (uint64_t)nrows * 32ull) g2++;
+            c->grid2_blocks_log2 = g2 - 6u;
+            const size_t b1 = (size_t)c->grid1_blocks * sizeof(uint2), b2 = ((size_t)1 << c->grid2_blocks_log2) * sizeof(uint2);
+            SK_HIP(c, hipMalloc((void **)&c->d_grid1, b1));
+            SK_HIP(c, hipMalloc((void **)&c->d_grid2, b2));
+            SK_HIP(c, hipMemsetAsync(c->d_grid1, 0, b1, c->stream));
+            SK_HIP(c, hipMemsetAsync(c->d_grid2, 0, b2, c->stream));
+            hipLaunchKernelGGL(sk_grid_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, d_in, nrows,
+                               (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+        }
         uint32_t flags[2] = {0, 0};
         SK_HIP(c, hipMemcpyAsync(flags, c->d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
         SK_HIP(c, hipStreamSynchronize(c->stream));
@@ -958,6 +1233,8 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     tv.slots = c->d_keys; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
     tv.bloom = c->d_bloom;
     tv.bloom_shift = 32u - c->bloom_blocks_log2;
+    tv.grid1 = c->d_grid1; tv.grid2 = c->d_grid2;
+    tv.grid1_blocks = c->grid1_blocks; tv.grid2_shift = 32u - c->grid2_blocks_log2;
     sk_wide_view wv;
     wv.keys31 = c->d_wide_keys; wv.rows = c->d_wide_rows; wv.index = c->d_wide_index;
     wv.wmask = c->wide_mask; wv.nwide = c->nwide;
@@ -978,7 +1255,15 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
 #define SK_LAUNCH_MAIN(F, S, A, T) hipLaunchKernelGGL((sk_scan_main<F, S, A, T>), grid, block, 0, c->stream, \
                                                       d_stream, nbytes, emit_begin, tv, sink, c->d_flags)
     const bool filter = c->bloom_blocks_log2 != 0;
-    if (tally_sink)                      { if (filter) SK_LAUNCH_MAIN(true, false, 0, true); else SK_LAUNCH_MAIN(false, false, 0, true); }
+#define SK_LAUNCH_GRID(T, A) hipLaunchKernelGGL((sk_scan_grid<T, A>), grid, block, 0, c->stream, \
+                                                d_stream, nbytes, emit_begin, tv, sink, c->d_flags)
+    const bool use_grid = c->kernel == 0 && c->d_grid1 && !c->stats;
+    if (use_grid && tally_sink)          SK_LAUNCH_GRID(true, 0);
+    else if (use_grid && c->ablate == 1) SK_LAUNCH_GRID(false, 1);
+    else if (use_grid && c->ablate == 2) SK_LAUNCH_GRID(false, 2);
+    else if (use_grid && c->ablate == 3) SK_LAUNCH_GRID(false, 3);
+    else if (use_grid)                   SK_LAUNCH_GRID(false, 0);
+    else if (tally_sink)                 { if (filter) SK_LAUNCH_MAIN(true, false, 0, true); else SK_LAUNCH_MAIN(false, false, 0, true); }
     else if (c->ablate == 1 && filter)   SK_LAUNCH_MAIN(true, false, 1, false);
     else if (c->ablate == 2 && filter)   SK_LAUNCH_MAIN(true, false, 2, false);
     else if (c->ablate == 3 && filter)   SK_LAUNCH_MAIN(true, false, 3, false);
@@ -987,6 +1272,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     else if (filter)                     SK_LAUNCH_MAIN(true, false, 0, false);
     else                                 SK_LAUNCH_MAIN(false, false, 0, false);
 #undef SK_LAUNCH_MAIN
+#undef SK_LAUNCH_GRID
     if (timed) {
         SK_HIP(c, hipEventRecord(e1, c->stream));
         c->ev.push_back(e0);

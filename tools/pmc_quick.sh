@@ -11,7 +11,7 @@ from collections import defaultdict
 acc = defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "sk_scan_main" in r["Kernel_Name"]:
+        if ("sk_scan_grid" in r["Kernel_Name"] or "sk_scan_main" in r["Kernel_Name"]):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print({k: round(sum(v) / len(v) / 1e6, 2) for k, v in acc.items()}, "(millions per launch)")
 PY

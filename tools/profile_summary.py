@@ -37,7 +37,7 @@ with open(os.path.join(out, "summary.txt"), "w") as f:
     for k, v in sorted(summary["kernels"].items(), key=lambda kv: -kv[1]["pct"]):
         f.write(f"{k:28s} calls={v['calls']:4d} avg={v['avg_ns'] / 1e6:10.4f} ms  {v['pct']:6.2f}%\n")
     for k, cs in summary["counters"].items():
-        if "sk_scan_main" not in k:
+        if "sk_scan_main" not in k and "sk_scan_grid" not in k:
             continue
         f.write(f"\n[{k}] per-launch averages\n")
         for c, v in sorted(cs.items()):
