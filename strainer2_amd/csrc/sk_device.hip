@@ -911,12 +911,15 @@ __global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint
         const uint32_t r = sk_revcomp16(f);
         const uint32_t g = sk_gmix(f < r ? f : r);
         const uint32_t a = sk_grid1_bits(g), b = sk_grid2_bits(g);
+        // consecutive keys share 15 of their 16 sub-words: most bits are set already, so look before the atomic
         uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
-        atomicOr(&blk[0], (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)));
-        atomicOr(&blk[1], (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u)));
+        uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
+        if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
+        if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
         blk = w2 + 2u * (size_t)sk_grid2_block(g, shift2);
-        atomicOr(&blk[0], (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)));
-        atomicOr(&blk[1], (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u)));
+        m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)); m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
+        if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
+        if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
     }
 }
 
