@@ -594,7 +594,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                   sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags)
 {
     __shared__ __attribute__((aligned(16))) uint32_t rec[(SK_NREC + 1) * SK_REC_DW];
-    __shared__ uint16_t wq_all[SK_WAVES][SK_WQ];
+    __shared__ uint16_t wq_all[SK_WAVES][128 + 16];              // below 128 before a push of at most 16
 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
     const uint32_t tid = threadIdx.x;
@@ -684,73 +684,143 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     }
 
     // ================= stage 2: the windows of the surviving chunks ==============================
+    // Up to 128 queued windows at a time, two per lane: the two dependent memory latencies of a batch
+    // (anchor probe in HBM, then the followers' strain-order key line) are what stage 2 waits for, so
+    // twice the windows per round trip is close to twice the rate.
     auto probe_some = [&](uint32_t n) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         qw -= n;
-        const bool act = lane < n;
-        const uint32_t e = act ? wq[qw + lane] : 0xFFFF0000u + lane * 2u;     // inactive: never consecutive
-        bool w_fwd = false;
-        const uint64_t cn = act ? sk_window_canon(rec, e, w_fwd) : 0ull;
-        const uint32_t pos = (uint32_t)tile0 + e;
+        bool act[2], w_fwd[2], anchor[2];
+        uint32_t e[2], pos[2], kk[2], hit[2], a_dir[2];
+        uint64_t cn[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint32_t idx = lane + 64u * (uint32_t)s2;
+            act[s2] = idx < n;
+            e[s2] = act[s2] ? wq[qw + idx] : 0xFFFF0000u + lane * 2u;           // inactive: never consecutive
+            w_fwd[s2] = false;
+            cn[s2] = act[s2] ? sk_window_canon(rec, e[s2], w_fwd[s2]) : 0ull;
+            pos[s2] = (uint32_t)tile0 + e[s2];
+        }
         if (ABLATE == 2) { __builtin_amdgcn_wave_barrier(); return; }
-        const uint32_t e_prev = (uint32_t)__shfl_up((int)e, 1);
-        const bool first = (lane == 0u) | (e != e_prev + 1u);                  // first window of a stretch
-        const unsigned long long fm = __ballot(first);
-        const uint32_t first_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
-        const uint32_t k = lane - first_lane;                                  // offset inside the stretch
-        const bool anchor = act & ((k & (SK_ANCHOR - 1u)) == 0u);
-        uint32_t hit = 0xFFFFFFFFu, a_dir = 0u;
-        if (anchor) {
-            uint32_t is_text = 0u;
-            hit = sk_find(cn, table, &is_text);
-            a_dir = (uint32_t)w_fwd ^ is_text;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint32_t e_prev = (uint32_t)__shfl_up((int)e[s2], 1);
+            const bool first = (lane == 0u) | (e[s2] != e_prev + 1u);          // first window of a stretch
+            const unsigned long long fm = __ballot(first);
+            const uint32_t first_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
+            kk[s2] = lane - first_lane;                                        // offset inside the stretch
+            anchor[s2] = act[s2] & ((kk[s2] & (SK_ANCHOR - 1u)) == 0u);
+            hit[s2] = 0xFFFFFFFFu; a_dir[s2] = 0u;
         }
-        const uint32_t my_anchor = lane - (k & (SK_ANCHOR - 1u));
-        const uint32_t n_idx = (uint32_t)__shfl((int)hit, (int)my_anchor);
-        const uint32_t n_dir = (uint32_t)__shfl((int)a_dir, (int)my_anchor);
-        if (act & !anchor) {
-            if (n_idx != 0xFFFFFFFFu && table.keys_by_loc) {
-                const uint32_t d = k & (SK_ANCHOR - 1u);
-                const uint32_t idx = n_dir ? n_idx - d : n_idx + d;
-                if (idx < table.nrows && table.keys_by_loc[idx] == cn) hit = idx;
+        // both slots' anchors probe the hash table together
+        uint32_t slot[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) slot[s2] = sk_slot0(sk_khash(cn[s2]), table.mask);
+        sk_u4 ent[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) ent[s2] = anchor[s2] ? table.slots[slot[s2]] : (sk_u4){0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (anchor[s2]) {
+                sk_u4 en = ent[s2];
+                uint32_t sl = slot[s2];
+                for (;;) {
+                    const uint64_t key = sk_slot_key(en);
+                    if (key == cn[s2]) { hit[s2] = en.z; a_dir[s2] = (uint32_t)w_fwd[s2] ^ (en.w & 1u); break; }
+                    if (key == SK_EMPTY64) break;
+                    sl = (sl + 1u) & table.mask;
+                    en = table.slots[sl];
+                }
             }
-            if (hit == 0xFFFFFFFFu) { uint32_t unused; hit = sk_find(cn, table, &unused); }
         }
-        if (TALLY) sk_tally_wave(sink, act ? hit : 0xFFFFFFFFu, pos, lane);
-        else if (hit != 0xFFFFFFFFu) sk_on_hit<false, ABLATE == 3>(sink, hit, pos);
+        // followers: the anchor's neighbour in strain order, both slots' key lines in flight together
+        uint32_t fidx[2];
+        uint64_t fkey[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint32_t my_anchor = lane - (kk[s2] & (SK_ANCHOR - 1u));
+            const uint32_t n_idx = (uint32_t)__shfl((int)hit[s2], (int)my_anchor);
+            const uint32_t n_dir = (uint32_t)__shfl((int)a_dir[s2], (int)my_anchor);
+            const uint32_t d = kk[s2] & (SK_ANCHOR - 1u);
+            fidx[s2] = 0xFFFFFFFFu;
+            fkey[s2] = 0ull;
+            if (act[s2] & !anchor[s2] && n_idx != 0xFFFFFFFFu && table.keys_by_loc) {
+                const uint32_t idx = n_dir ? n_idx - d : n_idx + d;            // wraps below 0 -> >= nrows
+                if (idx < table.nrows) { fidx[s2] = idx; fkey[s2] = table.keys_by_loc[idx]; }
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (act[s2] & !anchor[s2]) {
+                if (fidx[s2] != 0xFFFFFFFFu && fkey[s2] == cn[s2]) hit[s2] = fidx[s2];
+                if (hit[s2] == 0xFFFFFFFFu) { uint32_t unused; hit[s2] = sk_find(cn[s2], table, &unused); }
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (TALLY) sk_tally_wave(sink, act[s2] ? hit[s2] : 0xFFFFFFFFu, pos[s2], lane);
+            else if (hit[s2] != 0xFFFFFFFFu) sk_on_hit<false, ABLATE == 3>(sink, hit[s2], pos[s2]);
+        }
         __builtin_amdgcn_wave_barrier();
     };
 
-    unsigned long long lanes = __ballot(m != 0u);
-    while (lanes) {                                               // one thread's chunks after the other
-        const int l = __builtin_ctzll(lanes);
-        lanes &= lanes - 1ull;
-        uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
-        const uint32_t t0 = (tid & ~63u) + (uint32_t)l;           // the thread whose chunks these are
-        while (mm) {
-            const uint32_t i = (uint32_t)__builtin_ctz(mm);
-            mm &= mm - 1u;
-            const uint32_t c = (t0 + 1u) * SK_SPAN_CH + i;        // chunk index in the LDS records
-            // live windows: bit o <=> the 31 bases ending at chunk start + 15 + o are all ACGT
-            const uint64_t v = ~((uint64_t)sk_chunk_inv(rec, c - 1u) | ((uint64_t)sk_chunk_inv(rec, c + 1u) << 32)) &
-                               0x0000FFFFFFFFFFFFull;              // (the chunk itself is clean)
+    // live windows of the surviving chunks, computed by their own threads (all lanes in parallel):
+    // bit o of a chunk's mask <=> the 31 bases ending at chunk start + 15 + o are all ACGT.  The masks
+    // of a thread's eight chunks are packed two to a register for the hand-over below.
+    uint32_t lv[4] = {0u, 0u, 0u, 0u};
+    if (m) {
+        uint32_t inv[SK_SPAN_CH + 2];                              // chunk before the span, the span, chunk after
+        inv[0] = sk_chunk_inv(rec, (tid + 1u) * SK_SPAN_CH - 1u);
+        inv[SK_SPAN_CH + 1] = sk_chunk_inv(rec, (tid + 2u) * SK_SPAN_CH);
+#pragma unroll
+        for (int i = 0; i < SK_SPAN_CH; i++) {
+            const uint32_t ipair = my[8 + (i >> 1)];
+            inv[i + 1] = (i & 1) ? ipair >> 16 : ipair & 0xFFFFu;
+        }
+        uint32_t keep = 0;
+#pragma unroll
+        for (int i = 0; i < SK_SPAN_CH; i++) {
+            if (!((m >> i) & 1u)) continue;
+            const uint64_t v = ~((uint64_t)inv[i] | ((uint64_t)inv[i + 2] << 32)) & 0x0000FFFFFFFFFFFFull;   // (the chunk itself is clean)
             uint64_t rr = v & (v << 1);
             rr &= rr << 2;
             rr &= rr << 4;
             rr &= rr << 8;
             rr &= rr << 15;                                        // runs of >= 31
             uint32_t live16 = (uint32_t)(rr >> 31) & 0xFFFFu;
-            const uint32_t e0 = t0 * SK_SPAN + i * 16u + 15u;     // tile-relative END of the chunk's first window
-            const uint64_t p0 = tile0 + e0;
+            const uint64_t p0 = tile0 + tid * SK_SPAN + (uint32_t)i * 16u + 15u;   // END of the chunk's first window
             if (p0 < emit_begin) {
                 const uint64_t dlt = emit_begin - p0;
                 live16 = dlt >= 16u ? 0u : live16 & (0xFFFFu << (uint32_t)dlt);
             }
+            lv[i >> 1] |= live16 << (16 * (i & 1));
+            keep |= (uint32_t)(live16 != 0u) << i;
+        }
+        m = keep;
+    }
+
+    // hand-over to the wave's window queue: one thread's chunks after the other, so that consecutive
+    // windows sit in consecutive queue slots (everything in this loop is wave-uniform)
+    unsigned long long lanes = __ballot(m != 0u);
+    while (lanes) {
+        const int l = __builtin_ctzll(lanes);
+        lanes &= lanes - 1ull;
+        uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)lv[0], l), l1 = (uint32_t)__builtin_amdgcn_readlane((int)lv[1], l);
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_readlane((int)lv[2], l), l3 = (uint32_t)__builtin_amdgcn_readlane((int)lv[3], l);
+        const uint32_t t0 = (tid & ~63u) + (uint32_t)l;           // the thread whose chunks these are
+        while (mm) {
+            const uint32_t i = (uint32_t)__builtin_ctz(mm);
+            mm &= mm - 1u;
+            const uint32_t pair = (i >> 1) == 0u ? l0 : (i >> 1) == 1u ? l1 : (i >> 1) == 2u ? l2 : l3;
+            const uint32_t live16 = (pair >> (16u * (i & 1u))) & 0xFFFFu;
+            const uint32_t e0 = t0 * SK_SPAN + i * 16u + 15u;     // tile-relative END of the chunk's first window
             if (lane < 16u && ((live16 >> lane) & 1u))
                 wq[qw + (uint32_t)__popc(live16 & ((1u << lane) - 1u))] = (uint16_t)(e0 + lane);
             qw += (uint32_t)__popc(live16);
-            if (qw >= 64u) probe_some(64u);
+            if (qw >= 128u) probe_some(128u);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
