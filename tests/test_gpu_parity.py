@@ -125,6 +125,28 @@ def test_scan_stream_fuzz_vs_oracle(ctx, seed, junk):
     assert ocounts[:, 1:].sum() > 1000          # the test is not vacuous
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_both_scan_kernels_vs_oracle(kernel):
+    """the grid kernel (default) and the minimizer kernel of the previous generation, selected explicitly,
+    on a stream that crosses several tiles with junk, short records and strain reads"""
+    rng = random.Random(77 + kernel)
+    strain = _synth.rand_dna(rng, 50_000)
+    sstream = strain + b"\n"
+    ks = sk.Keyset.from_stream(sstream)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    data = _synth.fuzz_stream(rng, strain, 3000, p_junk=0.003, min_len=0, max_len=400)
+    assert len(data) > 5 * 32768
+    with sk.KmerContext(0) as c:
+        c.set_option("kernel", kernel)
+        c.load_keyset(ks, 4)
+        c.scan_stream(data, 2)
+        t.scan_stream(data, 2)
+        _, ocounts = t.rows()
+        got = c.counts(2)
+    assert np.array_equal(got, ocounts[:, 2]) and got.sum() > 10_000
+
+
 def test_scan_device_equals_scan_stream_and_tile_edges(ctx):
     """Device-resident entry point; stream lengths around tile (32768) and chunk (16) edges."""
     rng = random.Random(7)
