@@ -25,10 +25,12 @@
 #include <zlib.h>
 
 #include "../../include/strainer_kmer.h"
+#include "sk_alloc.h"
 #include "sk_common.h"
 
 #include "sk_parser.h"
 #include "sk_ctxjob.h"
+
 
 /* run a whole (possibly gzipped) file through the parser */
 static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords, int *sink_rc)

@@ -24,10 +24,12 @@
 #include <zlib.h>
 
 #include "../../include/strainer_kmer.h"
+#include "sk_alloc.h"
 #include "sk_common.h"
 #include "sk_parser.h"
 #include "sk_internal.h"
 #include "sk_ctxjob.h"
+
 
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
 enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
