@@ -17,6 +17,8 @@
 #include <ctype.h>
 #include <errno.h>
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +32,19 @@
 
 #include "sk_parser.h"
 #include "sk_ctxjob.h"
+
+/* tables of tens of MB that are touched at random: 2 MiB-aligned and offered to transparent huge pages
+ * (fewer page faults while they are filled, fewer TLB misses while they are probed) */
+static void *big_alloc(size_t bytes)
+{
+    void *p = NULL;
+    if (bytes < (8u << 20)) return malloc(bytes);
+    if (posix_memalign(&p, 2u << 20, (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1))) return malloc(bytes);
+    madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
+}
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 
 /* run a whole (possibly gzipped) file through the parser */
@@ -146,6 +161,7 @@ int64_t skh_decode_file(const char *path, uint64_t chunk_bytes, skh_sink_fn sink
 
 #define WIDE_FLAG 0x8000000000000000ull     /* order-list entry refers to wide key (index in low bits) */
 
+#define SK_RING 16u
 typedef struct {
     /* packed-key set: open addressing on u64 -> order index */
     uint64_t *pk; uint32_t *pv; uint64_t pmask; uint64_t pcount;
@@ -156,14 +172,20 @@ typedef struct {
     uint32_t default_val, incr;
     uint64_t short_records;
     signed char comp[256];
+    /* packed keys wait here for SK_RING more windows while their table line is fetched: the distinct-key
+     * set of a 5 Mbp strain (100+ MB) lives in DRAM and every insert is a cache miss otherwise */
+    uint64_t ring_key[SK_RING]; uint8_t ring_fwd[SK_RING]; uint32_t ring_n, ring_pos;
 } builder;
 
-static void builder_init(builder *b, uint32_t default_val, uint32_t incr)
+/* hint_bases: about how many bases the strain has (0 = unknown): the distinct-key set starts at twice
+ * that many slots instead of growing there by repeated rehashing */
+static void builder_init(builder *b, uint32_t default_val, uint32_t incr, uint64_t hint_bases)
 {
     memset(b, 0, sizeof *b);
     b->pmask = (1u << 16) - 1;
-    b->pk = (uint64_t *)malloc((b->pmask + 1) * sizeof(uint64_t));
-    b->pv = (uint32_t *)malloc((b->pmask + 1) * sizeof(uint32_t));
+    while (b->pmask + 1 < 2 * hint_bases && b->pmask < (1ull << 30) - 1) b->pmask = b->pmask * 2 + 1;
+    b->pk = (uint64_t *)big_alloc((b->pmask + 1) * sizeof(uint64_t));
+    b->pv = (uint32_t *)big_alloc((b->pmask + 1) * sizeof(uint32_t));
     memset(b->pk, 0xFF, (b->pmask + 1) * sizeof(uint64_t));
     b->wmask = 63;
     b->windex = (uint32_t *)calloc(b->wmask + 1, sizeof(uint32_t));
@@ -196,8 +218,8 @@ static void builder_grow_packed(builder *b)
 {
     uint64_t oldn = b->pmask + 1, i, nm = oldn * 2 - 1;
     uint64_t *ok = b->pk; uint32_t *ov = b->pv;
-    b->pk = (uint64_t *)malloc((nm + 1) * sizeof(uint64_t));
-    b->pv = (uint32_t *)malloc((nm + 1) * sizeof(uint32_t));
+    b->pk = (uint64_t *)big_alloc((nm + 1) * sizeof(uint64_t));
+    b->pv = (uint32_t *)big_alloc((nm + 1) * sizeof(uint32_t));
     memset(b->pk, 0xFF, (nm + 1) * sizeof(uint64_t));
     for (i = 0; i < oldn; i++) {
         uint64_t s;
@@ -211,7 +233,7 @@ static void builder_grow_packed(builder *b)
 }
 
 /* is_fwd: the key is the strain's text itself at this occurrence (not its reverse complement) */
-static void builder_add_packed(builder *b, uint64_t key, int is_fwd)
+static void builder_insert_packed(builder *b, uint64_t key, int is_fwd)
 {
     uint64_t s = sk_hash62(key) & b->pmask;
     while (b->pk[s] != SK_EMPTY64) {
@@ -224,8 +246,38 @@ static void builder_add_packed(builder *b, uint64_t key, int is_fwd)
     if (++b->pcount * 2 > b->pmask) builder_grow_packed(b);
 }
 
+/* queue a packed key: prefetch its table line now, insert it SK_RING windows later (order is kept) */
+static void builder_add_packed(builder *b, uint64_t key, int is_fwd)
+{
+    uint32_t at;
+    if (b->ring_n == SK_RING) {
+        builder_insert_packed(b, b->ring_key[b->ring_pos], b->ring_fwd[b->ring_pos]);
+        b->ring_pos = (b->ring_pos + 1u) & (SK_RING - 1u);
+        b->ring_n--;
+    }
+    at = (b->ring_pos + b->ring_n) & (SK_RING - 1u);
+    {
+        const uint64_t s0 = sk_hash62(key) & b->pmask;
+        __builtin_prefetch(&b->pk[s0], 1);
+        __builtin_prefetch(&b->pv[s0], 1);
+    }
+    b->ring_key[at] = key;
+    b->ring_fwd[at] = (uint8_t)is_fwd;
+    b->ring_n++;
+}
+
+static void builder_drain(builder *b)
+{
+    while (b->ring_n) {
+        builder_insert_packed(b, b->ring_key[b->ring_pos], b->ring_fwd[b->ring_pos]);
+        b->ring_pos = (b->ring_pos + 1u) & (SK_RING - 1u);
+        b->ring_n--;
+    }
+}
+
 static void builder_add_wide(builder *b, const char *key31)
 {
+    builder_drain(b);                                 /* wide and packed entries share one insertion order */
     uint32_t s = sk_hash_wide(key31) & b->wmask, i;
     while (b->windex[s]) {
         uint32_t e = b->windex[s] - 1;
@@ -312,35 +364,71 @@ static uint32_t djb2_bytes(const char *s)           /* src/BIO_hash.c:208-216, s
     return h;
 }
 
-/* Replays insert-with-doubling and returns entries in ascending slot order of the final table. */
+/* djb2 of the 31 letters of a packed key without the 31 dependent multiplies:
+ * h = 5381 * 33^31 + sum_i letter_i * 33^(30-i)  (mod 2^32), four letters (one byte of codes) per table lookup */
+static uint32_t djb2_tab[8][256], djb2_base;
+static pthread_once_t djb2_once = PTHREAD_ONCE_INIT;
+static void djb2_init(void)
+{
+    uint32_t pw[SK_K + 1], g, v, j;
+    pw[0] = 1u;
+    for (j = 1; j <= SK_K; j++) pw[j] = pw[j - 1] * 33u;
+    djb2_base = 5381u * pw[SK_K];
+    /* the key holds letter i (0 = first) at bits 61-2i..60-2i; byte group g covers bits 8g+7..8g, i.e.
+     * letters 30-4g-3 .. 30-4g (group 7 only has the first 3 letters, bits 61..56) */
+    for (g = 0; g < 8; g++)
+        for (v = 0; v < 256; v++) {
+            uint32_t sum = 0;
+            for (j = 0; j < 4; j++) {
+                const int letter = 30 - 4 * (int)g - (int)j;          /* letter held in bits 2j+1..2j of the byte */
+                if (letter < 0) continue;
+                sum += (uint32_t)"ACGT"[(v >> (2 * j)) & 3u] * pw[30 - letter];
+            }
+            djb2_tab[g][v] = sum;
+        }
+}
+static inline uint32_t djb2_packed(uint64_t key)
+{
+    return djb2_base + djb2_tab[0][key & 255u] + djb2_tab[1][(key >> 8) & 255u] + djb2_tab[2][(key >> 16) & 255u] +
+           djb2_tab[3][(key >> 24) & 255u] + djb2_tab[4][(key >> 32) & 255u] + djb2_tab[5][(key >> 40) & 255u] +
+           djb2_tab[6][(key >> 48) & 255u] + djb2_tab[7][(key >> 56) & 63u];
+}
+
+/* Replays insert-with-doubling and returns entries in ascending slot order of the final table.
+ * The slot array (64 MB for a 5 Mbp strain) is probed at random: the line of the insert 16 ahead is
+ * prefetched while the current one is placed. */
 static uint32_t *replay_slot_order(const builder *b, uint32_t initial_slots, uint32_t *final_slots)
 {
+    enum { AHEAD = 48 };
     uint32_t M = initial_slots, N = 0, e, i;
     uint32_t *h32 = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
     int32_t *slot;
     uint32_t *rows;
-    char tmp[32];
     if (M == 0) M = 1000; else if (M < 10) M = 10;       /* src/BIO_hash.c:18-21 */
+    pthread_once(&djb2_once, djb2_init);
     for (e = 0; e < b->n; e++) {
         if (b->order[e] & WIDE_FLAG) h32[e] = djb2_bytes(b->wkeys + (size_t)(b->order[e] & 0xFFFFFFFFu) * 32);
-        else { decode_key(b->order[e], tmp); h32[e] = djb2_bytes(tmp); }
+        else h32[e] = djb2_packed(b->order[e]);
     }
-    slot = (int32_t *)malloc((size_t)M * sizeof(int32_t));
+    slot = (int32_t *)big_alloc((size_t)M * sizeof(int32_t));
     memset(slot, 0xFF, (size_t)M * sizeof(int32_t));
     for (e = 0; e < b->n; e++) {
         uint32_t s = h32[e] % M;
-        while (slot[s] >= 0) s = (s + 1) % M;
+        if (e + AHEAD < b->n) __builtin_prefetch(&slot[h32[e + AHEAD] % M], 1);
+        while (slot[s] >= 0) s = s + 1 == M ? 0 : s + 1;
         slot[s] = (int32_t)e;
         if (N++ >= M / 2) {                              /* post-increment test: src/BIO_hash.c:138 */
             uint32_t M2 = M + M;
-            int32_t *ns = (int32_t *)malloc((size_t)M2 * sizeof(int32_t));
+            int32_t *ns = (int32_t *)big_alloc((size_t)M2 * sizeof(int32_t));
             memset(ns, 0xFF, (size_t)M2 * sizeof(int32_t));
             N = 0;
             for (i = 0; i < M; i++) {                    /* old slot order: src/BIO_hash.c:54-58 */
                 uint32_t t;
+                if (i + 160 < M && slot[i + 160] >= 0) __builtin_prefetch(&h32[slot[i + 160]]);
+                if (i + 64 < M && slot[i + 64] >= 0) __builtin_prefetch(&ns[h32[slot[i + 64]] % M2], 1);
                 if (slot[i] < 0) continue;
                 t = h32[slot[i]] % M2;
-                while (ns[t] >= 0) t = (t + 1) % M2;
+                while (ns[t] >= 0) t = t + 1 == M2 ? 0 : t + 1;
                 ns[t] = slot[i];
                 N++;
             }
@@ -349,8 +437,8 @@ static uint32_t *replay_slot_order(const builder *b, uint32_t initial_slots, uin
             M = M2;
         }
     }
-    rows = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
-    for (i = 0, e = 0; i < M; i++) if (slot[i] >= 0) rows[e++] = (uint32_t)slot[i];
+    rows = (uint32_t *)malloc(((size_t)b->n + 1) * sizeof(uint32_t));
+    for (i = 0, e = 0; i < M; i++) { rows[e] = (uint32_t)slot[i]; e += (uint32_t)(slot[i] >= 0); }   /* (branch-free compaction) */
     free(slot);
     free(h32);
     *final_slots = M;
@@ -359,7 +447,9 @@ static uint32_t *replay_slot_order(const builder *b, uint32_t initial_slots, uin
 
 static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
 {
-    uint32_t r, *rows = replay_slot_order(b, initial_slots, &ks->final_slots);
+    uint32_t r, *rows;
+    builder_drain(b);
+    rows = replay_slot_order(b, initial_slots, &ks->final_slots);
     uint32_t *wide_newrow = (uint32_t *)calloc(b->wn ? b->wn : 1, sizeof(uint32_t));
     ks->nrows = b->n;
     ks->nwide = b->wn;
@@ -370,7 +460,9 @@ static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
     ks->wide_keys = (char *)malloc((size_t)(b->wn ? b->wn : 1) * 32);
     ks->wide_rows = (uint32_t *)malloc((size_t)(b->wn ? b->wn : 1) * sizeof(uint32_t));
     for (r = 0; r < b->n; r++) {
-        uint64_t ent = b->order[rows[r]];
+        uint64_t ent;
+        if (r + 32 < b->n) { __builtin_prefetch(&b->order[rows[r + 32]]); __builtin_prefetch(&b->count[rows[r + 32]]); __builtin_prefetch(&b->fwd_first[rows[r + 32]]); }
+        ent = b->order[rows[r]];
         ks->first_count[r] = b->count[rows[r]];
         ks->locality[r] = rows[r] | (b->fwd_first[rows[r]] ? SK_LOCALITY_FWD : 0u);
         if (ent & WIDE_FLAG) { ks->packed[r] = SK_KEY_NONE; wide_newrow[ent & 0xFFFFFFFFu] = r; }
@@ -391,9 +483,25 @@ int skh_keyset_from_file(skh_keyset *ks, const char *path, uint32_t initial_slot
     int rc;
     if (!ks || !path) return SK_E_ARG;
     memset(ks, 0, sizeof *ks);
-    builder_init(&b, default_val, incr);
-    rc = parse_file(path, builder_record, &b, NULL, NULL);
-    if (rc == SK_OK) rc = keyset_finish(ks, &b, initial_slots);
+    {
+        struct stat st;
+        const size_t pl = strlen(path);
+        uint64_t hint = 0;
+        if (stat(path, &st) == 0 && S_ISREG(st.st_mode))
+            hint = (uint64_t)st.st_size * (pl > 3 && !strcmp(path + pl - 3, ".gz") ? 4u : 1u);
+        if (hint > (1ull << 28)) hint = 1ull << 28;
+        builder_init(&b, default_val, incr, hint);
+    }
+    {
+        const double t0 = now_s();
+        double t1;
+        rc = parse_file(path, builder_record, &b, NULL, NULL);
+        t1 = now_s();
+        if (rc == SK_OK) rc = keyset_finish(ks, &b, initial_slots);
+        if (getenv("SK_TIMING"))
+            fprintf(stderr, "key set of %s: decode + distinct k-mers %.2f s, row order replay + layout %.2f s (%u keys)\n",
+                    path, t1 - t0, now_s() - t1, b.n);
+    }
     builder_free(&b);
     return rc;
 }
@@ -405,7 +513,7 @@ int skh_keyset_from_stream(skh_keyset *ks, const char *stream, size_t nbytes, ui
     int rc;
     if (!ks || (!stream && nbytes)) return SK_E_ARG;
     memset(ks, 0, sizeof *ks);
-    builder_init(&b, default_val, incr);
+    builder_init(&b, default_val, incr, nbytes);
     parse_memory(stream, nbytes, builder_record, &b);
     rc = keyset_finish(ks, &b, initial_slots);
     builder_free(&b);
@@ -743,6 +851,7 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     uint32_t nfailed = 0;
     sk_ctxjob cj;
     int crc;
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     double scrub_fraction = -1.0;                    /* >= 0: print the scrub filter's result instead of the table */
     int scrub_independent = 0, j;
 
@@ -788,9 +897,12 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
 
     memset(&ks, 0, sizeof ks);
+    t0 = now_s();
     sk_ctxjob_start(&cj, device);                      /* the HIP runtime comes up while the key set is built */
     rc = skh_keyset_from_file(&ks, R, SK_REF_TABLE_SLOTS, 1, 1);
+    t1 = now_s();
     crc = sk_ctxjob_join(&cj, &ctx);
+    t2 = now_s();
     if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", R); goto done; }
     if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s\n", sk_strerror(rc)); goto done; }
     if (ks.short_records && rank == 0)
@@ -818,6 +930,7 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
         if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: RCCL rendezvous failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
     }
     rc = skh_keyset_load(ctx, &ks, 4);
+    t3 = now_s();
     if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); failed = 1; }
     if (rc == SK_OK && world > 1) rc = sk_counts_zero(ctx, 0);      /* column 0 must not be summed world times: keep it on rank 0 */
     if (rc == SK_OK && world > 1 && rank == 0) rc = sk_counts_set(ctx, 0, ks.first_count);
@@ -833,16 +946,22 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
         rc = sk_counts_allreduce(ctx, NULL);
         if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: all-reduce failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
     } else if (failed) goto done;
+    t4 = now_s();
     if (rank == 0 && scrub_fraction >= 0.0) {
         status = skh_scrub_filter_resident(ctx, &ks, C != NULL, scrub_fraction, scrub_independent, out, err);
+        t5 = now_s();
         goto done;
     }
     if (rank == 0) {
         rc = skh_print_counts(ctx, &ks, out, C != NULL);
         if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
     }
+    t5 = now_s();
     status = 0;
 done:
+    if (getenv("SK_TIMING") && t5 > 0)
+        fprintf(err, "kmer_scrub_count timing: key set %.2f s (+%.2f s more for the HIP context), table load %.2f s, scans %.2f s, "
+                     "%s %.2f s\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, scrub_fraction >= 0.0 ? "filter + print" : "print", t5 - t4);
     if (ctx) sk_ctx_destroy(ctx);
     skh_keyset_free(&ks);
     if (progress) fclose(progress);
