@@ -659,18 +659,38 @@ static void usage(FILE *err)
 
 /* build one strain's state in two steps: the key set (host only; several strains build theirs at the
  * same time on separate threads), then the table on the device, -a flags, optional -g filter, -o file */
-typedef struct { sd_prog *p; const char *r; int rc, done; } ks_job;
+/* one strain of a -S list, opened on a worker thread: key set on the host, then its own context, table,
+ * -a flags, -g filter and outfile.  What it would have printed is kept in two buffers and replayed by the
+ * main thread in list order. */
+typedef struct {
+    sd_prog *p; const char *r, *a, *g, *o; int device, failed, done;
+    char *out_buf, *err_buf; size_t out_len, err_len;
+} ks_job;
 typedef struct { ks_job *jobs; uint32_t njobs, next; pthread_mutex_t mu; pthread_cond_t cv; } ks_pool;
+
+static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a, const char *g, const char *o, int device);
 
 static void *sd_keyset_pool_thread(void *arg)
 {
     ks_pool *kp = (ks_pool *)arg;
     for (;;) {
         const uint32_t k = __atomic_fetch_add(&kp->next, 1u, __ATOMIC_RELAXED);
+        ks_job *j;
+        FILE *real_out, *real_err, *mo, *me;
+        int rc;
         if (k >= kp->njobs) return NULL;
-        kp->jobs[k].rc = skh_keyset_from_file(&kp->jobs[k].p->ks, kp->jobs[k].r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0);
+        j = &kp->jobs[k];
+        rc = skh_keyset_from_file(&j->p->ks, j->r, SK_REF_TABLE_SLOTS, SD_PLAIN, 0);
+        real_out = j->p->out; real_err = j->p->err;
+        mo = open_memstream(&j->out_buf, &j->out_len);
+        me = open_memstream(&j->err_buf, &j->err_len);
+        if (mo && me) { j->p->out = mo; j->p->err = me; }
+        j->failed = sd_strain_finish(j->p, rc, j->r, j->a, j->g, j->o, j->device);
+        if (mo) fclose(mo);
+        if (me) fclose(me);
+        j->p->out = real_out; j->p->err = real_err;
         pthread_mutex_lock(&kp->mu);
-        kp->jobs[k].done = 1;
+        j->done = 1;
         pthread_cond_broadcast(&kp->cv);
         pthread_mutex_unlock(&kp->mu);
     }
@@ -884,9 +904,11 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
         }
         free(line);
         fclose(fp);
-        {   /* key sets are built by SK_THREADS (default 8) host threads; the device work of strain k
-             * (table load, -a, -g) starts as soon as its key set is there and overlaps the later builds */
-            int nth = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : 8, t;
+        {   /* the strains are opened by worker threads, each strain start to finish on
+             * one of them; their messages are replayed here in list order, up to the first failure
+             * (SK_THREADS, default: the online CPUs, at most 16) */
+            long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+            int nth = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : (int)(ncpu < 1 ? 1 : ncpu > 16 ? 16 : ncpu), t;
             ks_pool kp;
             pthread_t th[16];
             uint32_t k, failed = 0;
@@ -895,19 +917,28 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
             kp.njobs = ns;
             pthread_mutex_init(&kp.mu, NULL);
             pthread_cond_init(&kp.cv, NULL);
-            for (k = 0; k < ns; k++) { kp.jobs[k].p = &p[k]; kp.jobs[k].r = paths[4 * k]; kp.jobs[k].rc = SK_E_NOMEM; }
+            for (k = 0; k < ns; k++) {
+                ks_job *j = &kp.jobs[k];
+                j->p = &p[k]; j->r = paths[4 * k]; j->a = paths[4 * k + 1]; j->o = paths[4 * k + 2]; j->g = paths[4 * k + 3];
+                j->device = device;
+            }
             if (nth > 16) nth = 16;
             if (nth < 1) nth = 1;
             if ((uint32_t)nth > ns) nth = (int)ns;
             for (t = 0; t < nth; t++) if (pthread_create(&th[t], NULL, sd_keyset_pool_thread, &kp)) break;
             nth = t;
-            if (nth == 0) sd_keyset_pool_thread(&kp);     /* no thread could be started: build them here */
+            if (nth == 0) sd_keyset_pool_thread(&kp);     /* no thread could be started: open them here */
             for (k = 0; k < ns; k++) {
+                ks_job *j = &kp.jobs[k];
                 pthread_mutex_lock(&kp.mu);
-                while (!kp.jobs[k].done) pthread_cond_wait(&kp.cv, &kp.mu);
+                while (!j->done) pthread_cond_wait(&kp.cv, &kp.mu);
                 pthread_mutex_unlock(&kp.mu);
-                if (!failed)
-                    failed = (uint32_t)sd_strain_finish(&p[k], kp.jobs[k].rc, paths[4 * k], paths[4 * k + 1], paths[4 * k + 3], paths[4 * k + 2], device);
+                if (!failed) {
+                    if (j->out_buf && j->out_len) fwrite(j->out_buf, 1, j->out_len, out);
+                    if (j->err_buf && j->err_len) fwrite(j->err_buf, 1, j->err_len, err);
+                    failed = (uint32_t)j->failed;
+                }
+                free(j->out_buf); free(j->err_buf);
             }
             for (t = 0; t < nth; t++) pthread_join(th[t], NULL);
             pthread_mutex_destroy(&kp.mu);
