@@ -29,6 +29,7 @@
 #include "sk_parser.h"
 #include "sk_internal.h"
 #include "sk_ctxjob.h"
+#include "sk_gzfast.h"
 
 
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
@@ -135,6 +136,13 @@ static int sd_on_record(void *user, char *seq, size_t len)
     return 0;
 }
 
+static int sd_feed_sink(void *user, const unsigned char *data, size_t n)
+{
+    parser *ps = (parser *)user;
+    parser_feed(ps, data, n);
+    return ps->state == P_STOP;
+}
+
 static void *sd_decode_thread(void *arg)
 {
     enum { BLK = 1 << 20 };
@@ -144,7 +152,9 @@ static void *sd_decode_thread(void *arg)
     int got;
     sd_chunk *c;
     parser_init(&ps, sd_on_record, st);
-    while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
+    /* gzip through the library's own inflate (sk_gzfast.h); plain files, or SK_ZLIB=1, through zlib */
+    if (getenv("SK_ZLIB") || skz_decode_file(st->path, sd_feed_sink, &ps) == SKZ_NOT_GZIP)
+        while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
     parser_eof(&ps);
     c = st->cur ? st->cur : (sd_chunk *)calloc(1, sizeof *c);
     st->cur = NULL;

@@ -1,0 +1,62 @@
+/* gzfast_check.c -- strainer2_amd/csrc/sk_gzfast.h against zlib: for every file named on the command line
+ * the bytes delivered by skz_decode_file must equal what gzread delivers (for corrupt files: a prefix of the
+ * same length as, or longer than, what gzread managed, and equal where both have data).  Prints one line
+ * per file with both rates.  Built (also under ASan/UBSan) and run by tests/test_gzfast.py. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <zlib.h>
+#include "../../strainer2_amd/csrc/sk_gzfast.h"
+
+typedef struct { unsigned char *p; size_t n, cap; } buf;
+static int collect(void *user, const unsigned char *d, size_t n)
+{
+    buf *b = (buf *)user;
+    if (b->n + n > b->cap) { b->cap = (b->n + n) * 2 + 4096; b->p = realloc(b->p, b->cap); }
+    memcpy(b->p + b->n, d, n);
+    b->n += n;
+    return 0;
+}
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+int main(int argc, char **argv)
+{
+    int i, bad = 0;
+    for (i = 1; i < argc; i++) {
+        buf a = {0}, b = {0};
+        unsigned char *blk = malloc(1 << 20);
+        gzFile g = gzopen(argv[i], "rb");
+        int got, zerr = 0, rc;
+        double t0, t1, t2;
+        if (!g) { printf("%s: cannot open\n", argv[i]); bad = 1; continue; }
+        t0 = now();
+        while ((got = gzread(g, blk, 1 << 20)) > 0) collect(&a, blk, (size_t)got);
+        {   /* zlib reports a truncated or damaged stream through gzread < 0, gzerror or gzclose */
+            int en = Z_OK;
+            gzerror(g, &en);
+            if (got < 0 || (en != Z_OK && en != Z_STREAM_END)) zerr = 1;
+            if (gzclose(g) != Z_OK) zerr = 1;
+        }
+        t1 = now();
+        rc = skz_decode_file(argv[i], collect, &b);
+        t2 = now();
+        if (rc == SKZ_NOT_GZIP) {
+            printf("%s: not gzip (zlib passes %zu bytes through)\n", argv[i], a.n);
+        } else if (rc == SKZ_OK && !zerr) {
+            const int same = a.n == b.n && (a.n == 0 || !memcmp(a.p, b.p, a.n));
+            printf("%s: %s %zu bytes; zlib %.0f MB/s, skz %.0f MB/s\n", argv[i], same ? "OK" : "MISMATCH", b.n,
+                   a.n / (t1 - t0) / 1e6, b.n / (t2 - t1 + 1e-9) / 1e6);
+            bad |= !same;
+        } else {
+            /* a damaged file: both must stop, and agree on the bytes both produced */
+            const size_t m = a.n < b.n ? a.n : b.n;
+            const int same = (rc != SKZ_OK) && zerr && (m == 0 || !memcmp(a.p, b.p, m));
+            printf("%s: damaged, zlib err=%d after %zu bytes, skz rc=%d after %zu bytes: %s\n", argv[i], zerr, a.n, rc, b.n,
+                   same ? "OK" : "MISMATCH");
+            bad |= !same;
+        }
+        free(a.p); free(b.p); free(blk);
+    }
+    return bad;
+}

@@ -1,0 +1,122 @@
+"""The library's own gzip/DEFLATE decoder (strainer2_amd/csrc/sk_gzfast.h) against zlib's gzread on the same
+files: every compression level, stored and fixed-Huffman blocks, long matches, repetitive and incompressible
+data, multi-member files, all optional header fields, trailing garbage, truncated and corrupted streams, empty
+members, and every .gz fixture of the repository.  The comparison program (tests/native/gzfast_check.c) is
+built under AddressSanitizer + UBSan."""
+import gzip
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gz") / "gzfast_check")
+    subprocess.run(["gcc"] + SAN + [os.path.join(REPO, "tests", "native", "gzfast_check.c"), "-lz", "-o", exe], check=True)
+    return exe
+
+
+def run(checker, files):
+    p = subprocess.run([checker] + [str(f) for f in files], env=ENV, capture_output=True)
+    assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    assert b"MISMATCH" not in p.stdout
+    return p.stdout.decode()
+
+
+def payloads():
+    rng = random.Random(12345)
+    dna = "".join(rng.choice("ACGT") for _ in range(300_000))
+    fastq = "".join(f"@r{i}\n{dna[i * 150:(i + 1) * 150]}\n+\n{''.join(rng.choice('ABCDEFGHIJ') for _ in range(150))}\n" for i in range(1500))
+    return {
+        "empty": b"",
+        "one": b"x",
+        "dna": dna.encode(),
+        "fastq": fastq.encode(),
+        "zeros": bytes(400_000),                                   # distance 1, length 258 runs
+        "period3": b"abc" * 150_000,                               # short distances
+        "random": bytes(rng.getrandbits(8) for _ in range(200_000)),   # incompressible: stored blocks at level 1+
+        "text": (b"the quick brown fox jumps over the lazy dog\n" * 20_000),
+        "far": (bytes(rng.getrandbits(8) for _ in range(32_000)) + b"Z") * 6,   # matches at the 32 KiB limit
+    }
+
+
+def test_levels_strategies_and_block_types(checker, tmp_path):
+    files = []
+    for name, data in payloads().items():
+        for level in (0, 1, 2, 4, 6, 9):
+            f = tmp_path / f"{name}.l{level}.gz"
+            with gzip.GzipFile(f, "wb", compresslevel=level, mtime=0) as g:
+                g.write(data)
+            files.append(f)
+        for strat, sname in ((zlib.Z_FIXED, "fixed"), (zlib.Z_HUFFMAN_ONLY, "huff"), (zlib.Z_RLE, "rle"), (zlib.Z_FILTERED, "filt")):
+            c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strat)
+            f = tmp_path / f"{name}.{sname}.gz"
+            f.write_bytes(c.compress(data) + c.flush())
+            files.append(f)
+        # many small blocks: a sync flush every few hundred bytes
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        out = b"".join(c.compress(data[i:i + 777]) + c.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(data), 777)) + c.flush()
+        f = tmp_path / f"{name}.sync.gz"
+        f.write_bytes(out)
+        files.append(f)
+    out = run(checker, files)
+    assert out.count(" OK ") == len(files)
+
+
+def test_members_headers_and_garbage(checker, tmp_path):
+    p = payloads()
+    a, b = gzip.compress(p["fastq"], 6, mtime=0), gzip.compress(p["dna"], 1, mtime=0)
+    (tmp_path / "two.gz").write_bytes(a + b)
+    (tmp_path / "three_with_empty.gz").write_bytes(a + gzip.compress(b"", mtime=0) + b)
+    (tmp_path / "garbage_after.gz").write_bytes(a + b"this is not gzip" * 10)
+    (tmp_path / "zeros_after.gz").write_bytes(a + bytes(100))
+    # FEXTRA + FNAME + FCOMMENT + FHCRC
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = raw.compress(p["text"]) + raw.flush()
+    hdr = bytes([0x1F, 0x8B, 8, 2 | 4 | 8 | 16, 0, 0, 0, 0, 0, 3]) + (5).to_bytes(2, "little") + b"extra" + b"name.txt\0" + b"a comment\0"
+    hdr += (zlib.crc32(hdr) & 0xFFFF).to_bytes(2, "little")
+    (tmp_path / "all_fields.gz").write_bytes(hdr + body + zlib.crc32(p["text"]).to_bytes(4, "little") + (len(p["text"]) & 0xFFFFFFFF).to_bytes(4, "little"))
+    (tmp_path / "plain.txt").write_bytes(p["fastq"])
+    out = run(checker, sorted(tmp_path.iterdir()))
+    assert out.count(" OK ") == 5 and "not gzip" in out
+
+
+def test_truncated_and_corrupted(checker, tmp_path):
+    p = payloads()
+    good = gzip.compress(p["fastq"], 6, mtime=0)
+    rng = random.Random(7)
+    files = []
+    for cut in (len(good) - 1, len(good) - 4, len(good) - 9, len(good) // 2, 100, 30, 19):
+        f = tmp_path / f"cut{cut}.gz"
+        f.write_bytes(good[:cut])
+        files.append(f)
+    for i in range(12):
+        bad = bytearray(good)
+        pos = rng.randrange(20, len(bad) - 8)
+        bad[pos] ^= 1 << rng.randrange(8)
+        f = tmp_path / f"flip{i}.gz"
+        f.write_bytes(bytes(bad))
+        files.append(f)
+    crc = bytearray(good)
+    crc[-6] ^= 0xFF
+    (tmp_path / "bad_crc.gz").write_bytes(bytes(crc))
+    files.append(tmp_path / "bad_crc.gz")
+    out = run(checker, files)
+    assert out.count("damaged") >= len(files) - 12          # (a flipped bit may happen to decode cleanly up to the CRC)
+
+
+def test_every_gz_fixture_of_the_repository(checker):
+    files = []
+    for root, _d, names in os.walk(os.path.join(REPO, "tests", "golden")):
+        files += [os.path.join(root, n) for n in names if n.endswith(".gz")]
+    assert len(files) > 50
+    out = run(checker, sorted(files))
+    assert out.count(" OK ") == len(files)
