@@ -17,6 +17,7 @@
 #include <zlib.h>
 #include "../../include/strainer_kmer.h"
 #include "sk_pyfmt.h"
+#include "sk_gzfast.h"
 
 /* ------------------------------------------------------------------ distinct keys */
 typedef struct {
@@ -159,51 +160,89 @@ static int take_line(tables *t, int file_idx, char *s, size_t len)
     return FLT_OK;
 }
 
+/* decompressed text arrives in pieces of any size (the library's own inflate hands out a few MB at a time,
+ * gzread whatever fits): complete lines are taken as they come, the tail waits for the next piece */
+typedef struct { tables *t; int file_idx, rc; char *carry; size_t have, cap; } line_feed;
+
+static int feed_lines(void *user, const unsigned char *data, size_t n)
+{
+    line_feed *f = (line_feed *)user;
+    const char *p = (const char *)data, *end = p + n, *nl;
+    if (f->have) {                                    /* finish the line left over from the previous piece */
+        nl = memchr(p, '\n', n);
+        {
+            const size_t add = nl ? (size_t)(nl - p) : n;
+            if (f->have + add + 1 > f->cap) {
+                size_t cap = f->cap ? f->cap : 4096;
+                char *c;
+                while (cap < f->have + add + 1) cap *= 2;
+                if (!(c = realloc(f->carry, cap))) { f->rc = FLT_NOMEM; return 1; }
+                f->carry = c; f->cap = cap;
+            }
+            memcpy(f->carry + f->have, p, add);
+            f->have += add;
+        }
+        if (!nl) return 0;
+        {
+            size_t len = f->have;
+            if (len && f->carry[len - 1] == '\r') len--;          /* text mode reads "\r\n" as one newline */
+            if ((f->carry[0] != '#' || len == 0) && (f->rc = take_line(f->t, f->file_idx, f->carry, len)) != FLT_OK) return 1;
+        }
+        f->have = 0;
+        p = nl + 1;
+    }
+    while ((nl = memchr(p, '\n', (size_t)(end - p))) != NULL) {
+        size_t len = (size_t)(nl - p);
+        if (len && p[len - 1] == '\r') len--;
+        if ((p[0] != '#' || len == 0) && (f->rc = take_line(f->t, f->file_idx, (char *)p, len)) != FLT_OK) return 1;
+        p = nl + 1;
+    }
+    if (p < end) {                                    /* keep the unfinished line */
+        const size_t add = (size_t)(end - p);
+        if (add + 1 > f->cap) {
+            size_t cap = f->cap ? f->cap : 4096;
+            char *c;
+            while (cap < add + 1) cap *= 2;
+            if (!(c = realloc(f->carry, cap))) { f->rc = FLT_NOMEM; return 1; }
+            f->carry = c; f->cap = cap;
+        }
+        memcpy(f->carry, p, add);
+        f->have = add;
+    }
+    return 0;
+}
+
 static int read_table(tables *t, int file_idx, const char *path)
 {
-    gzFile gz = gzopen(path, "rb");
-    size_t cap = 4u << 20, have = 0;
-    char *buf;
-    int n, rc = FLT_OK;
+    line_feed f;
     keydict *d = &t->keys;
-    if (!gz) return FLT_OPEN;
-    gzbuffer(gz, 1u << 20);
-    if (!(buf = malloc(cap))) { gzclose(gz); return FLT_NOMEM; }
+    int zrc;
+    memset(&f, 0, sizeof f);
+    f.t = t; f.file_idx = file_idx; f.rc = FLT_OK;
     if (file_idx > 0 && d->n) {       /* the previous file's strain dictionary, for the identity check (:169-170,199-201) */
         memcpy(d->prev_file, d->cur_file, (size_t)d->n * sizeof *d->cur_file);
         memcpy(d->prev_val, d->cur_val, (size_t)d->n * sizeof *d->cur_val);
     }
     t->norder = 0;
     t->all_kmers = 0;
-    for (;;) {
-        char *line, *nl, *end;
-        if (have == cap) {            /* a line longer than the buffer */
-            char *b = realloc(buf, cap * 2);
-            if (!b) { rc = FLT_NOMEM; break; }
-            buf = b; cap *= 2;
-        }
-        n = gzread(gz, buf + have, (unsigned)(cap - have));
-        if (n < 0) { rc = FLT_OPEN; break; }
-        have += (size_t)n;
-        end = buf + have;
-        line = buf;
-        while ((nl = memchr(line, '\n', (size_t)(end - line))) != NULL) {
-            size_t len = (size_t)(nl - line);
-            if (len && line[len - 1] == '\r') len--;          /* text mode reads "\r\n" as one newline */
-            if (line[0] != '#' || len == 0) { if ((rc = take_line(t, file_idx, line, len)) != FLT_OK) goto out; }
-            line = nl + 1;
-        }
-        have = (size_t)(end - line);
-        memmove(buf, line, have);
-        if (n == 0) {
-            if (have && buf[0] != '#' && (rc = take_line(t, file_idx, buf, have)) != FLT_OK) goto out;
-            break;
-        }
+    zrc = getenv("SK_ZLIB") ? SKZ_NOT_GZIP : skz_decode_file(path, feed_lines, &f);     /* own inflate; zlib for anything that is not gzip */
+    if (zrc == SKZ_OPEN) { free(f.carry); return FLT_OPEN; }
+    if (zrc == SKZ_NOT_GZIP) {
+        gzFile gz = gzopen(path, "rb");
+        unsigned char *buf;
+        int n;
+        if (!gz) { free(f.carry); return FLT_OPEN; }
+        gzbuffer(gz, 1u << 20);
+        if (!(buf = malloc(1u << 20))) { gzclose(gz); free(f.carry); return FLT_NOMEM; }
+        while ((n = gzread(gz, buf, 1u << 20)) > 0)
+            if (feed_lines(&f, buf, (size_t)n)) break;
+        free(buf);
+        gzclose(gz);
     }
-out:
-    free(buf);
-    gzclose(gz);
-    return rc;
+    if (f.rc == FLT_OK && f.have && f.carry[0] != '#')         /* last line without a newline */
+        f.rc = take_line(t, file_idx, f.carry, f.have);
+    free(f.carry);
+    return f.rc;
 }
 
 /* strain_hash != previous_strain_hash (:199-201): both dictionaries hold the same keys with the same values */
