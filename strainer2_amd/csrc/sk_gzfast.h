@@ -22,6 +22,7 @@
 #ifndef SK_GZFAST_H
 #define SK_GZFAST_H
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -139,7 +140,7 @@ typedef struct {
 } skz_stream;
 
 static uint32_t skz_crc_tab[8][256];
-static int skz_crc_ready;
+static pthread_once_t skz_crc_once = PTHREAD_ONCE_INIT;
 static uint32_t skz_crc32_table(uint32_t crc, const unsigned char *p, size_t n);
 #if defined(__x86_64__)
 static uint32_t skz_crc32_clmul(uint32_t crc, const unsigned char *buf, size_t n);
@@ -165,7 +166,6 @@ static void skz_crc_init(void)
         skz_crc_clmul_ok = (int)ok;
     }
 #endif
-    __atomic_store_n(&skz_crc_ready, 1, __ATOMIC_RELEASE);
 }
 static uint32_t skz_crc32_table(uint32_t crc, const unsigned char *p, size_t n)
 {
@@ -510,7 +510,7 @@ static int skz_decode_memory(const unsigned char *data, size_t n, skz_sink sink,
     size_t pos = 0, h;
     int rc = SKZ_OK, members = 0;
     if ((h = skz_header(data, n)) == 0) return SKZ_NOT_GZIP;
-    if (!__atomic_load_n(&skz_crc_ready, __ATOMIC_ACQUIRE)) skz_crc_init();
+    pthread_once(&skz_crc_once, skz_crc_init);
     memset(&s, 0, sizeof s);
     dyn = (skz_tables *)malloc(sizeof *dyn);
     fixed = (skz_tables *)malloc(sizeof *fixed);
