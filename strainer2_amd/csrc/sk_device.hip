@@ -53,7 +53,8 @@
 #ifndef SK_STREAM_POLICY
 #define SK_STREAM_POLICY 0
 #endif
-#define SK_NCHUNK_GRID  (SK_NCHUNK + 1)     // grid kernel: plus the chunk after the tile
+#define SK_NCHUNK_GRID  (SK_NCHUNK + 1)
+#define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
 #ifndef SK_PUMP_EVERY
 #define SK_PUMP_EVERY   2                   // windows between two drain sites (power of two <= 16)
 #endif
@@ -83,6 +84,10 @@ struct sk_table_view {
     // large one that settles what the small one lets through
     const uint2    *grid1, *grid2;
     uint32_t        grid1_blocks, grid2_shift;
+    // chunks (stream offset / 16) in which phase 1 saw a byte that only the byte-string kernel can judge;
+    // the count is flags[2]
+    uint32_t       *oddlist;
+    uint32_t        oddcap;
 };
 
 __device__ __forceinline__ uint64_t sk_slot_key(const sk_u4 e) { return ((uint64_t)e.y << 32) | e.x; }
@@ -318,7 +323,13 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             sk_decode4(v.z, c2, i2);
             sk_decode4(v.w, c3, i3);
             const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
-            bad |= sk_chunk_has_odd_byte(v, inv16);
+            if (sk_chunk_has_odd_byte(v, inv16)) {
+                bad = 1;
+                if (c >= SK_SPAN_CH) {                                   // (the chunks before the tile are the previous tile's)
+                    const uint32_t at = atomicAdd(&flags[2], 1u);
+                    if (at < table.oddcap) table.oddlist[at] = (uint32_t)((uint64_t)off >> 4);
+                }
+            }
             const uint32_t r = c >> 3, sl = c & 7u;
             rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
             ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
@@ -641,7 +652,13 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             sk_decode4(v.w, c3, i3);
             const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
             // bytes of the chunk after the tile belong to the next tile, which reports them itself
-            if (c < SK_NCHUNK) bad |= sk_chunk_has_odd_byte(v, inv16);
+            if (c < SK_NCHUNK && sk_chunk_has_odd_byte(v, inv16)) {
+                bad = 1;
+                if (c >= SK_SPAN_CH) {                                   // (the chunks before the tile are the previous tile's)
+                    const uint32_t at = atomicAdd(&flags[2], 1u);
+                    if (at < table.oddcap) table.oddlist[at] = (uint32_t)((tile0 - SK_SPAN + (uint64_t)c * 16u) >> 4);
+                }
+            }
             const uint32_t r = c >> 3, sl = c & 7u;
             rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
             ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
@@ -850,19 +867,31 @@ void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                   const uint32_t *__restrict__ flags)
 {
     if (flags[0] == 0u) return;                        // no window with a non-ACGT byte in this batch
+    // Work list: phase 1 of the scan kernel noted every 16-byte chunk that holds such a byte (flags[2] of them).
+    // A window that needs this kernel contains one; it is handled from the chunk that holds its LAST non-ACGT
+    // byte, so every window is handled once and the cost follows the number of odd bytes, not the batch size.
+    // If the list overflowed, every position of the batch is visited instead.
+    const uint32_t nodd = flags[2];
+    const bool listed = nodd <= table.oddcap;
+    const uint64_t nitems = listed ? (uint64_t)nodd * 46u : nbytes;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t p = emit_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nbytes; p += stride) {
-        if (p < (uint64_t)(SK_K - 1)) continue;
+    for (uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; item < nitems; item += stride) {
+        uint64_t p, owner = ~0ull;
+        if (listed) { owner = table.oddlist[item / 46u]; p = owner * 16u + item % 46u; }
+        else p = item;
+        if (p < emit_begin || p >= nbytes || p < (uint64_t)(SK_K - 1)) continue;
         const uint8_t *w = stream + (p - (SK_K - 1));
         char u[SK_K];
         bool hard = false, pure = true;
+        int last_odd = -1;
         for (int i = 0; i < SK_K; i++) {
             const uint32_t b = w[i];
             hard |= (bool)sk_is_hard_break(b);
-            pure &= (bool)sk_is_acgt(b);
+            if (!sk_is_acgt(b)) { pure = false; last_odd = i; }
             u[i] = (char)sk_upper(b);
         }
-        if (hard || pure) continue;                    // skipped by the reference / done by sk_scan_main
+        if (hard || pure) continue;                    // skipped by the reference / done by the scan kernel
+        if (listed && ((p - (SK_K - 1) + (uint64_t)last_odd) >> 4) != owner) continue;   // another chunk's window
         // orientation: sign of (window - revcomp) in signed-char order (src/genome_compare.c:1122-1141)
         int sign = 0;
         for (int i = 0; i < SK_K && sign == 0; i++) {
@@ -1012,6 +1041,7 @@ struct sk_ctx {
     uint32_t     grid1_blocks, grid2_blocks_log2;
     long         grid_kib;                // option: size of level 1 in KiB (-1 = automatic)
     long         kernel;                  // option: 0 = grid kernel (default), 1 = minimizer kernel
+    long         odd_cap;                 // option (tests): usable length of the odd-chunk list, 0 = all of it
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
     uint32_t    *d_perm, *d_inv;      // locality order of the counters (NULL = caller's row order)
@@ -1033,6 +1063,7 @@ struct sk_ctx {
     uint64_t     tickets;              // tickets issued so far
     // flags: [0] wide windows seen in the current batch, [1] table build errors
     uint32_t    *d_flags;
+    uint32_t    *d_oddlist;           // chunks with a byte for the byte-string kernel (SK_ODDCAP entries)
     // timing
     std::vector<hipEvent_t> ev;        // begin/end pairs
     double       timed_ms;
@@ -1108,6 +1139,7 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     c->err[0] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SK_E_NODEVICE; }
     if (hipMalloc((void **)&c->d_flags, 16 * sizeof(uint32_t)) != hipSuccess) { delete c; return SK_E_NOMEM; }
+    if (hipMalloc((void **)&c->d_oddlist, (size_t)SK_ODDCAP * sizeof(uint32_t)) != hipSuccess) { hipFree(c->d_flags); delete c; return SK_E_NOMEM; }
     hipMemsetAsync(c->d_flags, 0, 16 * sizeof(uint32_t), c->stream);
     signed char comp[256];
     sk_fill_complement(comp);
@@ -1156,6 +1188,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
     hipFree(c->t_tally); hipFree(c->t_hits);
     if (c->h_tally) hipHostFree(c->h_tally);
     hipFree(c->d_flags);
+    hipFree(c->d_oddlist);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1166,6 +1199,7 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
     if (!strcmp(name, "table_load_pct")) { if (value < 5 || value > 90) return SK_E_ARG; c->table_load_pct = value; return SK_OK; }
     if (!strcmp(name, "bloom_bits_log2")) { if (value < -1 || value > 34 || (value > 0 && value < 10)) return SK_E_ARG; c->bloom_bits_log2 = value; return SK_OK; }
     if (!strcmp(name, "grid_kib")) { if (value < -1 || value == 0 || value > (1 << 22)) return SK_E_ARG; c->grid_kib = value; return SK_OK; }
+    if (!strcmp(name, "odd_list_cap")) { if (value < 0 || value > (long)SK_ODDCAP) return SK_E_ARG; c->odd_cap = value; return SK_OK; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 1) return SK_E_ARG; c->kernel = value; return SK_OK; }
     if (!strcmp(name, "stats")) { c->stats = value != 0; return SK_OK; }
     if (!strcmp(name, "ablate")) { c->ablate = value; return SK_OK; }
@@ -1307,6 +1341,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     tv.slots = c->d_keys; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
     tv.bloom = c->d_bloom;
     tv.bloom_shift = 32u - c->bloom_blocks_log2;
+    tv.oddlist = c->d_oddlist; tv.oddcap = c->odd_cap ? (uint32_t)c->odd_cap : SK_ODDCAP;
     tv.grid1 = c->d_grid1; tv.grid2 = c->d_grid2;
     tv.grid1_blocks = c->grid1_blocks; tv.grid2_shift = 32u - c->grid2_blocks_log2;
     sk_wide_view wv;
@@ -1318,7 +1353,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     else sink.counts = c->d_counts + (size_t)col * c->nrows;
     const dim3 grid((uint32_t)ntiles), block(SK_THREADS);
 
-    SK_HIP(c, hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), c->stream));
+    SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(uint32_t), c->stream));     // [0] odd bytes seen, [2] listed chunks
     hipEvent_t e0 = NULL, e1 = NULL;
     const bool timed = c->ev.size() < 2 * 8192;
     if (timed) {

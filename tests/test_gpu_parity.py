@@ -147,6 +147,30 @@ def test_both_scan_kernels_vs_oracle(kernel):
     assert np.array_equal(got, ocounts[:, 2]) and got.sum() > 10_000
 
 
+@pytest.mark.parametrize("cap", [0, 3])
+def test_byte_string_path_list_and_overflow(cap):
+    """windows with IUPAC letters / U are found through the list of chunks that hold such bytes; with the list
+    cut to 3 entries it overflows and the byte-string kernel visits every position instead: same counts"""
+    rng = random.Random(5150)
+    strain = bytearray(_synth.rand_dna(rng, 30_000))
+    for ch in b"RYKMSW":
+        for _ in range(3):
+            strain[rng.randrange(len(strain))] = ch
+    sstream = bytes(strain) + b"\n"
+    ks = sk.Keyset.from_stream(sstream)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    data = _synth.fuzz_stream(rng, bytes(strain), 1500, p_junk=0.004, min_len=0, max_len=300)
+    with sk.KmerContext(0) as c:
+        c.set_option("odd_list_cap", cap)
+        c.load_keyset(ks, 4)
+        c.scan_stream(data, 1)
+        t.scan_stream(data, 1)
+        _, ocounts = t.rows()
+        got = c.counts(1)
+    assert np.array_equal(got, ocounts[:, 1]) and got.sum() > 5_000
+
+
 def test_scan_device_equals_scan_stream_and_tile_edges(ctx):
     """Device-resident entry point; stream lengths around tile (32768) and chunk (16) edges."""
     rng = random.Random(7)
