@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
 #include "../../include/strainer_kmer.h"
 #include "sk_pyfmt.h"
@@ -41,10 +42,13 @@ static uint64_t key_hash(const char *s, size_t len)
     return h ^ (h >> 31);
 }
 
-static int kd_init(keydict *d)
+/* hint_keys: about how many distinct keys to expect (0 = unknown); the slot array starts big enough for them
+ * instead of getting there by repeated rehashing */
+static int kd_init(keydict *d, uint64_t hint_keys)
 {
     memset(d, 0, sizeof *d);
     d->nslot = 1u << 16;
+    while (d->nslot < 2 * hint_keys && d->nslot < (1ull << 31)) d->nslot <<= 1;
     d->slot = calloc(d->nslot, sizeof *d->slot);
     return d->slot ? 0 : -1;
 }
@@ -191,11 +195,27 @@ static int feed_lines(void *user, const unsigned char *data, size_t n)
         f->have = 0;
         p = nl + 1;
     }
-    while ((nl = memchr(p, '\n', (size_t)(end - p))) != NULL) {
-        size_t len = (size_t)(nl - p);
-        if (len && p[len - 1] == '\r') len--;
-        if ((p[0] != '#' || len == 0) && (f->rc = take_line(f->t, f->file_idx, (char *)p, len)) != FLT_OK) return 1;
-        p = nl + 1;
+    for (;;) {                                        /* lines in batches: the dictionary slots of a batch are
+                                                       * prefetched before its lines are taken (every new key is a
+                                                       * cache miss in a table of tens of MB otherwise) */
+        enum { BATCH = 32 };
+        const char *lp[BATCH];
+        size_t ll[BATCH];
+        int nb = 0, i;
+        while (nb < BATCH && (nl = memchr(p, '\n', (size_t)(end - p))) != NULL) {
+            size_t len = (size_t)(nl - p);
+            if (len && p[len - 1] == '\r') len--;
+            if (p[0] != '#' || len == 0) {
+                const char *tab = memchr(p, '\t', len);
+                const keydict *d = &f->t->keys;
+                lp[nb] = p; ll[nb] = len; nb++;
+                if (tab) __builtin_prefetch(&d->slot[key_hash(p, (size_t)(tab - p)) & (d->nslot - 1)]);
+            }
+            p = nl + 1;
+        }
+        for (i = 0; i < nb; i++)
+            if ((f->rc = take_line(f->t, f->file_idx, (char *)lp[i], ll[i])) != FLT_OK) return 1;
+        if (nb < BATCH) break;
     }
     if (p < end) {                                    /* keep the unfinished line */
         const size_t add = (size_t)(end - p);
@@ -428,7 +448,13 @@ int skh_scrub_filter_main(int argc, char **argv, FILE *out, FILE *err)
     }
 
     memset(&t, 0, sizeof t);
-    if (kd_init(&t.keys)) { fprintf(err, "kmer_scrub_filter: out of memory\n"); return 1; }
+    {   /* a table line is ~38 bytes and gzip shrinks the tables about nine-fold */
+        struct stat st;
+        uint64_t hint = 0;
+        if (nfiles && stat(files[0], &st) == 0 && S_ISREG(st.st_mode)) hint = (uint64_t)st.st_size * 9u / 38u;
+        if (hint > (1ull << 28)) hint = 1ull << 28;
+        if (kd_init(&t.keys, hint)) { fprintf(err, "kmer_scrub_filter: out of memory\n"); return 1; }
+    }
     for (fi = 0; fi < nfiles; fi++) {                /* :164-201 */
         rc = read_table(&t, (int)fi, files[fi]);
         if (rc == FLT_OPEN) { fprintf(err, "kmer_scrub_filter: could not read %s\n", files[fi]); goto done; }
