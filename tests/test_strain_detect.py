@@ -217,3 +217,27 @@ def test_sd_many_strains_golden_strain_plus_another(golden, tmp_path):
     q = subprocess.run([exe, "-r", f"{other}/strain.fa", "-a", f"{other}/inf.txt", "-B", "B.txt", "-o", str(tmp_path / "b1.gz")], cwd=d, capture_output=True)
     assert q.returncode == 0
     assert gzip.open(tmp_path / "b.gz", "rb").read() == gzip.open(tmp_path / "b1.gz", "rb").read()
+
+
+@pytest.mark.gpu
+def test_sd_strain_list_is_dealt_to_ranks(golden, tmp_path):
+    """-S with RANK/WORLD_SIZE: strain i of the list belongs to rank i % world (no collective); each rank writes
+    only its own outfiles, and they equal the single-process ones"""
+    d = os.path.join(golden, "sd_cases", "batch")
+    exe = sk.cli_path("strain_detect")
+    with open(tmp_path / "strains.txt", "w") as f:
+        for s in range(3):
+            f.write(f"strain.fa\tinf.txt.gz\t{tmp_path}/r{s}.gz\n")
+    want = open(os.path.join(d, "expected.hits"), "rb").read()
+    for rank in (0, 1):
+        env = dict(os.environ, SK_WORLD_SIZE="2", SK_RANK=str(rank), SK_LOCAL_RANK="0")
+        p = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", "B.txt"], cwd=d, env=env, capture_output=True)
+        assert p.returncode == 0, p.stderr.decode()[-500:]
+    assert sorted(x for x in os.listdir(tmp_path) if x.startswith("r")) == ["r0.gz", "r1.gz", "r2.gz"]
+    for s in range(3):
+        assert gzip.open(tmp_path / f"r{s}.gz", "rb").read() == want
+    # a world of two where one rank has nothing to do
+    (tmp_path / "one.txt").write_text(f"strain.fa\tinf.txt.gz\t{tmp_path}/only.gz\n")
+    p = subprocess.run([exe, "-S", str(tmp_path / "one.txt"), "-B", "B.txt"], cwd=d, capture_output=True,
+                       env=dict(os.environ, SK_WORLD_SIZE="2", SK_RANK="1"))
+    assert p.returncode == 0 and not os.path.exists(tmp_path / "only.gz")
