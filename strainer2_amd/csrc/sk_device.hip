@@ -54,6 +54,8 @@
 #define SK_STREAM_POLICY 0
 #endif
 #define SK_NCHUNK_GRID  (SK_NCHUNK + 1)
+#define SK_AGG_LOG2     9
+#define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
 #ifndef SK_PUMP_EVERY
 #define SK_PUMP_EVERY   2                   // windows between two drain sites (power of two <= 16)
@@ -606,10 +608,16 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 {
     __shared__ __attribute__((aligned(16))) uint32_t rec[(SK_NREC + 1) * SK_REC_DW];
     __shared__ uint16_t wq_all[SK_WAVES][128 + 16];              // below 128 before a push of at most 16
+    // COUNT mode: rows this workgroup has already counted once in this tile; further hits on them are added
+    // up here and flushed with one atomic per row at the end.  Reads that repeat (duplicates, conserved or
+    // low-complexity k-mers) would otherwise serialise on a few counters in the L2 (same-address atomics).
+    __shared__ uint2 agg[SK_AGG];
 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+    if (!TALLY)
+        for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) agg[i] = make_uint2(0xFFFFFFFFu, 0u);   // (visible after phase 1's barrier)
 
     // ================= phase 1: bytes -> packed codes + invalid masks ==========================
     // All of a thread's 16-byte loads are issued before the first is decoded (nine HBM latencies in
@@ -776,10 +784,26 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 if (hit[s2] == 0xFFFFFFFFu) { uint32_t unused; hit[s2] = sk_find(cn[s2], table, &unused); }
             }
         }
+        if (TALLY) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            if (TALLY) sk_tally_wave(sink, act[s2] ? hit[s2] : 0xFFFFFFFFu, pos[s2], lane);
-            else if (hit[s2] != 0xFFFFFFFFu) sk_on_hit<false, ABLATE == 3>(sink, hit[s2], pos[s2]);
+            for (int s2 = 0; s2 < 2; s2++) sk_tally_wave(sink, act[s2] ? hit[s2] : 0xFFFFFFFFu, pos[s2], lane);
+        } else {
+            // first sighting of a row in this tile: count it in HBM now (neighbouring counters coalesce); seen
+            // before: add it up in LDS; its table slot taken by another row: count it in HBM as well.  Both
+            // slots' LDS round trips are in flight together.
+            uint32_t a[2], old[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                a[s2] = (hit[s2] * 0x9E3779B1u) >> (32 - SK_AGG_LOG2);
+                old[s2] = 0xFFFFFFFFu;
+                if (hit[s2] != 0xFFFFFFFFu) old[s2] = atomicCAS(&agg[a[s2]].x, 0xFFFFFFFFu, hit[s2]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                if (hit[s2] == 0xFFFFFFFFu) continue;
+                if (old[s2] == hit[s2]) atomicAdd(&agg[a[s2]].y, 1u);
+                else sk_on_hit<false, ABLATE == 3>(sink, hit[s2], pos[s2]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -845,6 +869,13 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     __builtin_amdgcn_wave_barrier();
     if (qw) probe_some(qw);
     if (bad) atomicAdd(&flags[0], 1u);
+    if (!TALLY) {                                                 // the repeats of this tile, one atomic per row
+        __syncthreads();
+        for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) {
+            const uint2 e = agg[i];
+            if (e.y != 0u && ABLATE != 3) atomicAdd(&sink.counts[e.x], e.y);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
