@@ -1,0 +1,101 @@
+"""Differential fuzzing of the scan against the oracle: many small random worlds (strain size and content,
+IUPAC letters and U in strain and reads, low-complexity and repeated stretches, duplicated reads, read lengths
+around k and around the 16-byte chunk grid, junk rates, streams that cross tile boundaries), all three scanned
+columns compared count for count, then the same through TALLY mode (per-read tallies and the hit log)."""
+import random
+
+import numpy as np
+import pytest
+
+import _oracle
+import _synth
+import strainer2_amd as sk
+
+pytestmark = pytest.mark.gpu
+
+
+def world(seed):
+    rng = random.Random(seed)
+    kind = seed % 6
+    n = rng.choice([40, 300, 3000, 30000, 120000])
+    strain = bytearray(_synth.rand_dna(rng, n))
+    if kind == 1:                                      # low complexity and tandem repeats
+        unit = _synth.rand_dna(rng, rng.choice([1, 2, 3, 7, 16, 31, 33]))
+        at = rng.randrange(0, max(1, n - 400))
+        rep = (unit * 400)[:min(400, n - at)]
+        strain[at:at + len(rep)] = rep
+    if kind == 2:                                      # IUPAC letters, U and N in the strain
+        for ch in b"RYKMSWBDHVUNn":
+            strain[rng.randrange(n)] = ch
+    if kind == 3 and n > 200:                          # the strain repeats itself (multiplicities > 1)
+        strain[n // 2:n // 2 + 100] = strain[10:110]
+    cut = rng.randrange(1, n)
+    sstream = bytes(strain[:cut]) + b"\n" + (bytes(strain[cut:]).lower() if kind == 4 else bytes(strain[cut:])) + b"\n"
+    junk = [0.0, 0.001, 0.01, 0.05][seed % 4]
+    lens = [(0, 64), (28, 34), (0, 200), (140, 160), (300, 2000), (15, 49)][seed % 6]
+    nreads = max(50, min(4000, 400_000 // (lens[1] + 1)))
+    data = _synth.fuzz_stream(rng, bytes(strain), nreads, p_junk=junk, min_len=lens[0], max_len=lens[1])
+    if kind == 5:                                      # the same read over and over
+        one = bytes(strain[:min(n, 150)]).replace(b"N", b"A") + b"\n"
+        data += one * 3000
+    return sstream, data
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_scan_count_fuzz(seed):
+    sstream, data = world(seed)
+    ks = sk.Keyset.from_stream(sstream)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream, short_policy=1) == 0          # (records under k-1 bases: skipped, as the product does)
+    with sk.KmerContext(0) as c:
+        if seed % 5 == 0:
+            c.set_option("kernel", 1)                  # the previous-generation kernel now and then
+        c.load_keyset(ks, 4)
+        third = len(data) // 3
+        cuts = [0, data.rfind(b"\n", 0, third) + 1, data.rfind(b"\n", 0, 2 * third) + 1, len(data)]
+        for col in (1, 2, 3):
+            piece = data[cuts[col - 1]:cuts[col]]
+            c.scan_stream(piece, col)
+            t.scan_stream(piece, col)
+        c.scan_stream(data, 2)                         # and the whole thing once more into one column
+        t.scan_stream(data, 2)
+        okeys, ocounts = t.rows()
+        assert ks.keys() == okeys
+        for col in range(4):
+            assert np.array_equal(c.counts(col), ocounts[:, col]), (seed, col)
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_tally_fuzz(seed):
+    """per-read tallies and the log of informative hits against counts derived from the oracle's scan of each
+    read on its own"""
+    sstream, data = world(seed)
+    ks = sk.Keyset.from_stream(sstream, default_val=1, incr=0)
+    reads = [r for r in data.split(b"\n")[:-1] if len(r) >= 31][:400]
+    if not reads or ks.nrows == 0:
+        pytest.skip("no read of k bases in this world")
+    rng = random.Random(seed)
+    inf_rows = np.array(sorted(rng.sample(range(ks.nrows), max(1, ks.nrows // 7))))
+    stream = b"\n".join(reads) + b"\n"
+    starts = np.cumsum([0] + [len(r) + 1 for r in reads[:-1]])
+    with sk.KmerContext(0) as c:
+        c.load_keyset(ks, 6)
+        typ = np.ones(ks.nrows, dtype=np.uint32)
+        typ[inf_rows] = 2
+        c.set_counts(0, typ)
+        tally, hits = c.tally_batch(stream, starts, 0, 2)
+    t = _oracle.OracleTable(ncols=6)
+    assert t.build_stream(sstream, default=1, incr=0, short_policy=1) == 0
+    assert ks.keys() == t.rows()[0]
+    is_inf = np.zeros(ks.nrows, dtype=bool)
+    is_inf[inf_rows] = True
+    prev = np.zeros(ks.nrows, dtype=np.int64)
+    for i, r in enumerate(reads):                      # the oracle one read at a time: differences of its counters
+        t.scan_stream(r + b"\n", 1)
+        _, oc = t.rows()
+        now = oc[:, 1].astype(np.int64)
+        d = now - prev
+        prev = now
+        assert int(tally[i, 0]) == int(d.sum()), (seed, i)
+        assert int(tally[i, 1]) == int(d[is_inf].sum()), (seed, i)
+    assert len(hits) == int(tally[:, 1].sum())
