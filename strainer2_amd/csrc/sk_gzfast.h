@@ -546,6 +546,7 @@ static int skz_decode_memory(const unsigned char *data, size_t n, skz_sink sink,
     return rc;
 }
 
+__attribute__((unused))
 static int skz_decode_file(const char *path, skz_sink sink, void *user)
 {
     const int fd = open(path, O_RDONLY);

@@ -32,7 +32,7 @@
 
 #include "sk_parser.h"
 #include "sk_ctxjob.h"
-#include "sk_gzfast.h"
+#include "sk_gzpipe.h"
 
 /* tables of tens of MB that are touched at random: 2 MiB-aligned and offered to transparent huge pages
  * (fewer page faults while they are filled, fewer TLB misses while they are probed) */
@@ -57,7 +57,8 @@ static int parse_feed_sink(void *user, const unsigned char *data, size_t n)
     return ps->state == P_STOP;
 }
 
-static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords, int *sink_rc)
+/* pipe: inflate on a helper thread while this one parses (worth it when there are fewer files than cores) */
+static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords, int *sink_rc, int pipe)
 {
     enum { BLK = 1 << 20 };
     gzFile g;
@@ -67,7 +68,17 @@ static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords
     parser_init(&ps, fn, user);
     /* gzip files go through the library's own inflate (sk_gzfast.h, about twice zlib's rate); anything else
      * -- plain text, which gzread passes through, or SK_ZLIB=1 -- through zlib */
-    zrc = getenv("SK_ZLIB") ? SKZ_NOT_GZIP : skz_decode_file(path, parse_feed_sink, &ps);
+    if (getenv("SK_ZLIB")) zrc = SKZ_NOT_GZIP;
+    else if (pipe) {
+        skzp zp;
+        zrc = skzp_open(&zp, path);
+        if (zrc == SKZ_OK) {
+            const unsigned char *data;
+            size_t n;
+            while (ps.state != P_STOP && (n = skzp_next(&zp, &data)) > 0) parser_feed(&ps, data, n);
+            skzp_close(&zp);
+        }
+    } else zrc = skz_decode_file(path, parse_feed_sink, &ps);
     if (zrc == SKZ_OPEN) { parser_free(&ps); return SK_E_OPEN; }
     if (zrc == SKZ_NOT_GZIP) {
         g = gzopen(path, "r");
@@ -162,7 +173,7 @@ int64_t skh_decode_file(const char *path, uint64_t chunk_bytes, skh_sink_fn sink
     w.cap = chunk_bytes;
     w.sink = sink;
     w.user = user;
-    rc = parse_file(path, writer_record, &w, &nrec, NULL);
+    rc = parse_file(path, writer_record, &w, &nrec, NULL, 0);
     if (rc == SK_OK) writer_flush(&w);
     if (bases) *bases += w.bases;
     free(w.buf);
@@ -511,7 +522,7 @@ int skh_keyset_from_file(skh_keyset *ks, const char *path, uint32_t initial_slot
     {
         const double t0 = now_s();
         double t1;
-        rc = parse_file(path, builder_record, &b, NULL, NULL);
+        rc = parse_file(path, builder_record, &b, NULL, NULL, 0);
         t1 = now_s();
         if (rc == SK_OK) rc = keyset_finish(ks, &b, initial_slots);
         if (getenv("SK_TIMING"))
@@ -589,6 +600,7 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases)
 typedef struct {
     sk_ctx         *ctx;
     uint32_t        col;
+    int             pipe;              /* fewer files than cores: each file's inflate gets a helper thread */
     pthread_mutex_t submit_mu;         /* sk_scan_stream is one-caller-at-a-time per context */
     pthread_mutex_t queue_mu;
     char          **path;              /* work list of this call (files this rank scans), in list order */
@@ -660,7 +672,7 @@ static int64_t worker_file(scan_worker *w, const char *path, uint64_t *bases)
     sw.sink = worker_sink;
     sw.user = w;
     sw.next_buf = worker_next_buf;
-    rc = parse_file(path, writer_record, &sw, &nrec, NULL);
+    rc = parse_file(path, writer_record, &sw, &nrec, NULL, w->pool->pipe);
     if (rc == SK_OK) writer_flush(&sw);
     *bases += sw.bases;
     if (rc != SK_OK) return rc;
@@ -746,6 +758,10 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     }
     free(line);
     fclose(fp);
+    {   /* with fewer files than half the cores, a file's inflate and its record parsing take a core each */
+        const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        pool.pipe = nthreads > 1 && (long)pool.npath * 2 <= ncpu;
+    }
     if (nthreads > 1 && pool.npath) {
         pthread_t *th;
         if ((uint32_t)nthreads > pool.npath) nthreads = (int)pool.npath;

@@ -29,7 +29,7 @@
 #include "sk_parser.h"
 #include "sk_internal.h"
 #include "sk_ctxjob.h"
-#include "sk_gzfast.h"
+#include "sk_gzpipe.h"
 
 
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
@@ -136,13 +136,6 @@ static int sd_on_record(void *user, char *seq, size_t len)
     return 0;
 }
 
-static int sd_feed_sink(void *user, const unsigned char *data, size_t n)
-{
-    parser *ps = (parser *)user;
-    parser_feed(ps, data, n);
-    return ps->state == P_STOP;
-}
-
 static void *sd_decode_thread(void *arg)
 {
     enum { BLK = 1 << 20 };
@@ -152,9 +145,18 @@ static void *sd_decode_thread(void *arg)
     int got;
     sd_chunk *c;
     parser_init(&ps, sd_on_record, st);
-    /* gzip through the library's own inflate (sk_gzfast.h); plain files, or SK_ZLIB=1, through zlib */
-    if (getenv("SK_ZLIB") || skz_decode_file(st->path, sd_feed_sink, &ps) == SKZ_NOT_GZIP)
-        while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
+    /* gzip: the library's own inflate on a helper thread, this thread parses (sk_gzpipe.h); plain files, or
+     * SK_ZLIB=1, through zlib */
+    {
+        skzp zp;
+        if (!getenv("SK_ZLIB") && skzp_open(&zp, st->path) == SKZ_OK) {
+            const unsigned char *data;
+            size_t n;
+            while (ps.state != P_STOP && !st->cancel && (n = skzp_next(&zp, &data)) > 0) parser_feed(&ps, data, n);
+            skzp_close(&zp);
+        } else
+            while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
+    }
     parser_eof(&ps);
     c = st->cur ? st->cur : (sd_chunk *)calloc(1, sizeof *c);
     st->cur = NULL;
