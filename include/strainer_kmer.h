@@ -290,6 +290,11 @@ int skh_scrub_filter_resident(sk_ctx *ctx, const skh_keyset *ks, int with_drug_c
  * / kmer_depth_count_by_metagenome bookkeeping (:64-93).  Keys are any u64 but 2^64-1.  Synchronous. */
 int sk_distinct_count(sk_ctx *ctx, const uint64_t *keys, const uint32_t *sample, uint64_t n, uint32_t nsamples,
                       uint64_t *out_unique, uint64_t *out_total);
+/* The same for hit lists whose k-mer text is not a fixed-length ACGT word: id[i] < nids numbers line i's
+ * joined string <sample><k-mer> (file order); a string counts once, for the sample of the first line showing it,
+ * as the script's global dictionary has it.  Synchronous. */
+int sk_first_seen_count(sk_ctx *ctx, const uint32_t *id, const uint32_t *sample, uint64_t n, uint32_t nids, uint32_t nsamples,
+                        uint64_t *out_unique, uint64_t *out_total);
 /* The script's command line (-k/--kmer_hits_file, -m/--min_kmer_hits, -b/--background_metagenomes_file):
  * same stdout bytes and exit status. */
 int skh_coverage_depth_main(int argc, char **argv, FILE *out, FILE *err);

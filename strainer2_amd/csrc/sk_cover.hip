@@ -55,6 +55,58 @@ __global__ void cov_count(const uint64_t *__restrict__ keys, const uint32_t *__r
     }
 }
 
+// "first sighting" counting, for hit lists whose k-mer text is not a fixed-length ACGT word: the script then
+// keys its uniqueness test by the joined string <sample><k-mer>, globally, and credits the sample of the FIRST
+// line that shows a string.  id[i] = number of line i's joined string (dense, < nids), in file order.
+__global__ void cov_first_min(const uint32_t *__restrict__ id, uint64_t n, unsigned long long *__restrict__ first)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMin(&first[id[i]], (unsigned long long)i);
+}
+__global__ void cov_first_count(const uint32_t *__restrict__ id, const uint32_t *__restrict__ sample, uint64_t n,
+                                const unsigned long long *__restrict__ first, unsigned long long *__restrict__ uniq,
+                                unsigned long long *__restrict__ total)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&total[sample[i]], 1ull);
+    if (first[id[i]] == (unsigned long long)i) atomicAdd(&uniq[sample[i]], 1ull);
+}
+
+extern "C" int sk_first_seen_count(sk_ctx *ctx, const uint32_t *id, const uint32_t *sample, uint64_t n, uint32_t nids, uint32_t nsamples,
+                                   uint64_t *out_unique, uint64_t *out_total)
+{
+    if (!ctx || !out_unique || !out_total || (n && (!id || !sample))) return SK_E_ARG;
+    if (nsamples == 0) return n ? SK_E_ARG : SK_OK;
+    memset(out_unique, 0, (size_t)nsamples * 8);
+    memset(out_total, 0, (size_t)nsamples * 8);
+    if (!n) return SK_OK;
+    for (uint64_t i = 0; i < n; i++)
+        if (id[i] >= nids || sample[i] >= nsamples) return sk_fail_(ctx, SK_E_ARG, "id or sample out of range");
+    int rc = SK_OK;
+    void *d_id = NULL, *d_sample = NULL, *d_first = NULL, *d_out = NULL;
+#define COV_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = sk_fail_(ctx, SK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); goto out; } } while (0)
+    COV_HIP(hipSetDevice(sk_ctx_device_(ctx)));
+    COV_HIP(hipMalloc(&d_id, n * 4));
+    COV_HIP(hipMalloc(&d_sample, n * 4));
+    COV_HIP(hipMalloc(&d_first, (size_t)nids * 8));
+    COV_HIP(hipMalloc(&d_out, (size_t)nsamples * 16));
+    COV_HIP(hipMemcpy(d_id, id, n * 4, hipMemcpyHostToDevice));
+    COV_HIP(hipMemcpy(d_sample, sample, n * 4, hipMemcpyHostToDevice));
+    COV_HIP(hipMemset(d_first, 0xFF, (size_t)nids * 8));
+    COV_HIP(hipMemset(d_out, 0, (size_t)nsamples * 16));
+    hipLaunchKernelGGL(cov_first_min, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const uint32_t *)d_id, n, (unsigned long long *)d_first);
+    hipLaunchKernelGGL(cov_first_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const uint32_t *)d_id, (const uint32_t *)d_sample, n,
+                       (const unsigned long long *)d_first, (unsigned long long *)d_out, (unsigned long long *)d_out + nsamples);
+    COV_HIP(hipGetLastError());
+    COV_HIP(hipMemcpy(out_unique, d_out, (size_t)nsamples * 8, hipMemcpyDeviceToHost));
+    COV_HIP(hipMemcpy(out_total, (uint64_t *)d_out + nsamples, (size_t)nsamples * 8, hipMemcpyDeviceToHost));
+#undef COV_HIP
+out:
+    (void)hipFree(d_id); (void)hipFree(d_sample); (void)hipFree(d_first); (void)hipFree(d_out);
+    return rc;
+}
+
 // Distinct and total number of keys per sample.  Keys must not be 0xFFFFFFFFFFFFFFFF.  Synchronous.
 extern "C" int sk_distinct_count(sk_ctx *ctx, const uint64_t *keys, const uint32_t *sample, uint64_t n, uint32_t nsamples,
                                  uint64_t *out_unique, uint64_t *out_total)

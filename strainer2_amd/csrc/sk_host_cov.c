@@ -101,7 +101,7 @@ typedef struct {
     uint32_t *depth_order; uint32_t ndepth;            /* samples in the order their first passing line came */
     uint32_t *eval_order; uint32_t neval;              /* samples in the order their total_kmer_evaluated line came */
     names     text;                                    /* general mode: the script's unique strings -> ids */
-    uint64_t *gen_unique, *gen_total; uint32_t gen_cap; /* general mode: per sample, new strings / passing lines */
+    uint32_t *gid, *gsample; uint64_t gn, gcap;        /* general mode: per passing line, in file order: joined-string number, sample */
     int       general;
     size_t    klen;                                    /* k-mer field length seen so far (0 = none yet) */
 } hitlist;
@@ -111,34 +111,32 @@ enum { COV_OK = 0, COV_OPEN, COV_FIELDS, COV_INT, COV_NOMEM };
 /* the script keys its uniqueness test by <sample name><k-mer text> joined without a separator (:88-93).
  * With k-mer fields of one length made of A/C/G/T -- all strain_detect ever writes -- that is the pair
  * (sample, packed k-mer), counted on the device.  Any other k-mer text (ragged lengths, other letters)
- * switches the file to "general" mode: the joined strings themselves are entered in a dictionary here,
- * exactly the script's bookkeeping, because two different pairs may then join to the same string. */
+ * switches the file to "general" mode, because two different pairs may then join to the same string: the
+ * joined strings are numbered here (a dictionary of texts, as the parse needs anyway) and the device credits
+ * every string to the sample of the first line that shows it (sk_first_seen_count), which is what the
+ * script's global "seen" dictionary does. */
 static int general_count(hitlist *h, uint32_t g, const char *ktext, size_t klen)
 {
     const char *sn = h->smp.name[g];
     const size_t sl = strlen(sn);
     char *u = malloc(sl + klen + 1);
-    const uint32_t before = h->text.n;
     int64_t id;
     if (!u) return COV_NOMEM;
     memcpy(u, sn, sl); memcpy(u + sl, ktext, klen);
-    id = name_get(&h->text, u, sl + klen);
+    id = name_get(&h->text, u, sl + klen);            /* number of the joined string */
     free(u);
     if (id < 0) return COV_NOMEM;
-    if (g >= h->gen_cap) {
-        uint32_t cap = h->gen_cap ? h->gen_cap : 64;
-        uint64_t *a, *b;
-        while (cap <= g) cap *= 2;
-        if (!(a = realloc(h->gen_unique, (size_t)cap * sizeof *a))) return COV_NOMEM;
-        h->gen_unique = a;
-        if (!(b = realloc(h->gen_total, (size_t)cap * sizeof *b))) return COV_NOMEM;
-        h->gen_total = b;
-        memset(a + h->gen_cap, 0, (size_t)(cap - h->gen_cap) * sizeof *a);
-        memset(b + h->gen_cap, 0, (size_t)(cap - h->gen_cap) * sizeof *b);
-        h->gen_cap = cap;
+    if (h->gn == h->gcap) {
+        const uint64_t cap = h->gcap ? h->gcap * 2 : 1u << 12;
+        uint32_t *a = realloc(h->gid, cap * sizeof *a), *b;
+        if (!a) return COV_NOMEM;
+        h->gid = a;
+        if (!(b = realloc(h->gsample, cap * sizeof *b))) return COV_NOMEM;
+        h->gsample = b;
+        h->gcap = cap;
     }
-    h->gen_total[g]++;
-    if (h->text.n != before) h->gen_unique[g]++;
+    h->gid[h->gn] = (uint32_t)id;
+    h->gsample[h->gn++] = g;
     return COV_OK;
 }
 
@@ -337,8 +335,9 @@ static int cov_report(hitlist *h, sk_ctx *ctx, const char *kfile, const char *bf
         }
     if (h->smp.n) {
         if (!(uniq = calloc(h->smp.n, sizeof *uniq)) || !(total = calloc(h->smp.n, sizeof *total))) { fprintf(err, "coverage_depth: out of memory\n"); goto done; }
-        if (h->general) {                            /* out-of-domain k-mer text: counted while reading (see to_general) */
-            for (s = 0; s < h->smp.n && s < h->gen_cap; s++) { uniq[s] = h->gen_unique[s]; total[s] = h->gen_total[s]; }
+        if (h->general) {                            /* out-of-domain k-mer text: first sightings of the joined strings */
+            rc = sk_first_seen_count(ctx, h->gid, h->gsample, h->gn, h->text.n, h->smp.n, uniq, total);
+            if (rc != SK_OK) { fprintf(err, "coverage_depth: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
         } else {
             rc = sk_distinct_count(ctx, h->key, h->sample, h->n, h->smp.n, uniq, total);
             if (rc != SK_OK) { fprintf(err, "coverage_depth: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
@@ -406,7 +405,7 @@ done:
 
 static void hitlist_free(hitlist *h)
 {
-    free(h->key); free(h->sample); free(h->depth_order); free(h->eval_order); free(h->gen_unique); free(h->gen_total);
+    free(h->key); free(h->sample); free(h->depth_order); free(h->eval_order); free(h->gid); free(h->gsample);
     names_free(&h->smp); names_free(&h->text);
     memset(h, 0, sizeof *h);
 }

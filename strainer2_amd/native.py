@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_decode_file",
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
-    "sk_distinct_count", "skh_coverage_depth_main",
+    "sk_distinct_count", "sk_first_seen_count", "skh_coverage_depth_main",
     "sk_batch_create", "sk_batch_destroy", "sk_batch_fill", "sk_tally_launch", "sk_tally_collect",
 ]
 

@@ -37,4 +37,20 @@ int sk_distinct_count(sk_ctx *ctx, const uint64_t *keys, const uint32_t *sample,
     return SK_OK;
 }
 
+int sk_first_seen_count(sk_ctx *ctx, const uint32_t *id, const uint32_t *sample, uint64_t n, uint32_t nids, uint32_t nsamples,
+                        uint64_t *out_unique, uint64_t *out_total)
+{
+    uint8_t *seen = calloc(nids + 1u, 1);
+    uint64_t i;
+    (void)ctx;
+    memset(out_unique, 0, (size_t)nsamples * 8);
+    memset(out_total, 0, (size_t)nsamples * 8);
+    for (i = 0; i < n; i++) {
+        out_total[sample[i]]++;
+        if (!seen[id[i]]) { seen[id[i]] = 1; out_unique[sample[i]]++; }
+    }
+    free(seen);
+    return SK_OK;
+}
+
 int main(int argc, char **argv) { return skh_coverage_depth_main(argc, argv, stdout, stderr); }

@@ -149,6 +149,12 @@ int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return die("sk
 int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return die("sk_counts_allreduce"); }
 int skh_scrub_filter_resident(sk_ctx *c, const skh_keyset *k, int d, double m, int i, FILE *o, FILE *e) { (void)c; (void)k; (void)d; (void)m; (void)i; (void)o; (void)e; return die("skh_scrub_filter_resident"); }
 
+int sk_first_seen_count(sk_ctx *ctx, const uint32_t *id, const uint32_t *sample, uint64_t n, uint32_t nids, uint32_t ns, uint64_t *uniq, uint64_t *total)
+{
+    (void)ctx; (void)id; (void)sample; (void)n; (void)nids; (void)ns; (void)uniq; (void)total;
+    return die("sk_first_seen_count");
+}
+
 #ifndef DOUBLE_MAIN
 #define DOUBLE_MAIN skh_strain_detect_main
 #endif
