@@ -781,7 +781,21 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         for (int s2 = 0; s2 < 2; s2++) {
             if (act[s2] & !anchor[s2]) {
                 if (fidx[s2] != 0xFFFFFFFFu && fkey[s2] == cn[s2]) hit[s2] = fidx[s2];
-                if (hit[s2] == 0xFFFFFFFFu) { uint32_t unused; hit[s2] = sk_find(cn[s2], table, &unused); }
+                if (hit[s2] == 0xFFFFFFFFu) {
+                    // Not where its neighbours are: mostly a read error, and then ~30 windows in a row end up
+                    // here.  Before the random table probe, ask the level-1 filter (L2-resident: free) about the
+                    // window's first and last 16-mer: they cover all 31 bases, so an erroneous base makes one of
+                    // them a stranger to the strain (no false negatives: a real k-mer always passes both).
+                    const uint32_t w0 = (uint32_t)(cn[s2] >> 30), w1 = (uint32_t)cn[s2];
+                    const uint32_t r0 = sk_revcomp32(w0), r1 = sk_revcomp32(w1);
+                    const uint32_t g0 = sk_gmix(w0 < r0 ? w0 : r0), g1 = sk_gmix(w1 < r1 ? w1 : r1);
+                    const uint2 q0 = table.grid1[sk_grid1_block(g0, table.grid1_blocks)];
+                    const uint2 q1 = table.grid1[sk_grid1_block(g1, table.grid1_blocks)];
+                    if (sk_grid_test(q0, sk_grid1_bits(g0)) && sk_grid_test(q1, sk_grid1_bits(g1))) {
+                        uint32_t unused;
+                        hit[s2] = sk_find(cn[s2], table, &unused);
+                    }
+                }
             }
         }
         if (TALLY) {
