@@ -699,10 +699,15 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     for (int i = 0; i < SK_SPAN_CH; i++)
         m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) && ABLATE != 4) << i;
     if (m) {                                                      // level 2 (rare for unrelated reads)
+        // A chunk right after one that passed level 2 is taken on its level-1 pass alone: inside a strain read
+        // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
+        // level 1 next to a level-2 pass is as rare as level 2's own false positives.  Pruning less is always
+        // exact: stage 2 verifies every window.
         uint32_t m2 = 0;
 #pragma unroll
         for (int i = 0; i < SK_SPAN_CH; i++)
             if ((m >> i) & 1u) {
+                if (i > 0 && ((m2 >> (i - 1)) & 1u)) { m2 |= 1u << i; continue; }
                 const uint2 b2 = table.grid2[sk_grid2_block(g[i], table.grid2_shift)];   // (nontemporal loads here: 7 % slower)
                 m2 |= (uint32_t)sk_grid_test(b2, sk_grid2_bits(g[i])) << i;
             }
