@@ -45,6 +45,9 @@ def payloads():
         "random": bytes(rng.getrandbits(8) for _ in range(200_000)),   # incompressible: stored blocks at level 1+
         "text": (b"the quick brown fox jumps over the lazy dog\n" * 20_000),
         "far": (bytes(rng.getrandbits(8) for _ in range(32_000)) + b"Z") * 6,   # matches at the 32 KiB limit
+        # symbol frequencies falling off geometrically: Huffman codes up to the 15-bit limit (subtables at full depth)
+        "skewed": bytes(min(255, int(rng.expovariate(0.35))) for _ in range(400_000)),
+        "skewed2": bytes((7 * min(36, int(rng.expovariate(0.5)))) & 255 for _ in range(300_000)),
     }
 
 
