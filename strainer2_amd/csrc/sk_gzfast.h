@@ -40,7 +40,7 @@ typedef int (*skz_sink)(void *user, const unsigned char *data, size_t n);
 
 /* table entry: bits 0..3 code length still to consume at this level, bits 4..7 kind, bits 8..15 number of
  * extra bits (length/distance) or of subtable index bits, bits 16..31 literal / base value / subtable start */
-enum { SKZ_K_LIT = 0, SKZ_K_LEN = 1, SKZ_K_EOB = 2, SKZ_K_SUB = 3, SKZ_K_BAD = 4, SKZ_K_DIST = 5 };
+enum { SKZ_K_LIT = 0, SKZ_K_LIT2 = 1, SKZ_K_LEN = 2, SKZ_K_EOB = 3, SKZ_K_SUB = 4, SKZ_K_BAD = 5, SKZ_K_DIST = 6 };
 #define SKZ_ENTRY(val, extra, kind, nbits) (((uint32_t)(val) << 16) | ((uint32_t)(extra) << 8) | ((uint32_t)(kind) << 4) | (uint32_t)(nbits))
 
 typedef struct {
@@ -126,6 +126,20 @@ static int skz_build(uint32_t *table, int tbits, size_t table_cap, const uint8_t
         sbits = (table[p] >> 8) & 0xFFu;
         e = skz_symbol_entry(is_dist, sym, (int)len - tbits);
         for (i = r >> tbits; i < ((size_t)1 << sbits); i += (size_t)1 << (len - (unsigned)tbits)) table[start + i] = e;
+    }
+    /* literal pairs: where the bits of a primary index spell one literal and then, completely, a second one,
+     * the entry yields both (sequence data is mostly literals with codes of 2-6 bits) */
+    if (!is_dist) {
+        uint32_t prim[1u << SKZ_LITLEN_BITS];
+        memcpy(prim, table, sizeof prim);
+        for (i = 0; i < ((size_t)1 << tbits); i++) {
+            const uint32_t e1 = prim[i], l1 = e1 & 15u;
+            uint32_t e2;
+            if (((e1 >> 4) & 15u) != SKZ_K_LIT || l1 >= (uint32_t)tbits) continue;
+            e2 = prim[i >> l1];                         /* (the unknown high bits read as zeros) */
+            if (((e2 >> 4) & 15u) != SKZ_K_LIT || (e2 & 15u) > (uint32_t)tbits - l1) continue;
+            table[i] = SKZ_ENTRY((e1 >> 16) | ((e2 >> 16) << 8), 0, SKZ_K_LIT2, l1 + (e2 & 15u));
+        }
     }
     return 0;
 }
@@ -374,35 +388,48 @@ static int skz_block(skz_stream *s, const skz_tables *t)
 #define SKZ_FILL_FAST() do { uint64_t w_; memcpy(&w_, in, 8); bitbuf |= w_ << bitcnt; in += (63u - bitcnt) >> 3; bitcnt |= 56u; } while (0)
 #define SKZ_FILL_SLOW() do { while (bitcnt <= 56u) { const uint64_t b_ = in < in_end ? *in : 0u; in++; bitbuf |= b_ << bitcnt; bitcnt += 8u; } } while (0)
 #define SKZ_KIND(e)   (((e) >> 4) & 15u)
+    uint32_t enext = 0;
+    int pre = 0;                                            /* enext = the entry after a match, looked up before its copy */
     for (;;) {
         uint32_t e;
-        if ((size_t)(s->out_end - out) < 3 + 2 * 258 + 16) {
+        if ((size_t)(s->out_end - out) < 6 + 2 * 258 + 16) {
             SKZ_SAVE();
             if (skz_flush(s, 1)) return 1;
             SKZ_LOAD();
         }
-        if (in_end - in >= 16) {                            /* (signed: `in` may already be past the end) */
-            SKZ_FILL_FAST();
-            e = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
-            if (SKZ_KIND(e) == SKZ_K_LIT) {                 /* up to three literals out of one refill (3 x 15 <= 56 bits) */
-                bitbuf >>= e & 15u; bitcnt -= e & 15u; *out++ = (unsigned char)(e >> 16);
+        if (pre || in_end - in >= 16) {                     /* (signed: `in` may already be past the end) */
+            if (pre) { e = enext; pre = 0; }
+            else {
+                SKZ_FILL_FAST();
                 e = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
-                if (SKZ_KIND(e) == SKZ_K_LIT) {
-                    bitbuf >>= e & 15u; bitcnt -= e & 15u; *out++ = (unsigned char)(e >> 16);
+            }
+            /* up to three entries out of one refill (3 x 15 <= 56 bits), each one literal or a pair of them */
+#define SKZ_IS_LITS(e) (SKZ_KIND(e) <= (uint32_t)SKZ_K_LIT2)
+            if (SKZ_IS_LITS(e)) {
+                bitbuf >>= e & 15u; bitcnt -= e & 15u; out[0] = (unsigned char)(e >> 16); out[1] = (unsigned char)(e >> 24); out += 1u + (SKZ_KIND(e) == SKZ_K_LIT2);
+                e = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
+                if (SKZ_IS_LITS(e)) {
+                    bitbuf >>= e & 15u; bitcnt -= e & 15u; out[0] = (unsigned char)(e >> 16); out[1] = (unsigned char)(e >> 24); out += 1u + (SKZ_KIND(e) == SKZ_K_LIT2);
                     e = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
-                    if (SKZ_KIND(e) == SKZ_K_LIT) {
-                        bitbuf >>= e & 15u; bitcnt -= e & 15u; *out++ = (unsigned char)(e >> 16);
+                    if (SKZ_IS_LITS(e)) {
+                        bitbuf >>= e & 15u; bitcnt -= e & 15u; out[0] = (unsigned char)(e >> 16); out[1] = (unsigned char)(e >> 24); out += 1u + (SKZ_KIND(e) == SKZ_K_LIT2);
                         continue;
                     }
                 }
+                if (in_end - in < 8) goto slow_refill;      /* (after a preloaded entry the 16-byte margin may be gone) */
                 SKZ_FILL_FAST();                            /* (the low bits, hence e, are unchanged) */
             }
         } else {
             if (in - in_end > 16) { rc = -1; break; }       /* decoding the zeros supplied past the end: truncated */
             SKZ_FILL_SLOW();
             e = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
-            if (SKZ_KIND(e) == SKZ_K_LIT) { bitbuf >>= e & 15u; bitcnt -= e & 15u; *out++ = (unsigned char)(e >> 16); continue; }
+            if (0) { slow_refill: SKZ_FILL_SLOW(); goto have_entry; }
+            if (SKZ_IS_LITS(e)) {
+                bitbuf >>= e & 15u; bitcnt -= e & 15u; out[0] = (unsigned char)(e >> 16); out[1] = (unsigned char)(e >> 24); out += 1u + (SKZ_KIND(e) == SKZ_K_LIT2);
+                continue;
+            }
         }
+have_entry:
         /* here: at least 56 bits (or the end of the input) and e is not a literal */
         if (SKZ_KIND(e) == SKZ_K_SUB) {
             bitbuf >>= SKZ_LITLEN_BITS; bitcnt -= SKZ_LITLEN_BITS;
@@ -428,6 +455,11 @@ static int skz_block(skz_stream *s, const skz_tables *t)
                 dist = (d >> 16) + (uint32_t)(bitbuf & (((uint64_t)1 << db) - 1u)); bitbuf >>= db; bitcnt -= db;
             }
             if (dist > (size_t)(out - s->out_base)) { rc = -1; break; }          /* before the start of the data */
+            if (in_end - in >= 16) {                        /* look the next entry up now: its latency hides behind the copy */
+                SKZ_FILL_FAST();
+                enext = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
+                pre = 1;
+            }
             dst = out; src = dst - dist;
             out += len;
             if (dist >= 8) {
@@ -451,6 +483,7 @@ static int skz_block(skz_stream *s, const skz_tables *t)
 #undef SKZ_FILL_FAST
 #undef SKZ_FILL_SLOW
 #undef SKZ_KIND
+#undef SKZ_IS_LITS
 }
 
 /* one DEFLATE stream (all blocks of a member) */
