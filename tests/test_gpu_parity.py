@@ -424,6 +424,10 @@ def test_scan_pinned_equals_scan_stream(ctx):
 def test_rccl_allreduce_on_the_counter_block_single_rank(repo):
     """torch.distributed (backend nccl = RCCL) all-reduce running directly on the library's device counters,
     as bench.py --gpus N does: world of one, counts unchanged (tools/nccl_single_rank_check.py)"""
+    import socket
+    with socket.socket() as sock:                      # a port that is free right now
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     p = subprocess.run([sys.executable, os.path.join(repo, "tools", "nccl_single_rank_check.py")], cwd=repo,
-                       capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT="29561"))
+                       capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT=str(port)))
     assert p.returncode == 0 and b"all-reduce on the library's counter block: ok" in p.stdout, p.stderr.decode()[-800:]
