@@ -20,7 +20,8 @@ contigs = synth.make_strain()
 open(os.path.join(work, "strain.fa"), "wb").write(synth.strain_fasta(contigs))
 qual = b"I" * 150
 t0 = time.time()
-for kind in ("fq", "fq.gz"):
+KINDS = tuple(os.environ.get("KINDS", "fq,fq.gz").split(","))
+for kind in KINDS:
     names = []
     for i in range(NFILES):
         p = os.path.join(work, f"reads{i}.{kind}")
@@ -40,8 +41,8 @@ open(os.path.join(work, "A.txt"), "w").write(os.path.join(work, "strain.fa") + "
 print(f"inputs ready in {time.time() - t0:.1f} s: {NFILES} x {READS} reads per format", flush=True)
 exe = os.path.join(REPO, "strainer2_amd", "bin", "kmer_scrub_count")
 bases = NFILES * READS * 150
-for kind in ("fq", "fq.gz"):
-    for threads in (1, 4, 16):
+for kind in KINDS:
+    for threads in tuple(int(x) for x in os.environ.get("THREADS", "1,4,16").split(",")):
         env = dict(os.environ, SK_THREADS=str(threads))
         t = time.time()
         with open(os.devnull, "wb") as null:
