@@ -7,7 +7,7 @@
 #include <string.h>
 #include <time.h>
 #include <zlib.h>
-#include "../../strainer2_amd/csrc/sk_gzfast.h"
+#include "../../strainer2_amd/csrc/sk_gzpipe.h"
 
 typedef struct { unsigned char *p; size_t n, cap; } buf;
 static int collect(void *user, const unsigned char *d, size_t n)
@@ -20,9 +20,28 @@ static int collect(void *user, const unsigned char *d, size_t n)
 }
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
+/* the same decode pulled through the helper-thread pipe (sk_gzpipe.h); with stop_after > 0 the consumer walks
+ * away after that many bytes, which must stop the helper cleanly */
+static int pipe_decode(const char *path, buf *b, size_t stop_after)
+{
+    skzp p;
+    const unsigned char *d;
+    size_t n;
+    int rc = skzp_open(&p, path);
+    if (rc != SKZ_OK) return rc;
+    while ((n = skzp_next(&p, &d)) > 0) {
+        collect(b, d, n);
+        if (stop_after && b->n >= stop_after) break;
+    }
+    rc = p.done ? p.rc : SKZ_STOPPED;
+    skzp_close(&p);
+    return rc;
+}
+
 int main(int argc, char **argv)
 {
-    int i, bad = 0;
+    int i, bad = 0, use_pipe = 0;
+    if (argc > 1 && !strcmp(argv[1], "--pipe")) { use_pipe = 1; argv++; argc--; }
     for (i = 1; i < argc; i++) {
         buf a = {0}, b = {0};
         unsigned char *blk = malloc(1 << 20);
@@ -39,7 +58,15 @@ int main(int argc, char **argv)
             if (gzclose(g) != Z_OK) zerr = 1;
         }
         t1 = now();
-        rc = skz_decode_file(argv[i], collect, &b);
+        if (use_pipe) {
+            buf c = {0};
+            rc = pipe_decode(argv[i], &b, 0);
+            if (rc != SKZ_NOT_GZIP && rc != SKZ_OPEN) {            /* and once more, abandoned half way */
+                pipe_decode(argv[i], &c, b.n / 2 + 1);
+                if (c.n > b.n || (c.n && memcmp(c.p, b.p, c.n))) { printf("%s: MISMATCH in the abandoned pipe run\n", argv[i]); bad = 1; }
+            }
+            free(c.p);
+        } else rc = skz_decode_file(argv[i], collect, &b);
         t2 = now();
         if (rc == SKZ_NOT_GZIP) {
             printf("%s: not gzip (zlib passes %zu bytes through)\n", argv[i], a.n);

@@ -23,8 +23,8 @@ def checker(tmp_path_factory):
     return exe
 
 
-def run(checker, files):
-    p = subprocess.run([checker] + [str(f) for f in files], env=ENV, capture_output=True)
+def run(checker, files, pipe=False):
+    p = subprocess.run([checker] + (["--pipe"] if pipe else []) + [str(f) for f in files], env=ENV, capture_output=True)
     assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     assert b"MISMATCH" not in p.stdout
@@ -123,3 +123,30 @@ def test_every_gz_fixture_of_the_repository(checker):
     assert len(files) > 50
     out = run(checker, sorted(files))
     assert out.count(" OK ") == len(files)
+
+
+@pytest.fixture(scope="module")
+def checker_tsan(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gzt") / "gzfast_check_tsan")
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", os.path.join(REPO, "tests", "native", "gzfast_check.c"),
+                    "-lz", "-lpthread", "-o", exe], check=True)
+    return exe
+
+
+def test_helper_thread_pipe(checker, checker_tsan, tmp_path):
+    """the same files pulled through sk_gzpipe.h (inflate on a helper thread), complete and abandoned half way,
+    under ASan/UBSan and under ThreadSanitizer"""
+    p = payloads()
+    files = []
+    for name in ("fastq", "zeros", "random", "empty", "one"):
+        f = tmp_path / f"{name}.gz"
+        f.write_bytes(gzip.compress(p[name], 6, mtime=0))
+        files.append(f)
+    (tmp_path / "two.gz").write_bytes(gzip.compress(p["fastq"], 1, mtime=0) + gzip.compress(p["dna"], 9, mtime=0))
+    (tmp_path / "cut.gz").write_bytes(gzip.compress(p["fastq"], 6, mtime=0)[:50_000])
+    files += [tmp_path / "two.gz", tmp_path / "cut.gz"]
+    out = run(checker, files, pipe=True)
+    assert out.count(" OK ") == 6 and out.count("damaged") == 1
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    q = subprocess.run([checker_tsan, "--pipe"] + [str(f) for f in files], env=env, capture_output=True)
+    assert b"ThreadSanitizer" not in q.stderr and q.returncode == 0, q.stderr.decode()[-2000:]
