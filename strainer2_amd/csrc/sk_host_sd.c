@@ -35,6 +35,13 @@
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
 enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
 #define SD_BATCH_BYTES (32u << 20)
+/* SK_SD_CHUNK_BYTES: smaller chunks (tests: chunk boundaries between mates, carried state across chunks) */
+static size_t sd_chunk_bytes(void)
+{
+    const char *e = getenv("SK_SD_CHUNK_BYTES");
+    const long v = e ? atol(e) : 0;
+    return v >= 64 && (unsigned long)v < SD_BATCH_BYTES ? (size_t)v : SD_BATCH_BYTES;
+}
 
 /* ---------------------------------------------------------------------------------------------
  * program state: one per strain (table on the device, type column, output, replay state)
@@ -76,6 +83,7 @@ typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv;
     sd_chunk   *q[3]; int qn, cancel;        /* decoded chunks waiting for the main thread */
     sd_chunk   *cur;                         /* producer: chunk under construction */
+    size_t      chunk_bytes;
     /* consumer */
     sd_chunk   *c; uint32_t ci;
     int         eof, end_kind; size_t end_len;
@@ -107,7 +115,7 @@ static int sd_on_record(void *user, char *seq, size_t len)
     sd_stream *st = (sd_stream *)user;
     sd_chunk *c = st->cur;
     if (st->cancel) return 1;
-    if (c && c->nrec && (c->blen + len + 1 > SD_BATCH_BYTES || c->nrec >= (1u << 22))) { stream_push(st, c); c = NULL; }
+    if (c && c->nrec && (c->blen + len + 1 > st->chunk_bytes || c->nrec >= (1u << 22))) { stream_push(st, c); c = NULL; }
     if (!c) c = st->cur = (sd_chunk *)calloc(1, sizeof *c);
     if (c->nrec == c->rcap) {
         c->rcap = c->rcap ? c->rcap * 2 : 1u << 16;
@@ -174,6 +182,7 @@ static int stream_open(sd_stream *st, const char *path)
 {
     memset(st, 0, sizeof *st);
     st->path = path;
+    st->chunk_bytes = sd_chunk_bytes();
     st->g = gzopen(path, "r");
     if (!st->g) return SK_E_OPEN;
     gzbuffer(st->g, 1 << 18);

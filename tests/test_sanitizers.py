@@ -139,6 +139,25 @@ def test_strain_detect_host_logic_under_sanitizers(sd_host_exe, name, tmp_path):
         assert open(tmp_path / "a_b_c.coverage_depth", "rb").read().startswith(b"strain_name\t")
 
 
+@pytest.mark.parametrize("name", ["batch", "cli_se", "cli_pe", "cli_pei"])
+@pytest.mark.parametrize("chunk", ["64", "333", "2000"])
+def test_strain_detect_tiny_chunks_under_sanitizers(sd_host_exe, name, chunk, tmp_path):
+    """chunks of a few reads: mates that sit in different chunks (PE and interleaved), tallies and the PE1 copy
+    carried across chunk boundaries, queues that fill up -- same output as with one big chunk"""
+    import gzip
+    d = os.path.join(SD_DIR, name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    argv = list(meta["argv"])
+    argv[argv.index("-o") + 1] = str(tmp_path / "o.gz")
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_SD_CHUNK_BYTES=chunk)
+    p = subprocess.run([sd_host_exe] + argv, cwd=d, env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in p.stderr, p.stderr.decode()[-3000:]
+    assert p.returncode == meta["returncode"] == 0
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+    assert gzip.open(tmp_path / "o.gz", "rb").read() == open(os.path.join(d, "expected.hits"), "rb").read()
+
+
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])
 def test_strain_detect_many_strains_host_logic_under_sanitizers(san, tmp_path):
     """-S with four strains (the thread pool is in use): every output equals the single-strain golden"""

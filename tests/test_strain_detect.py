@@ -241,3 +241,16 @@ def test_sd_strain_list_is_dealt_to_ranks(golden, tmp_path):
     p = subprocess.run([exe, "-S", str(tmp_path / "one.txt"), "-B", "B.txt"], cwd=d, capture_output=True,
                        env=dict(os.environ, SK_WORLD_SIZE="2", SK_RANK="1"))
     assert p.returncode == 0 and not os.path.exists(tmp_path / "only.gz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["batch", "cli_pe", "cli_pei", "background"])
+def test_sd_program_tiny_chunks(golden, name, tmp_path, monkeypatch):
+    """the same goldens with chunks of a few reads (SK_SD_CHUNK_BYTES): mates in different chunks, state carried
+    across chunk boundaries, many small tally launches"""
+    monkeypatch.setenv("SK_SD_CHUNK_BYTES", "500")
+    d, meta, out, err, hits = _case(golden, name)
+    p, got = _run(_gpu_runner, d, meta, tmp_path)
+    assert p.returncode == meta["returncode"] == 0
+    assert p.stdout == out and p.stderr == err
+    assert got == hits
