@@ -254,3 +254,16 @@ def test_sd_program_tiny_chunks(golden, name, tmp_path, monkeypatch):
     assert p.returncode == meta["returncode"] == 0
     assert p.stdout == out and p.stderr == err
     assert got == hits
+
+
+@pytest.mark.gpu
+def test_sd_strain_list_with_background_column(golden, tmp_path):
+    """-S with the optional 4th column (-g list): the background filter runs per strain on its worker thread and
+    its messages come out in list order; same result as the single-strain golden"""
+    d, meta, out, err, hits = _case(golden, "background")
+    (tmp_path / "strains.txt").write_text(f"strain.fa\tinf.txt\t{tmp_path}/a.gz\tbg.txt\nstrain.fa\tinf.txt\t{tmp_path}/b.gz\tbg.txt\n")
+    p = subprocess.run([sk.cli_path("strain_detect"), "-S", str(tmp_path / "strains.txt"), "-B", "B.txt"], cwd=d, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    assert p.stdout == out + out and p.stderr == err + err
+    for f in ("a.gz", "b.gz"):
+        assert gzip.open(tmp_path / f, "rb").read() == hits
