@@ -125,6 +125,56 @@ def test_every_gz_fixture_of_the_repository(checker):
     assert out.count(" OK ") == len(files)
 
 
+def test_random_streams_all_encoder_settings(checker, tmp_path):
+    """80 random payloads (random bytes, tiny alphabets, periodic, LZ-style self-copies at every distance, skewed
+    alphabets, FASTQ) through random zlib settings: level 0-9, window 2^9-2^15, memLevel 1-9, every strategy,
+    sync/full flushes in the middle, inputs fed in pieces"""
+    rng = random.Random(2024)
+
+    def gen(n):
+        kind = rng.randrange(6)
+        if kind == 0:
+            return bytes(rng.getrandbits(8) for _ in range(n))
+        if kind == 1:
+            a = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 8)))
+            return bytes(rng.choice(a) for _ in range(n))
+        if kind == 2:
+            seg = bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 300)))
+            return (seg * (n // len(seg) + 1))[:n]
+        if kind == 3:
+            out = bytearray()
+            while len(out) < n:
+                if out and rng.random() < 0.6:
+                    d, ln = rng.randrange(1, min(len(out), 32768) + 1), rng.randrange(3, 300)
+                    for _ in range(ln):
+                        out.append(out[-d])
+                else:
+                    out += bytes(rng.choice(b"ACGTN\n@+IJK") for _ in range(rng.randrange(1, 50)))
+            return bytes(out[:n])
+        if kind == 4:
+            lam = rng.uniform(0.05, 1.0)
+            return bytes(min(255, int(rng.expovariate(lam))) for _ in range(n))
+        return b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(100)),
+                                              bytes(rng.choice(b"FGHIJ#") for _ in range(100))) for i in range(n // 210 + 1))[:n]
+
+    files = []
+    for i in range(80):
+        data = gen(rng.choice([0, 1, 2, 10, 100, 1000, 5000, 70000, 200000]))
+        c = zlib.compressobj(rng.randrange(0, 10), zlib.DEFLATED, 16 + rng.randrange(9, 16), rng.randrange(1, 10), rng.choice([0, 1, 2, 3, 4]))
+        blob, pos = b"", 0
+        while pos < len(data):
+            step = rng.choice([len(data), 1000, 37, 100000])
+            blob += c.compress(data[pos:pos + step])
+            pos += step
+            if rng.random() < 0.2:
+                blob += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+        f = tmp_path / f"f{i}.gz"
+        f.write_bytes(blob + c.flush())
+        files.append(f)
+    assert run(checker, files).count(" OK ") == len(files)
+    assert run(checker, files, pipe=True).count(" OK ") == len(files)
+
+
 @pytest.fixture(scope="module")
 def checker_tsan(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("gzt") / "gzfast_check_tsan")
