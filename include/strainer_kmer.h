@@ -234,7 +234,8 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err);
 
 /* The whole strain_detect program with the reference's argv contract (src/strain_detect.c:61-158):
  * -r -a -o and one of -b [-c] [-t SE|PE|PEI] / -B, optional -g.  Messages the reference prints on
- * stdout go to `out`, stderr texts to `err`; the -o file is gz level 9.  Returns the exit status. */
+ * stdout go to `out`, stderr texts to `err`; the -o file is gzip (members compressed in parallel; the
+ * decompressed bytes are the reference's).  Returns the exit status. */
 int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err);
 
 /* Record reader exposed for tests: decode `path` into the record stream, calling `sink` with

@@ -30,6 +30,7 @@
 #include "sk_internal.h"
 #include "sk_ctxjob.h"
 #include "sk_gzpipe.h"
+#include "sk_gzout.h"
 
 
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
@@ -53,7 +54,7 @@ typedef struct {
     uint32_t   *type;          /* host copy of the type column */
     FILE       *out, *err;
     /* quantification */
-    gzFile      gz;            /* -o */
+    skzo_file  *zo;            /* -o: gzip members compressed on the output pool (sk_gzout.h) */
     unsigned    genome_inf;    /* informative rows after -a / -g */
     int         h1, i1, h2, i2;            /* tallies carried from read to read (src/strain_detect.c:444-454,497-500) */
     uint32_t   *copy_rows; uint32_t copy_n, copy_cap;   /* informative rows of the PE1 read last copied (:451) */
@@ -319,15 +320,56 @@ static sd_chunk *stream_steal(sd_stream *st)
     return c;
 }
 
+static unsigned char *put_int(unsigned char *w, int v)
+{
+    char tmp[12];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    if (v < 0) *w++ = '-';
+    do { tmp[n++] = (char)('0' + u % 10u); u /= 10u; } while (u);
+    while (n) *w++ = (unsigned char)tmp[--n];
+    return w;
+}
+
+/* the hit lines of one read: "<file>\t<hits PE1>\t<informative PE1>\t<hits PE2>\t<informative PE2>\t<k-mer>\n"
+ * (src/strain_detect.c:567,608), formatted straight into the output block */
 static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *name)
 {
+    const size_t nl = strlen(name);
     uint32_t j;
     char key[32];
     for (j = 0; j < n; j++) {
         skh_keyset_key(&p->ks, rows[j], key);
-        gzprintf(p->gz, "%s\t%d\t%d\t%d\t%d\t%s\n", name, p->h1, p->i1, p->h2, p->i2, key);
+        if (nl <= 3800) {
+            unsigned char *w0 = skzo_reserve(p->zo, nl + 128), *w = w0;
+            memcpy(w, name, nl); w += nl;
+            *w++ = '\t'; w = put_int(w, p->h1);
+            *w++ = '\t'; w = put_int(w, p->i1);
+            *w++ = '\t'; w = put_int(w, p->h2);
+            *w++ = '\t'; w = put_int(w, p->i2);
+            *w++ = '\t';
+            { const size_t kl = strlen(key); memcpy(w, key, kl); w += kl; }
+            *w++ = '\n';
+            p->zo->len += (size_t)(w - w0);
+        } else {                                           /* a path longer than a block's slack: the slow way */
+            char num[64];
+            skzo_append(p->zo, name, nl);
+            skzo_append(p->zo, num, (size_t)snprintf(num, sizeof num, "\t%d\t%d\t%d\t%d\t", p->h1, p->i1, p->h2, p->i2));
+            skzo_append(p->zo, key, strlen(key));
+            skzo_append(p->zo, "\n", 1);
+        }
         if (p->cov) skc_add_hit(p->cov, name, p->h1, p->h2, rows[j]);
     }
+}
+
+static void emit_trailer(sd_prog *p, const char *f1, const char *what, long long v)
+{
+    char num[64];
+    skzo_append(p->zo, "#", 1);
+    skzo_append(p->zo, f1, strlen(f1));
+    skzo_append(p->zo, "\t", 1);
+    skzo_append(p->zo, what, strlen(what));
+    skzo_append(p->zo, num, (size_t)snprintf(num, sizeof num, "\t%lld\n", v));
 }
 
 /* One strain over a run of n read pairs whose records sit in the current chunks: PE1 reads are records
@@ -522,10 +564,10 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
         goto done;
     }
     for (s = 0; s < ns; s++) {
-        gzprintf(p[s].gz, "#%s\ttotal_kmer_evaluated\t%lld\n", f1, evaluated);
-        gzprintf(p[s].gz, "#%s\ttotal_reads_evaluated\t%lld\n", f1, reads);
-        gzprintf(p[s].gz, "#%s\ttotal_genome_kmers\t%lld\n", f1, (long long)p[s].ks.nrows);
-        gzprintf(p[s].gz, "#%s\ttotal_genome_informative_kmers\t%lld\n", f1, (long long)p[s].genome_inf);
+        emit_trailer(&p[s], f1, "total_kmer_evaluated", (long long)evaluated);
+        emit_trailer(&p[s], f1, "total_reads_evaluated", (long long)reads);
+        emit_trailer(&p[s], f1, "total_genome_kmers", (long long)p[s].ks.nrows);
+        emit_trailer(&p[s], f1, "total_genome_informative_kmers", (long long)p[s].genome_inf);
         if (p[s].cov) {
             skc_add_trailer(p[s].cov, f1, "total_kmer_evaluated", (int64_t)evaluated);
             skc_add_trailer(p[s].cov, f1, "total_reads_evaluated", (int64_t)reads);
@@ -678,6 +720,8 @@ static void usage(FILE *err)
     fputs("\ninformative kmer file is a list of all of the kmers left in the reference genome post scrubbing\n", err);
 }
 
+static skzo_pool *sd_zpool;             /* compressors of every -o file of the run (set by the main function) */
+
 /* build one strain's state in two steps: the key set (host only; several strains build theirs at the
  * same time on separate threads), then the table on the device, -a flags, optional -g filter, -o file */
 /* one strain of a -S list, opened on a worker thread: key set on the host, then its own context, table,
@@ -736,8 +780,8 @@ static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a,
     if (sd_flag_informative(p, a, &n_inform)) return 1;
     if (g && sd_background_filter(p, g, 0.5, n_inform)) return 1;
     for (i = 0; i < p->ks.nrows; i++) if (p->type[i] == SD_INFORMATIVE) p->genome_inf++;
-    p->gz = gzopen(o, "wb9");
-    if (!p->gz) { fprintf(err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
+    p->zo = skzo_open(sd_zpool, o);
+    if (!p->zo) { fprintf(err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
     p->o_path = strdup(o);
     return 0;
 }
@@ -783,7 +827,7 @@ static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *
 
 static void sd_strain_close(sd_prog *p)
 {
-    if (p->gz) gzclose(p->gz);
+    if (p->zo && skzo_close(p->zo)) fprintf(stderr, "strain_detect: error writing the -o file\n");
     if (p->ctx) sk_ctx_destroy(p->ctx);
     skh_keyset_free(&p->ks);
     free(p->type); free(p->copy_rows); free(p->hitbuf); free(p->tallybuf); free(p->cov_path); free(p->o_path);
@@ -834,6 +878,7 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
 {
     const char *a = NULL, *r = NULL, *b = NULL, *b2 = NULL, *B = NULL, *tt = NULL, *g = NULL, *o = NULL, *S = NULL, *env;
     int c, j, mode = SD_SE, status = 1, device = 0, n_S = 0, want_cov = 0;
+    skzo_pool zpool;
     const char *cov_file = NULL;
     long long cov_min = 1;
     double t_begin = 0;
@@ -899,6 +944,11 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
     }
     if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
     t_begin = now_s();
+    {
+        const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        skzo_pool_start(&zpool, getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : (int)(ncpu > 16 ? 16 : ncpu < 1 ? 1 : ncpu));
+        sd_zpool = &zpool;
+    }
 
     if (S) {
         FILE *fp = fopen(S, "r");
@@ -907,7 +957,7 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
         const int world = getenv("SK_WORLD_SIZE") ? atoi(getenv("SK_WORLD_SIZE")) : (getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1);
         const int rank = getenv("SK_RANK") ? atoi(getenv("SK_RANK")) : (getenv("RANK") ? atoi(getenv("RANK")) : 0);
         unsigned lineno = 0;
-        if (!fp) { fprintf(err, "strain_detect: could not read the strain list %s\n", S); return 1; }
+        if (!fp) { fprintf(err, "strain_detect: could not read the strain list %s\n", S); goto done; }
         if (!getenv("SK_DEVICE") && (env = getenv("SK_LOCAL_RANK") ? getenv("SK_LOCAL_RANK") : getenv("LOCAL_RANK")) != NULL) device = atoi(env);
         while (getline(&line, &cap, fp) != -1) {
             char *nl, *fr, *fa, *fo, *fg;
@@ -985,6 +1035,8 @@ done:
         fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally (upload+kernels+collect+sort) %.2f s, "
                      "total before close %.2f s\n", t_setup, t_wait, t_tally, now_s() - t_begin);
     for (s = 0; s < ns; s++) sd_strain_close(&p[s]);
+    skzo_pool_stop(&zpool);
+    sd_zpool = NULL;
     for (s = 0; paths && s < 4 * ns; s++) free(paths[s]);
     free(paths);
     free(p);

@@ -24,7 +24,7 @@ keys = ks.keys()
 rng = np.random.default_rng(7)
 pick = rng.choice(len(keys), size=len(keys) // 100, replace=False)
 open(os.path.join(work, "inf.txt"), "wb").write(b"#informative\n" + b"\n".join(keys[i] for i in sorted(pick)) + b"\n")
-stream, _ = synth.make_reads(contigs, READS, seed=synth.SEED + 500)
+stream, _ = synth.make_reads(contigs, READS, seed=synth.SEED + 500, hit_frac=float(os.environ.get("HIT_FRAC", "0.02")))
 rows = stream.reshape(READS, 151)[:, :150]
 with open(os.path.join(work, "reads.fa"), "wb") as f:
     f.write(b"".join(b">r%d\n%s\n" % (j, rows[j].tobytes()) for j in range(READS)))
