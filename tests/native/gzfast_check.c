@@ -33,7 +33,9 @@ static int pipe_decode(const char *path, buf *b, size_t stop_after)
         collect(b, d, n);
         if (stop_after && b->n >= stop_after) break;
     }
+    pthread_mutex_lock(&p.mu);                        /* (the helper may still be running when we walked away) */
     rc = p.done ? p.rc : SKZ_STOPPED;
+    pthread_mutex_unlock(&p.mu);
     skzp_close(&p);
     return rc;
 }
