@@ -8,6 +8,10 @@
  *     GEN_calculate_kmer_count()           src/genome_compare.c:179-236     (THE hot loop)
  *     BIO_searchHash()/BIO_getHashKeys()   src/BIO_hash.c:161-172,174-188   (lookup / row order)
  *     print_hash_counts()                  src/kmer_scrub_count.c:134-156   (TSV)
+ *     quantify_hits_PE()/hash_scrubbed_kmers()/background_filter()   src/strain_detect.c:387-663,668-726,160-240
+ *
+ * and, either side of it in the workflow (test/example.sh), the two scripts scripts/kmer_scrub_filter.py and
+ * scripts/coverage_depth.py, which are covered here too (sk_filter_*, sk_distinct_count, skh_*_main).
  *
  * The entry points below replace those calls one for one (each cites what it replaces).
  * Plain pointers and sizes only; no C++ or torch types.  Two layers:
