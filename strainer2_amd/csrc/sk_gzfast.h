@@ -46,6 +46,7 @@ enum { SKZ_K_LIT = 0, SKZ_K_LIT2 = 1, SKZ_K_LEN = 2, SKZ_K_EOB = 3, SKZ_K_SUB = 
 typedef struct {
     uint32_t litlen[(1u << SKZ_LITLEN_BITS) + 286 * 16];   /* primary + subtables (one of 2^(15-11) per long code at most) */
     uint32_t dist[(1u << SKZ_DIST_BITS) + 30 * 128];
+    uint8_t  lens[320]; unsigned nlit, ndist;              /* the code lengths the tables were built from (for skz_tail) */
 } skz_tables;
 
 static const uint16_t skz_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -151,6 +152,9 @@ typedef struct {
     skz_sink sink; void *user;
     uint32_t crc; uint64_t total;
     int stopped;
+    const unsigned char *data;                                 /* start of the mapped file (bit positions count from here) */
+    uint64_t stop_bit;                                         /* skz_inflate returns 2 at the first block boundary at or past this bit (0: none) */
+    int skip_crc;
 } skz_stream;
 
 static uint32_t skz_crc_tab[8][256];
@@ -272,7 +276,7 @@ static int skz_flush(skz_stream *s, int make_room)
 {
     const size_t n = (size_t)(s->out - s->out_flushed);
     if (n) {
-        s->crc = skz_crc32(s->crc, s->out_flushed, n);
+        if (!s->skip_crc) s->crc = skz_crc32(s->crc, s->out_flushed, n);
         s->total += n;
         if (!s->stopped && s->sink(s->user, s->out_flushed, n)) s->stopped = 1;
         s->out_flushed = s->out;
@@ -306,7 +310,18 @@ static int skz_flush(skz_stream *s, int make_room)
 /* more input consumed than there was (bits still in the buffer are counted as not consumed) */
 static inline int skz_overrun(const skz_stream *s) { return s->in > s->in_end + (s->bitcnt >> 3); }
 
-static int skz_read_dynamic(skz_stream *s, skz_tables *t)
+/* 1 when the code lengths describe a complete prefix code (Kraft sum exactly 1) */
+static int skz_complete(const uint8_t *lens, unsigned nsym)
+{
+    uint32_t sum = 0;
+    unsigned i;
+    for (i = 0; i < nsym; i++) if (lens[i]) sum += 1u << (15 - lens[i]);
+    return sum == (1u << 15);
+}
+
+/* strict: also insist on what zlib insists on for a block it would accept -- a complete literal/length code and a
+ * distance code that is complete or a single code (used by the block finder of sk_gzpar.h, where a header is a guess) */
+static int skz_read_dynamic(skz_stream *s, skz_tables *t, int strict)
 {
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     uint8_t lens[320], cl[19];
@@ -355,8 +370,15 @@ static int skz_read_dynamic(skz_stream *s, skz_tables *t)
         while (rep--) lens[n++] = (uint8_t)val;
     }
     if (skz_overrun(s) || lens[256] == 0) return -1;
+    if (strict) {
+        unsigned nd = 0;
+        for (i = 0; i < hdist; i++) nd += lens[hlit + i] != 0;
+        if (!skz_complete(lens, hlit)) return -1;
+        if (nd > 1 && !skz_complete(lens + hlit, hdist)) return -1;
+    }
     if (skz_build(t->litlen, SKZ_LITLEN_BITS, sizeof t->litlen / sizeof t->litlen[0], lens, hlit, 0)) return -1;
     if (skz_build(t->dist, SKZ_DIST_BITS, sizeof t->dist / sizeof t->dist[0], lens + hlit, hdist, 1)) return -1;
+    memcpy(t->lens, lens, hlit + hdist); t->nlit = hlit; t->ndist = hdist;
     return 0;
 }
 
@@ -369,8 +391,95 @@ static void skz_fixed_tables(skz_tables *t)
     for (; i < 280; i++) lens[i] = 7;
     for (; i < 288; i++) lens[i] = 8;
     skz_build(t->litlen, SKZ_LITLEN_BITS, sizeof t->litlen / sizeof t->litlen[0], lens, 288, 0);
+    memcpy(t->lens, lens, 288); t->nlit = 288;
     for (i = 0; i < 32; i++) lens[i] = 5;
     skz_build(t->dist, SKZ_DIST_BITS, sizeof t->dist / sizeof t->dist[0], lens, 32, 1);
+    memcpy(t->lens + 288, lens, 32); t->ndist = 32;
+}
+
+/* ---- the last bytes of the input, bit by bit --------------------------------------------------------------
+ * The table decoder above looks codes up in bits that may lie past the end of the input (zeros are supplied).
+ * In a complete file that never matters; in a file that was cut short it decides how much text comes out, and
+ * the reference (zlib's gzread under kseq) delivers exactly the symbols all of whose bits are there: a literal
+ * when its code is complete, a match when its length code, length bits, distance code and distance bits all
+ * are.  Within 16 bytes of the end skz_block therefore hands over to this decoder, which reads real bits only
+ * (canonical decoding from the code lengths, one bit at a time -- a few hundred symbols per file at most). */
+typedef struct { unsigned short count[16], symbol[288]; } skz_canon;
+
+static void skz_canon_build(skz_canon *c, const uint8_t *lens, unsigned n)
+{
+    unsigned offs[16], i;
+    memset(c->count, 0, sizeof c->count);
+    for (i = 0; i < n; i++) c->count[lens[i]]++;
+    c->count[0] = 0;
+    offs[1] = 0;
+    for (i = 1; i < 15; i++) offs[i + 1] = offs[i] + c->count[i];
+    for (i = 0; i < n; i++) if (lens[i]) c->symbol[offs[lens[i]]++] = (unsigned short)i;
+}
+
+/* one real bit, -1 when the input is used up */
+static inline int skz_real_bit(skz_stream *s)
+{
+    int b;
+    if (!s->bitcnt) {
+        if (s->in >= s->in_end) return -1;
+        s->bitbuf = *s->in++; s->bitcnt = 8;
+    }
+    b = (int)(s->bitbuf & 1u);
+    s->bitbuf >>= 1; s->bitcnt--;
+    return b;
+}
+static inline int skz_real_bits(skz_stream *s, unsigned n, uint32_t *v)
+{
+    unsigned i;
+    *v = 0;
+    for (i = 0; i < n; i++) { const int b = skz_real_bit(s); if (b < 0) return -1; *v |= (uint32_t)b << i; }
+    return 0;
+}
+/* the next symbol of a canonical code: >= 0, -1 input used up, -2 no such code */
+static int skz_real_symbol(skz_stream *s, const skz_canon *c)
+{
+    int code = 0, first = 0, index = 0, len;
+    for (len = 1; len <= 15; len++) {
+        const int b = skz_real_bit(s), count = c->count[len];
+        if (b < 0) return -1;
+        code |= b;
+        if (code - count < first) return c->symbol[index + (code - first)];
+        index += count; first += count;
+        first <<= 1; code <<= 1;
+    }
+    return -2;
+}
+
+/* the rest of the current block from the state in *s (every bit in the bit buffer is a real one): 0 at the
+ * end-of-block code, 1 stopped by the consumer, -1 when the input ends first or is damaged */
+static int skz_tail(skz_stream *s, const skz_tables *t)
+{
+    skz_canon lit, dst;
+    skz_canon_build(&lit, t->lens, t->nlit);
+    skz_canon_build(&dst, t->lens + t->nlit, t->ndist);
+    for (;;) {
+        int sym;
+        if ((size_t)(s->out_end - s->out) < 258 + 16 && skz_flush(s, 1)) return 1;
+        sym = skz_real_symbol(s, &lit);
+        if (sym < 0) return -1;
+        if (sym < 256) { *s->out++ = (unsigned char)sym; continue; }
+        if (sym == 256) return 0;
+        if (sym >= 286) return -1;
+        {
+            uint32_t x, len, dist;
+            int ds;
+            unsigned char *d;
+            if (skz_real_bits(s, skz_len_extra[sym - 257], &x)) return -1;
+            len = skz_len_base[sym - 257] + x;
+            ds = skz_real_symbol(s, &dst);
+            if (ds < 0 || ds >= 30) return -1;
+            if (skz_real_bits(s, skz_dist_extra[ds], &x)) return -1;
+            dist = skz_dist_base[ds] + x;
+            if (dist > (size_t)(s->out - s->out_base)) return -1;
+            for (d = s->out, s->out += len; d < s->out; d++) *d = *(d - dist);
+        }
+    }
 }
 
 /* one compressed block's symbols.  The decoder state lives in local variables for the duration (byte stores
@@ -386,7 +495,6 @@ static int skz_block(skz_stream *s, const skz_tables *t)
 #define SKZ_SAVE()    do { s->in = in; s->bitbuf = bitbuf; s->bitcnt = bitcnt; s->out = out; } while (0)
 #define SKZ_LOAD()    do { out = s->out; } while (0)
 #define SKZ_FILL_FAST() do { uint64_t w_; memcpy(&w_, in, 8); bitbuf |= w_ << bitcnt; in += (63u - bitcnt) >> 3; bitcnt |= 56u; } while (0)
-#define SKZ_FILL_SLOW() do { while (bitcnt <= 56u) { const uint64_t b_ = in < in_end ? *in : 0u; in++; bitbuf |= b_ << bitcnt; bitcnt += 8u; } } while (0)
 #define SKZ_KIND(e)   (((e) >> 4) & 15u)
     uint32_t enext = 0;
     int pre = 0;                                            /* enext = the entry after a match, looked up before its copy */
@@ -416,21 +524,15 @@ static int skz_block(skz_stream *s, const skz_tables *t)
                         continue;
                     }
                 }
-                if (in_end - in < 8) goto slow_refill;      /* (after a preloaded entry the 16-byte margin may be gone) */
+                if (in_end - in < 8) goto tail;             /* (after a preloaded entry the 16-byte margin may be gone) */
                 SKZ_FILL_FAST();                            /* (the low bits, hence e, are unchanged) */
             }
         } else {
-            if (in - in_end > 16) { rc = -1; break; }       /* decoding the zeros supplied past the end: truncated */
-            SKZ_FILL_SLOW();
-            e = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
-            if (0) { slow_refill: SKZ_FILL_SLOW(); goto have_entry; }
-            if (SKZ_IS_LITS(e)) {
-                bitbuf >>= e & 15u; bitcnt -= e & 15u; out[0] = (unsigned char)(e >> 16); out[1] = (unsigned char)(e >> 24); out += 1u + (SKZ_KIND(e) == SKZ_K_LIT2);
-                continue;
-            }
+tail:       /* within 16 bytes of the end of the input: real bits only from here on (e's bits are still in the buffer) */
+            SKZ_SAVE();
+            return skz_tail(s, t);
         }
-have_entry:
-        /* here: at least 56 bits (or the end of the input) and e is not a literal */
+        /* here: at least 56 real bits and e is not a literal */
         if (SKZ_KIND(e) == SKZ_K_SUB) {
             bitbuf >>= SKZ_LITLEN_BITS; bitcnt -= SKZ_LITLEN_BITS;
             e = lt[(e >> 16) + (uint32_t)(bitbuf & (((uint64_t)1 << ((e >> 8) & 255u)) - 1u))];
@@ -481,17 +583,29 @@ have_entry:
 #undef SKZ_SAVE
 #undef SKZ_LOAD
 #undef SKZ_FILL_FAST
-#undef SKZ_FILL_SLOW
 #undef SKZ_KIND
 #undef SKZ_IS_LITS
 }
 
-/* one DEFLATE stream (all blocks of a member) */
+/* where the next unread bit is, counted from s->data */
+static inline uint64_t skz_bit_position(const skz_stream *s) { return (uint64_t)(s->in - s->data) * 8u - s->bitcnt; }
+
+/* continue reading at bit `bit` of s->data */
+static inline void skz_seek_bit(skz_stream *s, uint64_t bit)
+{
+    s->in = s->data + (bit >> 3);
+    s->bitbuf = 0; s->bitcnt = 0;
+    if (bit & 7u) { SKZ_REFILL(s); SKZ_DROP(s, bit & 7u); }
+}
+
+/* one DEFLATE stream (all blocks of a member); 0 at the end of the final block, 1 stopped by the consumer, 2 at
+ * s->stop_bit, -1 corrupt */
 static int skz_inflate(skz_stream *s, skz_tables *dyn, const skz_tables *fixed)
 {
     for (;;) {
         uint32_t final, type;
-        int rc;
+        int rc, cut = 0;
+        if (s->stop_bit && skz_bit_position(s) >= s->stop_bit) return 2;
         SKZ_REFILL(s);
         final = SKZ_BITS(s, 1); SKZ_DROP(s, 1);
         type = SKZ_BITS(s, 2); SKZ_DROP(s, 2);
@@ -504,7 +618,8 @@ static int skz_inflate(skz_stream *s, skz_tables *dyn, const skz_tables *fixed)
             len = (uint32_t)s->in[0] | ((uint32_t)s->in[1] << 8);
             nlen = (uint32_t)s->in[2] | ((uint32_t)s->in[3] << 8);
             s->in += 4;
-            if ((len ^ 0xFFFFu) != nlen || (size_t)(s->in_end - s->in) < len) return -1;
+            if ((len ^ 0xFFFFu) != nlen) return -1;
+            if ((size_t)(s->in_end - s->in) < len) { cut = 1; len = (uint32_t)(s->in_end - s->in); }   /* zlib copies what there is */
             while (len) {
                 size_t room = (size_t)(s->out_end - s->out), take;
                 if (room < 4096) { if (skz_flush(s, 1)) return 1; room = (size_t)(s->out_end - s->out); }
@@ -512,10 +627,11 @@ static int skz_inflate(skz_stream *s, skz_tables *dyn, const skz_tables *fixed)
                 memcpy(s->out, s->in, take);
                 s->out += take; s->in += take; len -= (uint32_t)take;
             }
+            if (cut) return -1;
         } else if (type == 1) {
             if ((rc = skz_block(s, fixed)) != 0) return rc;
         } else if (type == 2) {
-            if (skz_read_dynamic(s, dyn)) return -1;
+            if (skz_read_dynamic(s, dyn, 0)) return -1;
             if ((rc = skz_block(s, dyn)) != 0) return rc;
         } else return -1;
         if (final) return 0;
@@ -536,13 +652,18 @@ static size_t skz_header(const unsigned char *p, size_t n)
     return i <= n ? i : 0;
 }
 
-static int skz_decode_memory(const unsigned char *data, size_t n, skz_sink sink, void *user)
+/* where to pick a member up in the middle (sk_gzpar.h hands the rest of a file over this way): the next block
+ * starts at bit `bit` of the file, the last `wlen` bytes produced so far are `window`, and crc/total cover
+ * everything of this member already delivered */
+typedef struct { uint64_t bit; const unsigned char *window; size_t wlen; uint32_t crc; uint64_t total; int members; } skz_resume;
+
+/* members from byte `pos` on (or, with rs, from the middle of the member described there) */
+static int skz_decode_members(const unsigned char *data, size_t n, size_t pos, const skz_resume *rs, skz_sink sink, void *user)
 {
     skz_stream s;
     skz_tables *dyn, *fixed;
-    size_t pos = 0, h;
-    int rc = SKZ_OK, members = 0;
-    if ((h = skz_header(data, n)) == 0) return SKZ_NOT_GZIP;
+    size_t h;
+    int rc = SKZ_OK, members = rs ? rs->members : 0;
     pthread_once(&skz_crc_once, skz_crc_init);
     memset(&s, 0, sizeof s);
     dyn = (skz_tables *)malloc(sizeof *dyn);
@@ -552,14 +673,23 @@ static int skz_decode_memory(const unsigned char *data, size_t n, skz_sink sink,
     skz_fixed_tables(fixed);
     s.out_end = s.out_base + SKZ_WINDOW + SKZ_OUT_CHUNK;
     s.sink = sink; s.user = user;
-    while (pos < n) {
+    s.data = data; s.in_end = data + n;
+    while (rs || pos < n) {
         int r;
-        h = skz_header(data + pos, n - pos);
-        if (h == 0) { if (!members) rc = SKZ_CORRUPT; break; }       /* trailing bytes after the last member: ignored */
-        s.in = data + pos + h; s.in_end = data + n;
-        s.bitbuf = 0; s.bitcnt = 0;
-        s.out = s.out_flushed = s.out_base;                          /* a member cannot refer back into the previous one */
-        s.crc = 0; s.total = 0;
+        if (rs) {
+            skz_seek_bit(&s, rs->bit);
+            memcpy(s.out_base, rs->window, rs->wlen);
+            s.out = s.out_flushed = s.out_base + rs->wlen;
+            s.crc = rs->crc; s.total = rs->total;
+            rs = NULL;
+        } else {
+            h = skz_header(data + pos, n - pos);
+            if (h == 0) { if (!members) rc = SKZ_CORRUPT; break; }       /* trailing bytes after the last member: ignored */
+            s.in = data + pos + h;
+            s.bitbuf = 0; s.bitcnt = 0;
+            s.out = s.out_flushed = s.out_base;                          /* a member cannot refer back into the previous one */
+            s.crc = 0; s.total = 0;
+        }
         r = skz_inflate(&s, dyn, fixed);
         skz_flush(&s, 0);
         if (r == 1 || s.stopped) { rc = SKZ_STOPPED; break; }
@@ -577,6 +707,12 @@ static int skz_decode_memory(const unsigned char *data, size_t n, skz_sink sink,
     }
     free(dyn); free(fixed); free(s.out_base);
     return rc;
+}
+
+static int skz_decode_memory(const unsigned char *data, size_t n, skz_sink sink, void *user)
+{
+    if (skz_header(data, n) == 0) return SKZ_NOT_GZIP;
+    return skz_decode_members(data, n, 0, NULL, sink, user);
 }
 
 __attribute__((unused))

@@ -2,16 +2,17 @@
  * the next ones are being inflated, so one gzip file is decoded by two cores instead of one (inflate and
  * record parsing cost about the same per byte).  Built on sk_gzfast.h; pull-style:
  *
- *     skzp p;  if (skzp_open(&p, path) != SKZ_OK) ... zlib route ...
+ *     skzp p;  if (skzp_open_threads(&p, path, threads) != SKZ_OK) ... zlib route ...
  *     while ((n = skzp_next(&p, &data)) > 0) parser_feed(ps, data, n);
  *     skzp_close(&p);                       // may be called early: stops the helper
  *
- * skzp_open answers SKZ_NOT_GZIP / SKZ_OPEN exactly as skz_decode_file would, before any thread is started.
+ * skzp_open_threads answers SKZ_NOT_GZIP / SKZ_OPEN exactly as skz_decode_file would, before any thread is started.
  */
 #ifndef SK_GZPIPE_H
 #define SK_GZPIPE_H
 #include <pthread.h>
 #include "sk_gzfast.h"
+#include "sk_gzpar.h"
 
 #define SKZP_NBUF 3
 
@@ -22,6 +23,7 @@ typedef struct {
     unsigned char *buf[SKZP_NBUF]; size_t len[SKZP_NBUF], cap[SKZP_NBUF];
     unsigned head, count;             /* filled pieces: buf[head], buf[head+1], ... */
     int done, cancel, rc, holding;    /* holding: the consumer still reads buf[head] */
+    int threads; size_t seg_bytes;    /* > 1: the member is inflated by that many threads (sk_gzpar.h) */
 } skzp;
 
 static int skzp_sink(void *user, const unsigned char *data, size_t n)
@@ -51,7 +53,8 @@ static int skzp_sink(void *user, const unsigned char *data, size_t n)
 static void *skzp_thread(void *arg)
 {
     skzp *p = (skzp *)arg;
-    const int rc = skz_decode_memory(p->map, p->map_len, skzp_sink, p);
+    const int rc = p->threads > 1 ? skzq_decode_memory(p->map, p->map_len, p->threads, p->seg_bytes, skzp_sink, p)
+                                  : skz_decode_memory(p->map, p->map_len, skzp_sink, p);
     pthread_mutex_lock(&p->mu);
     p->rc = rc;
     p->done = 1;
@@ -60,11 +63,15 @@ static void *skzp_thread(void *arg)
     return NULL;
 }
 
-static int skzp_open(skzp *p, const char *path)
+/* threads: how many cores may inflate this one file (1: the helper thread alone).  SK_GZ_SEG overrides the
+ * segment size of the parallel decoder (the tests use tiny ones). */
+static int skzp_open_threads(skzp *p, const char *path, int threads)
 {
     const int fd = open(path, O_RDONLY);
     struct stat st;
     memset(p, 0, sizeof *p);
+    p->threads = threads;
+    p->seg_bytes = getenv("SK_GZ_SEG") ? (size_t)strtoull(getenv("SK_GZ_SEG"), NULL, 10) : 0;
     if (fd < 0) return SKZ_OPEN;
     if (fstat(fd, &st) || !S_ISREG(st.st_mode) || st.st_size < 18) { close(fd); return SKZ_NOT_GZIP; }
     p->map = (unsigned char *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);

@@ -57,7 +57,8 @@ static int parse_feed_sink(void *user, const unsigned char *data, size_t n)
     return ps->state == P_STOP;
 }
 
-/* pipe: inflate on a helper thread while this one parses (worth it when there are fewer files than cores) */
+/* pipe: inflate on a helper thread while this one parses (worth it when there are fewer files than cores);
+ * pipe > 1: the helper inflates each gzip member with that many threads (sk_gzpar.h) */
 static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords, int *sink_rc, int pipe)
 {
     enum { BLK = 1 << 20 };
@@ -71,7 +72,7 @@ static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords
     if (getenv("SK_ZLIB")) zrc = SKZ_NOT_GZIP;
     else if (pipe) {
         skzp zp;
-        zrc = skzp_open(&zp, path);
+        zrc = skzp_open_threads(&zp, path, pipe);               /* pipe > 1: that many threads inflate the one file */
         if (zrc == SKZ_OK) {
             const unsigned char *data;
             size_t n;
@@ -600,7 +601,7 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases)
 typedef struct {
     sk_ctx         *ctx;
     uint32_t        col;
-    int             pipe;              /* fewer files than cores: each file's inflate gets a helper thread */
+    int             pipe;              /* fewer files than cores: each file's inflate gets a helper thread (> 1: that many) */
     pthread_mutex_t submit_mu;         /* sk_scan_stream is one-caller-at-a-time per context */
     pthread_mutex_t queue_mu;
     char          **path;              /* work list of this call (files this rank scans), in list order */
@@ -758,9 +759,15 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     }
     free(line);
     fclose(fp);
-    {   /* with fewer files than half the cores, a file's inflate and its record parsing take a core each */
+    {   /* with fewer files than half the cores, a file's inflate and its record parsing take a core each; with
+         * fewer still, the threads left over inflate inside the files (a speculative segment costs about twice a
+         * serial one, so it takes three threads per file to be worth it).  SK_GZ_THREADS sets the number per file. */
         const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        const char *gzt = getenv("SK_GZ_THREADS");
         pool.pipe = nthreads > 1 && (long)pool.npath * 2 <= ncpu;
+        if (pool.pipe && pool.npath && nthreads / (int)pool.npath >= 3) pool.pipe = nthreads / (int)pool.npath;
+        if (gzt && nthreads > 1) pool.pipe = atoi(gzt) < 1 ? 1 : atoi(gzt);
+        if (pool.pipe > 16) pool.pipe = 16;
     }
     if (nthreads > 1 && pool.npath) {
         pthread_t *th;

@@ -79,6 +79,7 @@ typedef struct sd_chunk {
 
 typedef struct {
     const char *path;
+    int gz_threads;                 /* threads inflating this file (sk_gzpar.h when > 1) */
     gzFile      g;
     pthread_t   th; int started;
     pthread_mutex_t mu; pthread_cond_t cv;
@@ -158,7 +159,7 @@ static void *sd_decode_thread(void *arg)
      * SK_ZLIB=1, through zlib */
     {
         skzp zp;
-        if (!getenv("SK_ZLIB") && skzp_open(&zp, st->path) == SKZ_OK) {
+        if (!getenv("SK_ZLIB") && skzp_open_threads(&zp, st->path, st->gz_threads) == SKZ_OK) {
             const unsigned char *data;
             size_t n;
             while (ps.state != P_STOP && !st->cancel && (n = skzp_next(&zp, &data)) > 0) parser_feed(&ps, data, n);
@@ -178,11 +179,24 @@ static void *sd_decode_thread(void *arg)
     return NULL;
 }
 
+/* how many threads may inflate each of the `nfiles` files read at the same time: SK_GZ_THREADS, or the host
+ * thread budget (SK_THREADS, default min(16, online CPUs)) shared out -- used when it leaves three or more per
+ * file, below that the one helper thread of sk_gzpipe.h does as well */
+static int sd_gz_threads(int nfiles)
+{
+    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    const int budget = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : (int)(ncpu < 1 ? 1 : ncpu > 16 ? 16 : ncpu);
+    int per = budget / nfiles;
+    if (getenv("SK_GZ_THREADS")) per = atoi(getenv("SK_GZ_THREADS"));
+    return per >= 3 ? (per > 16 ? 16 : per) : 1;
+}
+
 /* SK_E_OPEN if the file cannot be opened (nothing started) */
-static int stream_open(sd_stream *st, const char *path)
+static int stream_open(sd_stream *st, const char *path, int gz_threads)
 {
     memset(st, 0, sizeof *st);
     st->path = path;
+    st->gz_threads = gz_threads;
     st->chunk_bytes = sd_chunk_bytes();
     st->g = gzopen(path, "r");
     if (!st->g) return SK_E_OPEN;
@@ -511,11 +525,11 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
     FILE *err = p[0].err;
 
     memset(&B, 0, sizeof B);
-    rc = stream_open(&A, f1);
+    rc = stream_open(&A, f1, sd_gz_threads(mode == SD_PE ? 2 : 1));
     if (rc == SK_E_OPEN) { fprintf(err, "could not read file (read1) %s in quantify_hits_PE() (error: %s)\n", f1, strerror(errno)); return 1; }
     if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f1); return 1; }
     if (mode == SD_PE) {
-        rc = stream_open(&B, f2);
+        rc = stream_open(&B, f2, sd_gz_threads(2));
         if (rc == SK_E_OPEN) { fprintf(err, "could not read file (read2) is_PE %s in quantify_hits_PE() (error: (null))\n", f2); stream_close(&A); return 1; }
         if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f2); stream_close(&A); return 1; }
     }

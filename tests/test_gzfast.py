@@ -23,8 +23,10 @@ def checker(tmp_path_factory):
     return exe
 
 
-def run(checker, files, pipe=False):
-    p = subprocess.run([checker] + (["--pipe"] if pipe else []) + [str(f) for f in files], env=ENV, capture_output=True)
+def run(checker, files, pipe=False, par=0, seg=0):
+    env = dict(ENV, SK_GZ_SEG=str(seg)) if seg else ENV
+    p = subprocess.run([checker] + (["--pipe"] if pipe else []) + (["--par", str(par)] if par else []) + [str(f) for f in files],
+                       env=env, capture_output=True)
     assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     assert b"MISMATCH" not in p.stdout
@@ -200,3 +202,96 @@ def test_helper_thread_pipe(checker, checker_tsan, tmp_path):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
     q = subprocess.run([checker_tsan, "--pipe"] + [str(f) for f in files], env=env, capture_output=True)
     assert b"ThreadSanitizer" not in q.stderr and q.returncode == 0, q.stderr.decode()[-2000:]
+
+
+def test_one_member_inflated_by_several_threads(checker, checker_tsan, tmp_path):
+    """sk_gzpar.h: segments found by block search, decoded speculatively into symbols, stitched in order.  With
+    segments of 64 bytes to 30 KB every route is taken many times (guess accepted, gap decoded first, segment
+    decoded again, no block in a segment, member end inside a segment, second member, damage) and the bytes
+    must still be zlib's, under ASan/UBSan and under ThreadSanitizer."""
+    p = payloads()
+    rng = random.Random(99)
+    files = []
+    for name in ("fastq", "dna", "text", "far", "skewed", "random", "zeros", "period3"):
+        for level in (1, 6, 9):
+            f = tmp_path / f"{name}.l{level}.gz"
+            f.write_bytes(gzip.compress(p[name], level, mtime=0))
+            files.append(f)
+    for strat, sname in ((zlib.Z_FIXED, "fixed"), (zlib.Z_HUFFMAN_ONLY, "huff"), (zlib.Z_RLE, "rle")):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strat)
+        f = tmp_path / f"fastq.{sname}.gz"
+        f.write_bytes(c.compress(p["fastq"]) + c.flush())
+        files.append(f)
+    # pigz-style: an empty stored block (sync flush) every so often -- the boundary block the search does not see
+    c = zlib.compressobj(6, zlib.DEFLATED, 31)
+    f = tmp_path / "fastq.sync.gz"
+    f.write_bytes(b"".join(c.compress(p["fastq"][i:i + 5000]) + c.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(p["fastq"]), 5000)) + c.flush())
+    files.append(f)
+    # fixed-Huffman and dynamic blocks taking turns (raw pieces of separate compressors, each ended by a full flush):
+    # half the segment boundaries are followed by blocks the search skips, then by one it finds
+    body, data = b"", p["fastq"][:300_000]
+    for j, i in enumerate(range(0, len(data), 2500)):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED if j % 2 else zlib.Z_DEFAULT_STRATEGY)
+        body += c.compress(data[i:i + 2500]) + c.flush(zlib.Z_FULL_FLUSH)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body += c.compress(b"the end\n") + c.flush()
+    whole = data + b"the end\n"
+    f = tmp_path / "fixed_dynamic_turns.gz"
+    f.write_bytes(bytes([0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 3]) + body + zlib.crc32(whole).to_bytes(4, "little") + len(whole).to_bytes(4, "little"))
+    files.append(f)
+    a, b = gzip.compress(p["fastq"], 6, mtime=0), gzip.compress(p["dna"], 1, mtime=0)
+    (tmp_path / "two.gz").write_bytes(a + b)
+    (tmp_path / "garbage_after.gz").write_bytes(a + b"this is not gzip" * 1000)
+    (tmp_path / "many_small.gz").write_bytes(b"".join(gzip.compress(p["fastq"][i:i + 20000], 6, mtime=0) for i in range(0, len(p["fastq"]), 20000)))
+    files += [tmp_path / "two.gz", tmp_path / "garbage_after.gz", tmp_path / "many_small.gz"]
+    good = len(files)
+    for cut in (len(a) - 1, len(a) - 9, len(a) // 2, len(a) // 7):
+        f = tmp_path / f"cut{cut}.gz"
+        f.write_bytes(a[:cut])
+        files.append(f)
+    for i in range(10):
+        bad = bytearray(a)
+        bad[rng.randrange(20, len(bad) - 8)] ^= 1 << rng.randrange(8)
+        f = tmp_path / f"flip{i}.gz"
+        f.write_bytes(bytes(bad))
+        files.append(f)
+    total = [0, 0, 0]
+    for seg in (64, 1500, 30000):
+        out = run(checker, files, par=3, seg=seg)
+        assert out.count(" OK ") >= good and out.count("damaged") >= 4
+        stats = [int(x) for x in out.split("par: direct ")[1].replace("gap", "").replace("again", "").split()]
+        assert stats[0] > 20 and stats[2] > 0, (seg, stats)
+        total = [a + b for a, b in zip(total, stats)]
+    assert min(total) > 0, total                                  # (direct, after a gap, decoded again)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", SK_GZ_SEG="1500")
+    t = subprocess.run([checker_tsan, "--par", "4"] + [str(f) for f in files], env=env, capture_output=True)
+    assert t.returncode == 0 and b"ThreadSanitizer" not in t.stderr and b"MISMATCH" not in t.stdout, (t.stdout[-1500:], t.stderr[-3000:])
+
+
+def test_files_cut_short_give_exactly_zlibs_bytes(checker, tmp_path):
+    """the reference parses whatever gzread can still decode of a truncated file, so the decoder must stop at the
+    same symbol: 400 cut points over dynamic, fixed and stored blocks, block headers and the trailer (the checker
+    insists on equal byte counts when zlib reports an early end of input)"""
+    p = payloads()
+    rng = random.Random(4321)
+    blobs = {
+        "fq6": gzip.compress(p["fastq"][:120_000], 6, mtime=0),
+        "fq1": gzip.compress(p["fastq"][:120_000], 1, mtime=0),
+        "stored": gzip.compress(p["random"][:70_000], 6, mtime=0),
+        "text9": gzip.compress(p["text"][:200_000], 9, mtime=0),
+    }
+    c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+    blobs["fixed"] = c.compress(p["fastq"][:60_000]) + c.flush()
+    c = zlib.compressobj(6, zlib.DEFLATED, 31)
+    blobs["sync"] = b"".join(c.compress(p["fastq"][i:i + 900]) + c.flush(zlib.Z_SYNC_FLUSH) for i in range(0, 60_000, 900)) + c.flush()
+    files = []
+    for name, blob in blobs.items():
+        cuts = {len(blob) - k for k in range(1, 40)} | {rng.randrange(19, len(blob)) for _ in range(40)}
+        for cut in sorted(cuts):
+            f = tmp_path / f"{name}.{cut}.gz"
+            f.write_bytes(blob[:cut])
+            files.append(f)
+    out = run(checker, files)
+    assert out.count("damaged") == len(files) and out.count(": OK") == len(files)
+    out = run(checker, files, par=3, seg=700)
+    assert out.count("damaged") == len(files) and out.count(": OK") == len(files)

@@ -227,3 +227,53 @@ def test_kmer_scrub_count_thread_pool_under_sanitizers(ks_host_exe, tmp_path):
     for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
         assert bad not in p.stderr, p.stderr.decode()[-3000:]
     assert (p.returncode, p.stdout) == (want.returncode, want.stdout) and want.returncode == 0
+
+
+@pytest.mark.parametrize("name", ["batch", "cli_pe", "cli_pei"])
+def test_strain_detect_members_inflated_by_several_threads(sd_host_exe, name, tmp_path):
+    """the read files of strain_detect through sk_gzpar.h (three inflating threads per file, segments of 100 bytes
+    so that the small fixtures are cut into many): same output"""
+    import gzip
+    d = os.path.join(SD_DIR, name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    argv = list(meta["argv"])
+    argv[argv.index("-o") + 1] = str(tmp_path / "o.gz")
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_GZ_THREADS="3", SK_GZ_SEG="100")
+    p = subprocess.run([sd_host_exe] + argv, cwd=d, env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in p.stderr, p.stderr.decode()[-3000:]
+    assert p.returncode == meta["returncode"] == 0
+    assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
+    assert gzip.open(tmp_path / "o.gz", "rb").read() == open(os.path.join(d, "expected.hits"), "rb").read()
+
+
+def test_kmer_scrub_count_members_inflated_by_several_threads(ks_host_exe, tmp_path):
+    """three .gz list files, each inflated by three threads in segments of 200 bytes, one of them cut short: the
+    oracle program's table and messages"""
+    import gzip
+    import random
+    rng = random.Random(6)
+    strain = "".join(rng.choice("ACGT") for _ in range(20000))
+    (tmp_path / "s.fa").write_text(">s\n" + strain + "\n")
+    names = []
+    for i in range(3):
+        recs = []
+        for j in range(600):
+            a = rng.randrange(0, len(strain) - 200)
+            seq = strain[a:a + rng.randrange(20, 200)]
+            recs.append(f"@r{j}\n{seq}\n+\n{'I' * len(seq)}\n")
+        blob = gzip.compress("".join(recs).encode(), 6, mtime=0)
+        (tmp_path / f"m{i}.fq.gz").write_bytes(blob if i < 2 else blob[:len(blob) * 2 // 3])
+        names.append(f"m{i}.fq.gz")
+    (tmp_path / "A.txt").write_text(names[0] + "\n")
+    (tmp_path / "B.txt").write_text("\n".join(names) + "\n")
+    argv = ["-r", "s.fa", "-A", "A.txt", "-B", "B.txt"]
+    oracle = os.path.join(REPO, "oracle", "kso_oracle")
+    if not os.path.exists(oracle):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "kso_oracle"], check=True, stdout=subprocess.DEVNULL)
+    want = subprocess.run([oracle] + argv, cwd=tmp_path, capture_output=True)
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_GZ_THREADS="3", SK_GZ_SEG="200")
+    p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in p.stderr, p.stderr.decode()[-3000:]
+    assert (p.returncode, p.stdout, p.stderr) == (want.returncode, want.stdout, want.stderr)
