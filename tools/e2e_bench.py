@@ -19,6 +19,9 @@ os.makedirs(work, exist_ok=True)
 contigs = synth.make_strain()
 open(os.path.join(work, "strain.fa"), "wb").write(synth.strain_fasta(contigs))
 qual = b"I" * 150
+# QUAL=binned: quality strings drawn per base from four binned values (as current Illumina machines write them)
+# instead of a constant line -- gzip then compresses ~4.5x instead of ~6x and inflate has real work to do
+BINNED = os.environ.get("QUAL") == "binned"
 t0 = time.time()
 KINDS = tuple(os.environ.get("KINDS", "fq,fq.gz").split(","))
 for kind in KINDS:
@@ -30,7 +33,13 @@ for kind in KINDS:
             continue
         stream, _ = synth.make_reads(contigs, READS, seed=synth.SEED + 100 + i)
         rows = stream.reshape(READS, 151)[:, :150]
-        body = b"".join(b"@r%d\n%s\n+\n%s\n" % (j, rows[j].tobytes(), qual) for j in range(READS))
+        if BINNED:
+            import numpy as np
+            q = np.random.default_rng(1000 + i).choice(np.frombuffer(b"FFFFFFFFFF::,#", dtype=np.uint8), size=(READS, 150))
+            body = b"".join(b"@r%d\n%s\n+\n%s\n" % (j, rows[j].tobytes(), q[j].tobytes()) for j in range(READS))
+            del q
+        else:
+            body = b"".join(b"@r%d\n%s\n+\n%s\n" % (j, rows[j].tobytes(), qual) for j in range(READS))
         if kind.endswith("gz"):
             with gzip.open(p, "wb", compresslevel=4) as f:
                 f.write(body)
