@@ -69,6 +69,7 @@ typedef struct {
  * ------------------------------------------------------------------------------------------- */
 typedef struct sd_chunk {
     uint8_t  *buf; uint64_t blen, bcap;      /* record stream: the records of length >= k, '\n' after each */
+    int       pinned;                        /* buf belongs to the pool of page-locked buffers */
     uint32_t *pstart, *prec; uint32_t np, pcap;   /* those records: offset in buf, index in len[] */
     uint64_t *len; uint32_t nrec, rcap;      /* every record, length as the reference sees it */
     int       last, end_kind; size_t end_len;/* last chunk of the file: how the parser ended */
@@ -91,13 +92,47 @@ typedef struct {
     int         eof, end_kind; size_t end_len;
 } sd_stream;
 
+/* Page-locked chunk buffers, recycled.  The upload of a chunk from ordinary memory goes through the runtime's
+ * staging path, which collapses (measured: 17 -> 1.7 GB/s) as soon as other threads of the process fault pages
+ * in at a high rate -- which is what the decode threads do when one .gz file is inflated by eight of them. */
+#define SD_PIN_MAX 16
+static struct {
+    pthread_mutex_t mu;
+    sk_ctx *ctx; size_t bytes;
+    void *idle[SD_PIN_MAX]; int nidle, total;
+} sd_pin = { PTHREAD_MUTEX_INITIALIZER, NULL, 0, {NULL}, 0, 0 };
+
+static void *sd_pin_get(void)
+{
+    void *q = NULL;
+    pthread_mutex_lock(&sd_pin.mu);
+    if (sd_pin.nidle) q = sd_pin.idle[--sd_pin.nidle];
+    else if (sd_pin.ctx && sd_pin.total < SD_PIN_MAX && sk_pinned_alloc(sd_pin.ctx, &q, sd_pin.bytes) == SK_OK) sd_pin.total++;
+    else q = NULL;
+    pthread_mutex_unlock(&sd_pin.mu);
+    return q;
+}
+static void sd_pin_put(void *q)
+{
+    pthread_mutex_lock(&sd_pin.mu);
+    sd_pin.idle[sd_pin.nidle++] = q;                     /* (at most `total` <= SD_PIN_MAX are ever out) */
+    pthread_mutex_unlock(&sd_pin.mu);
+}
+static void sd_pin_open(sk_ctx *ctx, size_t bytes) { sd_pin.ctx = ctx; sd_pin.bytes = bytes; }
+static void sd_pin_close(void)
+{
+    while (sd_pin.nidle) { sk_pinned_free(sd_pin.ctx, sd_pin.idle[--sd_pin.nidle]); sd_pin.total--; }
+    sd_pin.ctx = NULL;
+}
+
 static void chunk_free(sd_chunk *c)
 {
     uint32_t s;
     if (!c) return;
     for (s = 0; s < c->nstrains; s++) { free(c->hits[s]); free(c->inf[s]); free(c->hbeg[s]); free(c->rows[s]); }
     free(c->hits); free(c->inf); free(c->hbeg); free(c->rows);
-    free(c->buf); free(c->pstart); free(c->prec); free(c->len);
+    if (c->pinned) sd_pin_put(c->buf); else free(c->buf);
+    free(c->pstart); free(c->prec); free(c->len);
     free(c);
 }
 
@@ -130,10 +165,14 @@ static int sd_on_record(void *user, char *seq, size_t len)
             c->pstart = (uint32_t *)realloc(c->pstart, (size_t)c->pcap * sizeof *c->pstart);
             c->prec = (uint32_t *)realloc(c->prec, (size_t)c->pcap * sizeof *c->prec);
         }
+        if (!c->buf && len + 1 <= st->chunk_bytes && (c->buf = (uint8_t *)sd_pin_get()) != NULL) {
+            c->pinned = 1;                                 /* the usual case: a whole chunk's worth, page-locked */
+            c->bcap = st->chunk_bytes;
+        }
         if (c->blen + len + 1 > c->bcap) {                 /* a record never straddles chunks: grow instead */
             uint64_t cap = c->bcap ? c->bcap : 1u << 20;
             while (cap < c->blen + len + 1) cap *= 2;
-            c->buf = (uint8_t *)realloc(c->buf, cap);
+            c->buf = (uint8_t *)realloc(c->buf, cap);      /* (never a pool buffer: those hold chunk_bytes, the most a chunk takes) */
             c->bcap = cap;
         }
         c->pstart[c->np] = (uint32_t)c->blen;
@@ -229,7 +268,7 @@ static void stream_close(sd_stream *st)
 }
 
 /* SK_SD_TIMING=1: where the wall clock went, on stderr at exit */
-static double t_wait, t_tally, t_setup;
+static double t_wait, t_tally, t_setup, t_alloc, t_fill, t_launch, t_collect, t_post;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 static int hit_cmp(const void *a, const void *b)
@@ -244,6 +283,7 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
 {
     uint32_t s, r, k;
     int rc;
+    double t0 = now_s(), t1;
     c->nstrains = ns;
     c->hits = (uint32_t **)calloc(ns, sizeof *c->hits);
     c->inf = (uint32_t **)calloc(ns, sizeof *c->inf);
@@ -255,11 +295,14 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
         c->hbeg[s] = (uint32_t *)calloc((size_t)c->nrec + 2, sizeof(uint32_t));
     }
     if (c->np == 0) return SK_OK;
+    t1 = now_s(); t_alloc += t1 - t0; t0 = t1;
     if ((rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
+    t1 = now_s(); t_fill += t1 - t0; t0 = t1;
     for (s = 0; s < ns; s++) {
         if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
         if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
     }
+    t1 = now_s(); t_launch += t1 - t0; t0 = t1;
     for (s = 0; s < ns; s++) {
         uint64_t nh = 0, h = 0;
         uint32_t *tally, n = 0;
@@ -275,6 +318,7 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
             if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
             if ((rc = sk_tally_collect(p[s].ctx, tally, p[s].hitbuf, &nh)) != SK_OK) return rc;
         }
+        t1 = now_s(); t_collect += t1 - t0; t0 = t1;
         qsort(p[s].hitbuf, (size_t)nh, sizeof(sk_hit), hit_cmp);
         c->rows[s] = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
         for (k = 0, r = 0; k < c->np; k++) {
@@ -285,6 +329,7 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
             while (h < nh && p[s].hitbuf[h].pos < end) c->rows[s][n++] = p[s].hitbuf[h++].row;
         }
         for (; r <= c->nrec; r++) c->hbeg[s][r] = n;
+        t1 = now_s(); t_post += t1 - t0; t0 = t1;
     }
     return SK_OK;
 }
@@ -859,6 +904,7 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
         fprintf(err, "strain_detect: %s (%s)\n", sk_strerror(rc), sk_last_error(p[0].ctx));
         return 1;
     }
+    sd_pin_open(p[0].ctx, sd_chunk_bytes());
     pool_start(&pool, ns);
     if (B) {
         FILE *fp = fopen(B, "r");
@@ -1046,8 +1092,10 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
     status = 0;
 done:
     if (getenv("SK_SD_TIMING"))
-        fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally (upload+kernels+collect+sort) %.2f s, "
-                     "total before close %.2f s\n", t_setup, t_wait, t_tally, now_s() - t_begin);
+        fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (arrays %.2f, upload %.2f, "
+                     "launch %.2f, collect %.2f, sort+spread %.2f), total before close %.2f s\n", t_setup, t_wait, t_tally, t_alloc, t_fill,
+                t_launch, t_collect, t_post, now_s() - t_begin);
+    sd_pin_close();
     for (s = 0; s < ns; s++) sd_strain_close(&p[s]);
     skzo_pool_stop(&zpool);
     sd_zpool = NULL;

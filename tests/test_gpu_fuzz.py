@@ -2,6 +2,7 @@
 IUPAC letters and U in strain and reads, low-complexity and repeated stretches, duplicated reads, read lengths
 around k and around the 16-byte chunk grid, junk rates, streams that cross tile boundaries), all three scanned
 columns compared count for count, then the same through TALLY mode (per-read tallies and the hit log)."""
+import os
 import random
 
 import numpy as np
@@ -12,6 +13,9 @@ import _synth
 import strainer2_amd as sk
 
 pytestmark = pytest.mark.gpu
+
+# SK_FUZZ_EXTRA=N: N more seeds per test on top of the ones that always run (a longer hunt, run by hand)
+EXTRA = int(os.environ.get("SK_FUZZ_EXTRA", "0"))
 
 
 def world(seed):
@@ -41,7 +45,7 @@ def world(seed):
     return sstream, data
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", list(range(36)) + list(range(1000, 1000 + EXTRA)))
 def test_scan_count_fuzz(seed):
     sstream, data = world(seed)
     ks = sk.Keyset.from_stream(sstream)
@@ -65,7 +69,7 @@ def test_scan_count_fuzz(seed):
             assert np.array_equal(c.counts(col), ocounts[:, col]), (seed, col)
 
 
-@pytest.mark.parametrize("seed", range(100, 112))
+@pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(5000, 5000 + EXTRA // 3)))
 def test_tally_fuzz(seed):
     """per-read tallies and the log of informative hits against counts derived from the oracle's scan of each
     read on its own"""
