@@ -33,7 +33,7 @@
 #include "sk_gzfast.h"
 
 #define SKZQ_SEG        (2u << 20)
-#define SKZQ_MAX_RATIO  64u                     /* a speculative segment may grow to this many times its compressed size */
+#define SKZQ_MAX_RATIO  24u                     /* a speculative segment may grow to this many times its compressed size */
 #define SKZQ_MAX_THREADS 32
 
 typedef struct {

@@ -93,13 +93,14 @@ static void parser_feed(parser *ps, const unsigned char *b, size_t n)
             while (i < n && b[i] != '>' && b[i] != '@') i++;
             if (i < n) { i++; begin_header(ps); }
             break;
-        case P_NAME:
-            while (i < n) {
-                int c = b[i++];
-                ps->name_any = 1;
-                if (isspace(c)) { ps->state = (c == '\n') ? P_LINE_START : P_COMMENT; break; }
-            }
-            break;
+        case P_NAME: {
+            /* the name ends at the first white space and the rest of the header line is skipped (P_COMMENT), so all
+             * that matters is where the line ends; a header cut off by the end of the input gives an empty record
+             * from either state (parser_eof) */
+            const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
+            if (i < n) ps->name_any = 1;
+            if (nl) { i = (size_t)(nl - b) + 1; ps->state = P_LINE_START; } else i = n;
+            break; }
         case P_COMMENT: {
             const unsigned char *nl = (const unsigned char *)memchr(b + i, '\n', n - i);
             if (nl) { i = (size_t)(nl - b) + 1; ps->state = P_LINE_START; } else i = n;
