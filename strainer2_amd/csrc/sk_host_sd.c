@@ -61,6 +61,7 @@ typedef struct {
     skc_acc    *cov; char *cov_path, *o_path;           /* --coverage-depth: step 4 of the workflow, fed at emission */
     sk_hit     *hitbuf; uint64_t hitcap;   /* landing area of the hit log */
     uint32_t   *tallybuf; uint32_t tallycap;
+    int         hc_out, job_rc;            /* results of this strain's part of a pool job */
 } sd_prog;
 
 /* ---------------------------------------------------------------------------------------------
@@ -268,8 +269,96 @@ static void stream_close(sd_stream *st)
 }
 
 /* SK_SD_TIMING=1: where the wall clock went, on stderr at exit */
-static double t_wait, t_tally, t_setup, t_alloc, t_fill, t_launch, t_collect, t_post;
+static double t_wait, t_tally, t_setup, t_fill, t_launch, t_post, t_close;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+/* The strains are independent once a chunk is on the device: the per-strain work -- collecting and spreading a
+ * chunk's tallies, replaying a run (and with it the gz compression of each strain's own output), closing a strain
+ * -- is dealt out strain by strain to a few threads.  pool_run(pool, n, fn, arg) calls fn(arg, s) for every s < n,
+ * the calling thread being one of the workers, and returns when all are done. */
+typedef void (*sd_job_fn)(void *arg, uint32_t s);
+typedef struct {
+    pthread_t th[16]; int nth;
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+    unsigned long gen; int quit;
+    sd_job_fn fn; void *arg; uint32_t ns;
+    uint32_t next, done;
+} sd_pool;
+
+static void pool_drain(sd_pool *pl)
+{
+    uint32_t mine = 0;
+    for (;;) {
+        const uint32_t s = __atomic_fetch_add(&pl->next, 1u, __ATOMIC_ACQ_REL);   /* pairs with the release store that opens a job */
+        if (s >= pl->ns) break;
+        pl->fn(pl->arg, s);
+        mine++;
+    }
+    pthread_mutex_lock(&pl->mu);
+    pl->done += mine;
+    if (pl->done == pl->ns) pthread_cond_broadcast(&pl->cv_done);
+    pthread_mutex_unlock(&pl->mu);
+}
+
+static void *pool_worker_sd(void *arg)
+{
+    sd_pool *pl = (sd_pool *)arg;
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&pl->mu);
+        while (pl->gen == seen && !pl->quit) pthread_cond_wait(&pl->cv_work, &pl->mu);
+        if (pl->quit) { pthread_mutex_unlock(&pl->mu); return NULL; }
+        seen = pl->gen;
+        pthread_mutex_unlock(&pl->mu);
+        pool_drain(pl);
+    }
+}
+
+static void pool_start(sd_pool *pl, uint32_t ns)
+{
+    int want = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : 8, i;
+    memset(pl, 0, sizeof *pl);
+    if (want > 16) want = 16;
+    if ((uint32_t)want > ns) want = (int)ns;
+    pthread_mutex_init(&pl->mu, NULL);
+    pthread_cond_init(&pl->cv_work, NULL);
+    pthread_cond_init(&pl->cv_done, NULL);
+    for (i = 0; i + 1 < want; i++)                       /* the calling thread is one of the workers */
+        if (pthread_create(&pl->th[pl->nth], NULL, pool_worker_sd, pl) == 0) pl->nth++;
+}
+
+static void pool_stop(sd_pool *pl)
+{
+    int i;
+    pthread_mutex_lock(&pl->mu);
+    pl->quit = 1;
+    pthread_cond_broadcast(&pl->cv_work);
+    pthread_mutex_unlock(&pl->mu);
+    for (i = 0; i < pl->nth; i++) pthread_join(pl->th[i], NULL);
+    pthread_mutex_destroy(&pl->mu);
+    pthread_cond_destroy(&pl->cv_work);
+    pthread_cond_destroy(&pl->cv_done);
+}
+
+static void pool_run(sd_pool *pl, uint32_t ns, sd_job_fn fn, void *arg)
+{
+    if (!pl || pl->nth == 0 || ns < 2) {
+        uint32_t s;
+        for (s = 0; s < ns; s++) fn(arg, s);
+        return;
+    }
+    pthread_mutex_lock(&pl->mu);
+    pl->fn = fn; pl->arg = arg; pl->ns = ns;
+    pl->done = 0;
+    __atomic_store_n(&pl->next, 0u, __ATOMIC_RELEASE);   /* a worker still leaving the previous job may pick up this one's items */
+    pl->gen++;
+    pthread_cond_broadcast(&pl->cv_work);
+    pthread_mutex_unlock(&pl->mu);
+    pool_drain(pl);
+    pthread_mutex_lock(&pl->mu);
+    while (pl->done != pl->ns) pthread_cond_wait(&pl->cv_done, &pl->mu);
+    pthread_mutex_unlock(&pl->mu);
+}
 
 static int hit_cmp(const void *a, const void *b)
 {
@@ -278,10 +367,51 @@ static int hit_cmp(const void *a, const void *b)
 }
 
 /* tally one chunk against every strain: one upload, one launch per strain (they overlap on the device),
- * then the per-record tallies and per-record lists of informative rows, in window order */
-static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
+ * then -- strain by strain on the pool -- the per-record tallies and per-record lists of informative rows, in
+ * window order */
+typedef struct { sd_prog *p; sk_batch *batch; sd_chunk *c; } sd_tally_job;
+
+static void tally_one(void *arg, uint32_t s)
 {
-    uint32_t s, r, k;
+    sd_tally_job *j = (sd_tally_job *)arg;
+    sd_prog *p = &j->p[s];
+    sd_chunk *c = j->c;
+    uint64_t nh = 0, h = 0;
+    uint32_t *tally, n = 0, r, k;
+    int rc;
+    p->job_rc = SK_OK;
+    c->hits[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
+    c->inf[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
+    c->hbeg[s] = (uint32_t *)calloc((size_t)c->nrec + 2, sizeof(uint32_t));
+    if (c->np == 0) return;
+    if (p->tallycap < c->np) {
+        p->tallycap = c->np + c->np / 4 + 1024;
+        p->tallybuf = (uint32_t *)realloc(p->tallybuf, (size_t)p->tallycap * 8);
+    }
+    tally = p->tallybuf;
+    if ((rc = sk_tally_collect(p->ctx, tally, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
+    if (nh > p->hitcap) {                                 /* the log overflowed: once more with room */
+        p->hitcap = nh + nh / 4;
+        p->hitbuf = (sk_hit *)realloc(p->hitbuf, (size_t)p->hitcap * sizeof(sk_hit));
+        if ((rc = sk_tally_launch(p->ctx, j->batch, SD_TYPE, SD_INFORMATIVE, p->hitcap)) != SK_OK ||
+            (rc = sk_tally_collect(p->ctx, tally, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
+    }
+    qsort(p->hitbuf, (size_t)nh, sizeof(sk_hit), hit_cmp);
+    c->rows[s] = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
+    for (k = 0, r = 0; k < c->np; k++) {
+        const uint32_t rec = c->prec[k], end = k + 1 < c->np ? c->pstart[k + 1] : 0xFFFFFFFFu;
+        for (; r <= rec; r++) c->hbeg[s][r] = n;          /* records without a piece own an empty range */
+        c->hits[s][rec] = tally[2 * k];
+        c->inf[s][rec] = tally[2 * k + 1];
+        while (h < nh && p->hitbuf[h].pos < end) c->rows[s][n++] = p->hitbuf[h++].row;
+    }
+    for (; r <= c->nrec; r++) c->hbeg[s][r] = n;
+}
+
+static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, sd_chunk *c)
+{
+    sd_tally_job job;
+    uint32_t s;
     int rc;
     double t0 = now_s(), t1;
     c->nstrains = ns;
@@ -289,54 +419,25 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
     c->inf = (uint32_t **)calloc(ns, sizeof *c->inf);
     c->hbeg = (uint32_t **)calloc(ns, sizeof *c->hbeg);
     c->rows = (uint32_t **)calloc(ns, sizeof *c->rows);
-    for (s = 0; s < ns; s++) {
-        c->hits[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
-        c->inf[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
-        c->hbeg[s] = (uint32_t *)calloc((size_t)c->nrec + 2, sizeof(uint32_t));
-    }
-    if (c->np == 0) return SK_OK;
-    t1 = now_s(); t_alloc += t1 - t0; t0 = t1;
-    if ((rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
-    t1 = now_s(); t_fill += t1 - t0; t0 = t1;
-    for (s = 0; s < ns; s++) {
-        if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
-        if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
-    }
-    t1 = now_s(); t_launch += t1 - t0; t0 = t1;
-    for (s = 0; s < ns; s++) {
-        uint64_t nh = 0, h = 0;
-        uint32_t *tally, n = 0;
-        if (p[s].tallycap < c->np) {
-            p[s].tallycap = c->np + c->np / 4 + 1024;
-            p[s].tallybuf = (uint32_t *)realloc(p[s].tallybuf, (size_t)p[s].tallycap * 8);
-        }
-        tally = p[s].tallybuf;
-        if ((rc = sk_tally_collect(p[s].ctx, tally, p[s].hitbuf, &nh)) != SK_OK) return rc;
-        if (nh > p[s].hitcap) {                           /* the log overflowed: once more with room */
-            p[s].hitcap = nh + nh / 4;
-            p[s].hitbuf = (sk_hit *)realloc(p[s].hitbuf, (size_t)p[s].hitcap * sizeof(sk_hit));
+    if (c->np) {
+        if ((rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
+        t1 = now_s(); t_fill += t1 - t0; t0 = t1;
+        for (s = 0; s < ns; s++) {
+            if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
             if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
-            if ((rc = sk_tally_collect(p[s].ctx, tally, p[s].hitbuf, &nh)) != SK_OK) return rc;
         }
-        t1 = now_s(); t_collect += t1 - t0; t0 = t1;
-        qsort(p[s].hitbuf, (size_t)nh, sizeof(sk_hit), hit_cmp);
-        c->rows[s] = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
-        for (k = 0, r = 0; k < c->np; k++) {
-            const uint32_t rec = c->prec[k], end = k + 1 < c->np ? c->pstart[k + 1] : 0xFFFFFFFFu;
-            for (; r <= rec; r++) c->hbeg[s][r] = n;      /* records without a piece own an empty range */
-            c->hits[s][rec] = tally[2 * k];
-            c->inf[s][rec] = tally[2 * k + 1];
-            while (h < nh && p[s].hitbuf[h].pos < end) c->rows[s][n++] = p[s].hitbuf[h++].row;
-        }
-        for (; r <= c->nrec; r++) c->hbeg[s][r] = n;
-        t1 = now_s(); t_post += t1 - t0; t0 = t1;
+        t1 = now_s(); t_launch += t1 - t0; t0 = t1;
     }
+    job.p = p; job.batch = batch; job.c = c;
+    pool_run(pool, ns, tally_one, &job);
+    t_post += now_s() - t0;
+    for (s = 0; s < ns; s++) if (p[s].job_rc != SK_OK) return p[s].job_rc;
     return SK_OK;
 }
 
 /* make sure the stream's current chunk has an unread record: 1 = st->c->...[st->ci] is it, 0 = end of
  * file (end_kind, end_len set), < 0 device error */
-static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch)
+static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool)
 {
     for (;;) {
         sd_chunk *c;
@@ -361,7 +462,7 @@ static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch)
         pthread_mutex_unlock(&st->mu);
         {
             const double t0 = now_s();
-            rc = sd_tally_chunk(p, ns, batch, c);
+            rc = sd_tally_chunk(p, ns, batch, pool, c);
             t_tally += now_s() - t0;
         }
         if (rc != SK_OK) { chunk_free(c); return rc; }
@@ -464,97 +565,22 @@ static void sd_replay_run(sd_prog *p, uint32_t s, const char *f1, const sd_chunk
     *have_copy_io = have_copy;
 }
 
-/* The strains are independent once a run's tallies are in: with several strains, sd_replay_run (and with
- * it the gz compression of each strain's own output) is spread over a few threads, strain by strain. */
-typedef struct {
-    pthread_t th[16]; int nth;
-    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
-    unsigned long gen; int quit;
-    sd_prog *p; uint32_t ns; const char *f1; const sd_chunk *ca, *cb; uint32_t a0, b0, astep, n; int have_copy_in, have_copy_out;
-    uint32_t next, done;
-} sd_pool;
-
-static void pool_drain(sd_pool *pl)
-{
-    uint32_t mine = 0;
-    int hc = pl->have_copy_in;
-    for (;;) {
-        const uint32_t s = __atomic_fetch_add(&pl->next, 1u, __ATOMIC_ACQ_REL);   /* pairs with the release store that opens a job */
-        if (s >= pl->ns) break;
-        hc = pl->have_copy_in;
-        sd_replay_run(&pl->p[s], s, pl->f1, pl->ca, pl->a0, pl->cb, pl->b0, pl->astep, pl->n, &hc);
-        mine++;
-    }
-    pthread_mutex_lock(&pl->mu);
-    if (mine) pl->have_copy_out = hc;
-    pl->done += mine;
-    if (pl->done == pl->ns) pthread_cond_broadcast(&pl->cv_done);
-    pthread_mutex_unlock(&pl->mu);
-}
-
-static void *pool_worker_sd(void *arg)
-{
-    sd_pool *pl = (sd_pool *)arg;
-    unsigned long seen = 0;
-    for (;;) {
-        pthread_mutex_lock(&pl->mu);
-        while (pl->gen == seen && !pl->quit) pthread_cond_wait(&pl->cv_work, &pl->mu);
-        if (pl->quit) { pthread_mutex_unlock(&pl->mu); return NULL; }
-        seen = pl->gen;
-        pthread_mutex_unlock(&pl->mu);
-        pool_drain(pl);
-    }
-}
-
-static void pool_start(sd_pool *pl, uint32_t ns)
-{
-    int want = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : 8, i;
-    memset(pl, 0, sizeof *pl);
-    if (want > 16) want = 16;
-    if ((uint32_t)want > ns) want = (int)ns;
-    pthread_mutex_init(&pl->mu, NULL);
-    pthread_cond_init(&pl->cv_work, NULL);
-    pthread_cond_init(&pl->cv_done, NULL);
-    for (i = 0; i + 1 < want; i++)                       /* the calling thread is one of the workers */
-        if (pthread_create(&pl->th[pl->nth], NULL, pool_worker_sd, pl) == 0) pl->nth++;
-}
-
-static void pool_stop(sd_pool *pl)
-{
-    int i;
-    pthread_mutex_lock(&pl->mu);
-    pl->quit = 1;
-    pthread_cond_broadcast(&pl->cv_work);
-    pthread_mutex_unlock(&pl->mu);
-    for (i = 0; i < pl->nth; i++) pthread_join(pl->th[i], NULL);
-    pthread_mutex_destroy(&pl->mu);
-    pthread_cond_destroy(&pl->cv_work);
-    pthread_cond_destroy(&pl->cv_done);
-}
-
 /* replay one run for every strain; returns the (strain-independent) have_copy afterwards */
+typedef struct { sd_prog *p; const char *f1; const sd_chunk *ca, *cb; uint32_t a0, b0, astep, n; int have_copy; } sd_replay_job;
+static void replay_one(void *arg, uint32_t s)
+{
+    sd_replay_job *j = (sd_replay_job *)arg;
+    int hc = j->have_copy;
+    sd_replay_run(&j->p[s], s, j->f1, j->ca, j->a0, j->cb, j->b0, j->astep, j->n, &hc);
+    j->p[s].hc_out = hc;
+}
 static int pool_replay(sd_pool *pl, sd_prog *p, uint32_t ns, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb,
                        uint32_t b0, uint32_t astep, uint32_t n, int have_copy)
 {
-    if (pl->nth == 0 || n < 2) {
-        uint32_t s;
-        int hc = have_copy;
-        for (s = 0; s < ns; s++) { hc = have_copy; sd_replay_run(&p[s], s, f1, ca, a0, cb, b0, astep, n, &hc); }
-        return hc;
-    }
-    pthread_mutex_lock(&pl->mu);
-    pl->p = p; pl->ns = ns; pl->f1 = f1; pl->ca = ca; pl->cb = cb; pl->a0 = a0; pl->b0 = b0; pl->astep = astep; pl->n = n;
-    pl->have_copy_in = pl->have_copy_out = have_copy;
-    pl->done = 0;
-    __atomic_store_n(&pl->next, 0u, __ATOMIC_RELEASE);   /* a worker still leaving the previous job may pick up this one's strains */
-    pl->gen++;
-    pthread_cond_broadcast(&pl->cv_work);
-    pthread_mutex_unlock(&pl->mu);
-    pool_drain(pl);
-    pthread_mutex_lock(&pl->mu);
-    while (pl->done != pl->ns) pthread_cond_wait(&pl->cv_done, &pl->mu);
-    pthread_mutex_unlock(&pl->mu);
-    return pl->have_copy_out;
+    sd_replay_job j;
+    j.p = p; j.f1 = f1; j.ca = ca; j.cb = cb; j.a0 = a0; j.b0 = b0; j.astep = astep; j.n = n; j.have_copy = have_copy;
+    pool_run(n < 2 ? NULL : pl, ns, replay_one, &j);
+    return ns ? p[0].hc_out : have_copy;
 }
 
 /* one metagenome (pair), for every strain at once.  The read lengths -- hence which read refreshes which
@@ -580,13 +606,13 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
     }
     for (s = 0; s < ns; s++) { p[s].h1 = p[s].i1 = p[s].h2 = p[s].i2 = 0; p[s].copy_n = 0; }
 
-    while ((got = stream_fill(&A, p, ns, batch)) == 1) {
+    while ((got = stream_fill(&A, p, ns, batch, pool)) == 1) {
         sd_chunk *ca = A.c, *cb = NULL, *held = NULL;
         uint32_t a0 = A.ci, b0 = 0, n = ca->nrec - a0, astep = 1;
         int mate_missing = 0;
         uint64_t stale_len2 = 0;
         if (mode == SD_PE) {
-            got = stream_fill(&B, p, ns, batch);
+            got = stream_fill(&B, p, ns, batch, pool);
             if (got < 0) break;
             if (got == 1) { cb = B.c; b0 = B.ci; if (cb->nrec - b0 < n) n = cb->nrec - b0; }
             else { mate_missing = 1; stale_len2 = B.end_kind == SKP_END_RESET ? 0 : B.end_len; }   /* PE2 is exhausted for good */
@@ -594,7 +620,7 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
             if (n >= 2) { cb = ca; b0 = a0 + 1; astep = 2; n /= 2; }
             else {                                       /* the mate is the first record of the next chunk, or missing */
                 held = stream_steal(&A);
-                got = stream_fill(&A, p, ns, batch);
+                got = stream_fill(&A, p, ns, batch, pool);
                 if (got < 0) { chunk_free(held); break; }
                 if (got == 1) { cb = A.c; b0 = A.ci; }
                 else { mate_missing = 1; stale_len2 = A.end_kind == SKP_END_RESET ? 0 : A.end_len; }
@@ -894,6 +920,8 @@ static void sd_strain_close(sd_prog *p)
     memset(p, 0, sizeof *p);
 }
 
+static void close_one(void *arg, uint32_t s) { sd_strain_close(&((sd_prog *)arg)[s]); }
+
 /* the metagenome side of main (src/strain_detect.c:263-384), for ns strains at once */
 static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const char *b2, int mode, FILE *out, FILE *err)
 {
@@ -1092,11 +1120,19 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
     status = 0;
 done:
     if (getenv("SK_SD_TIMING"))
-        fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (arrays %.2f, upload %.2f, "
-                     "launch %.2f, collect %.2f, sort+spread %.2f), total before close %.2f s\n", t_setup, t_wait, t_tally, t_alloc, t_fill,
-                t_launch, t_collect, t_post, now_s() - t_begin);
+        fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (upload %.2f, launch %.2f, "
+                     "collect+sort+spread per strain on the pool %.2f), total before close %.2f s\n", t_setup, t_wait, t_tally, t_fill,
+                t_launch, t_post, now_s() - t_begin);
     sd_pin_close();
-    for (s = 0; s < ns; s++) sd_strain_close(&p[s]);
+    {   /* closing a strain = finishing its gz output, freeing its device context and tables: strain by strain on threads */
+        sd_pool cp;
+        const double t0 = now_s();
+        pool_start(&cp, ns);
+        pool_run(&cp, ns, close_one, p);
+        pool_stop(&cp);
+        t_close = now_s() - t0;
+        if (getenv("SK_SD_TIMING")) fprintf(err, "strain_detect timing: closing the strains %.2f s\n", t_close);
+    }
     skzo_pool_stop(&zpool);
     sd_zpool = NULL;
     for (s = 0; paths && s < 4 * ns; s++) free(paths[s]);
