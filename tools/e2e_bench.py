@@ -45,6 +45,7 @@ for kind in KINDS:
                 f.write(body)
         else:
             open(p, "wb").write(body)
+        print(f"  wrote {p} ({time.time() - t0:.0f} s)", flush=True)
     open(os.path.join(work, f"B_{kind}.txt"), "w").write("\n".join(names) + "\n")
 open(os.path.join(work, "A.txt"), "w").write(os.path.join(work, "strain.fa") + "\n")
 print(f"inputs ready in {time.time() - t0:.1f} s: {NFILES} x {READS} reads per format", flush=True)
@@ -60,3 +61,30 @@ for kind in KINDS:
         dt = time.time() - t
         print(f"{kind:6s} SK_THREADS={threads:2d}: {dt:6.2f} s wall for {bases / 1e9:.2f} Gbase in -B  "
               f"=> {bases / dt / 1e9:.3f} Gbase/s end to end (includes strain build, table print)", flush=True)
+
+# REPEAT=N: the .gz list N times over in one -B (cfg 3 at full size without N times the disk space), and the
+# size-independent parity property that goes with it: every metagenome_count must be N x the one-pass count
+REPEAT = int(os.environ.get("REPEAT", "0"))
+if REPEAT > 1:
+    import pandas as pd
+    kind = KINDS[-1]
+    names = open(os.path.join(work, f"B_{kind}.txt")).read().split()
+    open(os.path.join(work, "B_repeat.txt"), "w").write("\n".join(names * REPEAT) + "\n")
+    env = dict(os.environ, SK_THREADS=os.environ.get("THREADS", "16").split(",")[-1])
+    outs = []
+    for lst, label in ((f"B_{kind}.txt", "one pass"), ("B_repeat.txt", f"{REPEAT} passes")):
+        out = os.path.join(work, "counts_" + label.split()[0] + ".tsv")
+        t = time.time()
+        with open(out, "wb") as f:
+            subprocess.run([exe, "-r", os.path.join(work, "strain.fa"), "-A", os.path.join(work, "A.txt"), "-B", os.path.join(work, lst)],
+                           stdout=f, check=True, env=env)
+        dt = time.time() - t
+        n = bases * (REPEAT if lst == "B_repeat.txt" else 1)
+        print(f"{label:10s} of the {kind} list, SK_THREADS={env['SK_THREADS']}: {dt:6.2f} s wall for {n / 1e9:.1f} Gbase => {n / dt / 1e9:.2f} Gbase/s end to end", flush=True)
+        outs.append(pd.read_csv(out, sep="\t"))
+    a, b = outs
+    same_keys = (a["#kmer"] == b["#kmer"]).all() and (a["reference_count"] == b["reference_count"]).all() and (a["pangenome_count"] == b["pangenome_count"]).all()
+    linear = (b["metagenome_count"] == REPEAT * a["metagenome_count"]).all()
+    print(f"rows {len(a)}, hits in one pass {int(a['metagenome_count'].sum())}; same rows/other columns: {bool(same_keys)}; "
+          f"metagenome_count of {REPEAT} passes == {REPEAT} x one pass in every row: {bool(linear)}", flush=True)
+    assert same_keys and linear
