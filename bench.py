@@ -39,13 +39,26 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
+def host_cpus():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota where there is one
+    (the GPU boxes show 256 CPUs and grant 16 CPUs' worth of time), at most 64"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(sstream, reads, read_len, target_seconds=12.0):
     """The oracle ("port": same string-keyed work per window as the reference) timed on this host's
     cores on a bounded sample of the same reads.  P forked workers share one built table."""
     global _ORACLE_TABLE
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import _oracle
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cores = host_cpus()
     t = _oracle.OracleTable()
     tb = time.perf_counter()
     assert t.build_stream(sstream) == 0
@@ -86,7 +99,7 @@ def cpu_baseline_reference(contigs, reads, read_len, reads_per_core=300_000):
     exe = os.path.join(REPO, "oracle", "_ref", "kmer_scrub_count")
     if not os.access(exe, os.X_OK):
         return None
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cores = host_cpus()
     rec = read_len + 1
     per = int(min(reads_per_core, (reads.size // rec) // cores))
     work = tempfile.mkdtemp(prefix="sk_cpu_ref_")

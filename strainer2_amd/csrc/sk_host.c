@@ -33,6 +33,7 @@
 #include "sk_parser.h"
 #include "sk_ctxjob.h"
 #include "sk_gzpipe.h"
+#include "sk_cpus.h"
 
 /* tables of tens of MB that are touched at random: 2 MiB-aligned and offered to transparent huge pages
  * (fewer page faults while they are filled, fewer TLB misses while they are probed) */
@@ -597,7 +598,7 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases)
 
 /* ---- list walk: files are decoded by a small pool of host threads (gz inflate + record parsing is
  * the slow part of the whole program), batches are submitted to the one device context under a lock.
- * SK_THREADS sets the pool size (default: min(16, online CPUs); 1 = the reference's strict sequence). */
+ * SK_THREADS sets the pool size (default: min(16, usable CPUs, sk_cpus.h); 1 = the reference's strict sequence). */
 typedef struct {
     sk_ctx         *ctx;
     uint32_t        col;
@@ -728,7 +729,7 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     pthread_mutex_init(&pool.submit_mu, NULL);
     pthread_mutex_init(&pool.queue_mu, NULL);
     if (env) nthreads = atoi(env);
-    else { long n = sysconf(_SC_NPROCESSORS_ONLN); nthreads = n > 16 ? 16 : (int)n; }
+    else { long n = sk_cpu_budget(); nthreads = n > 16 ? 16 : (int)n; }
     if (nthreads < 1) nthreads = 1;
 
     /* the reference logs "<line>\t<time>" before it scans each file (src/genome_compare.c:167-170);
@@ -762,7 +763,7 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     {   /* with fewer files than half the cores, a file's inflate and its record parsing take a core each; with
          * fewer still, the threads left over inflate inside the files (a speculative segment costs about twice a
          * serial one, so it takes three threads per file to be worth it).  SK_GZ_THREADS sets the number per file. */
-        const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        const long ncpu = sk_cpu_budget();
         const char *gzt = getenv("SK_GZ_THREADS");
         pool.pipe = nthreads > 1 && (long)pool.npath * 2 <= ncpu;
         if (pool.pipe && pool.npath && nthreads / (int)pool.npath >= 3) pool.pipe = nthreads / (int)pool.npath;

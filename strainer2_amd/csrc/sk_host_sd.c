@@ -30,6 +30,7 @@
 #include "sk_internal.h"
 #include "sk_ctxjob.h"
 #include "sk_gzpipe.h"
+#include "sk_cpus.h"
 #include "sk_gzout.h"
 
 
@@ -220,11 +221,11 @@ static void *sd_decode_thread(void *arg)
 }
 
 /* how many threads may inflate each of the `nfiles` files read at the same time: SK_GZ_THREADS, or the host
- * thread budget (SK_THREADS, default min(16, online CPUs)) shared out -- used when it leaves three or more per
+ * thread budget (SK_THREADS, default min(16, usable CPUs)) shared out -- used when it leaves three or more per
  * file, below that the one helper thread of sk_gzpipe.h does as well */
 static int sd_gz_threads(int nfiles)
 {
-    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    const long ncpu = sk_cpu_budget();
     const int budget = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : (int)(ncpu < 1 ? 1 : ncpu > 16 ? 16 : ncpu);
     int per = budget / nfiles;
     if (getenv("SK_GZ_THREADS")) per = atoi(getenv("SK_GZ_THREADS"));
@@ -1033,7 +1034,7 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
     if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
     t_begin = now_s();
     {
-        const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        const long ncpu = sk_cpu_budget();
         skzo_pool_start(&zpool, getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : (int)(ncpu > 16 ? 16 : ncpu < 1 ? 1 : ncpu));
         sd_zpool = &zpool;
     }
@@ -1065,8 +1066,8 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
         fclose(fp);
         {   /* the strains are opened by worker threads, each strain start to finish on
              * one of them; their messages are replayed here in list order, up to the first failure
-             * (SK_THREADS, default: the online CPUs, at most 16) */
-            long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+             * (SK_THREADS, default: the usable CPUs, at most 16) */
+            long ncpu = sk_cpu_budget();
             int nth = getenv("SK_THREADS") ? atoi(getenv("SK_THREADS")) : (int)(ncpu < 1 ? 1 : ncpu > 16 ? 16 : ncpu), t;
             ks_pool kp;
             pthread_t th[16];
