@@ -11,6 +11,8 @@ import pytest
 
 import _oracle
 import _synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import strainer2_amd as sk
 from strainer2_amd import native
 
@@ -106,6 +108,56 @@ def test_reader_matches_oracle_records(golden):
         assert got == want, path
         assert got_nrec == nrec, path
         assert bases == len(data) - nrec, path
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_reader_grammar_soup_vs_oracle(seed, tmp_path):
+    """files thrown together from header, sequence, '+', quality and blank lines in every order -- equal and unequal
+    quality lengths, wrapped sequences, CR line ends, '@' and '>' opening quality lines, a missing last newline,
+    plain and gzipped, also cut short -- must give the records the oracle's reader gives (which is pinned to the
+    reference's kseq by test_oracle_golden.py).  Covers the parser's whole-record shortcut next to its general path."""
+    import gzip
+    rng = random.Random(9000 + seed)
+    nl = rng.choice([b"\n", b"\n", b"\r\n"])
+    strain = _synth.rand_dna(rng, 3000)
+    out = []
+    for _ in range(rng.randrange(1, 400)):
+        kind = rng.random()
+        n = rng.choice([0, 1, 2, 30, 31, 40, 150, 151])
+        a = rng.randrange(0, len(strain) - n)
+        seq = strain[a:a + n]                              # (pieces of the strain: which bytes count as sequence shows in the table)
+        if kind < 0.55:                                    # a well-formed four-line record (now and then not quite)
+            q = bytes(rng.choice(b"FFFF:,#@>+I") for _ in range(n if rng.random() < 0.9 else rng.choice([0, 1, max(0, n - 1), n + 1])))
+            out += [b"@r%d some text" % len(out), seq, b"+" + (b"r" if rng.random() < 0.2 else b""), q]
+        elif kind < 0.7:                                   # FASTA, wrapped
+            out += [b">c%d" % len(out)] + [seq[i:i + 60] for i in range(0, n, 60)]
+        elif kind < 0.8:                                   # FASTQ with wrapped sequence and quality
+            q = b"I" * n
+            out += [b"@w%d" % len(out)] + [seq[i:i + 50] for i in range(0, n, 50)] + [b"+"] + [q[i:i + 70] for i in range(0, n, 70)]
+        else:                                              # loose lines
+            out.append(rng.choice([b"", b"+", b"@", b">", b"\r", seq, b"@" + seq, b"+" + seq, b" ", b"\t@x"]))
+    text = nl.join(out) + (nl if rng.random() < 0.8 else b"")
+    if rng.random() < 0.3:
+        text = text[:rng.randrange(len(text) + 1)]
+    f = tmp_path / ("soup.fq.gz" if seed % 2 else "soup.fq")
+    f.write_bytes(gzip.compress(text, 6, mtime=0) if seed % 2 else text)
+    data, nrec, _st = _oracle.decode_file(str(f))
+    want = [r for r in data.split(b"\n")[:-1] if len(r) >= 31]
+    for chunk_bytes in (1 << 20, 4096):
+        chunks, got_nrec, bases = sk.decode_file(str(f), chunk_bytes=chunk_bytes)
+        got = b"".join(chunks).split(b"\n")[:-1]
+        if chunk_bytes == 1 << 20:
+            assert got == want, seed
+        assert got_nrec == nrec and bases == len(data) - nrec, seed
+    # and the oracle's reader against the reference's own on the same soup, through the two programs
+    ref, orc = os.path.join(REPO, "oracle", "_ref", "kmer_scrub_count"), os.path.join(REPO, "oracle", "kso_oracle")
+    if os.path.exists(ref) and os.path.exists(orc):
+        (tmp_path / "strain.fa").write_bytes(b">s\n" + strain + b"\n")
+        (tmp_path / "A.txt").write_text(str(f) + "\n")
+        argv = ["-r", str(tmp_path / "strain.fa"), "-A", str(tmp_path / "A.txt")]
+        a, b = (subprocess.run([exe] + argv, capture_output=True, timeout=60) for exe in (ref, orc))
+        assert (a.returncode, a.stdout) == (b.returncode, b.stdout), seed
+        assert int(sum(int(line.split(b"\t")[2]) for line in a.stdout.splitlines()[1:])) >= 0
 
 
 def test_reader_cuts_long_records_with_overlap(tmp_path):
