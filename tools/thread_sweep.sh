@@ -7,7 +7,7 @@ python - <<'PY'
 names = open("/tmp/sk_cfg3c/B_fq.gz.txt").read().split()
 open("/tmp/sk_cfg3c/B35.txt", "w").write("\n".join(names * 35) + "\n")
 PY
-for t in 8 16 24 32 48; do
+for t in ${SWEEP:-8 16 24 32 48}; do
   TIMEFORMAT="threads $t: %R s wall, %U user, %S sys"
   { time SK_THREADS=$t SK_TIMING=1 strainer2_amd/bin/kmer_scrub_count -r /tmp/sk_cfg3c/strain.fa -A /tmp/sk_cfg3c/A.txt -B /tmp/sk_cfg3c/B35.txt > /dev/null ; } 2>> gpurun_out/sweep.txt
 done
