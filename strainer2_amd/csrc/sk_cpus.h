@@ -1,9 +1,11 @@
 /* sk_cpus.h -- how many CPUs the host layer may count on: the online CPUs, cut down to the cgroup's CPU quota
  * where there is one (a container on a 256-CPU host may be granted 16 CPUs' worth of time; threads beyond that
- * only take turns). */
+ * only take turns), shared out among the processes of a one-process-per-GPU start on this node
+ * (LOCAL_WORLD_SIZE, as torchrun sets it, or OMPI_COMM_WORLD_LOCAL_SIZE). */
 #ifndef SK_CPUS_H
 #define SK_CPUS_H
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -20,6 +22,11 @@ static long sk_cpu_budget(void)
             if (share < n) n = share;
         }
         fclose(f);
+    }
+    {
+        const char *lw = getenv("LOCAL_WORLD_SIZE") ? getenv("LOCAL_WORLD_SIZE") : getenv("OMPI_COMM_WORLD_LOCAL_SIZE");
+        const long ranks = lw ? atol(lw) : 1;
+        if (ranks > 1) n = n / ranks < 1 ? 1 : n / ranks;
     }
     return n;
 }

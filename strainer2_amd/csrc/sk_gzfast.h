@@ -33,8 +33,12 @@
 enum { SKZ_OK = 0, SKZ_OPEN = -1, SKZ_NOT_GZIP = 1, SKZ_CORRUPT = 2, SKZ_STOPPED = 3 };
 typedef int (*skz_sink)(void *user, const unsigned char *data, size_t n);
 
+#ifndef SKZ_LITLEN_BITS
 #define SKZ_LITLEN_BITS 11
+#endif
+#ifndef SKZ_DIST_BITS
 #define SKZ_DIST_BITS   8
+#endif
 #define SKZ_WINDOW      32768u
 #define SKZ_OUT_CHUNK   (4u << 20)
 
