@@ -495,6 +495,9 @@ static int skz_block(skz_stream *s, const skz_tables *t)
     uint64_t bitbuf = s->bitbuf;
     unsigned bitcnt = s->bitcnt;
     unsigned char *out = s->out;
+    unsigned char *const out_base = s->out_base;            /* (locals: byte stores through `out` may alias every field of *s) */
+    const unsigned char *out_lim = s->out_end - (6 + 2 * 258 + 16);
+    const unsigned char *const in_fast = in_end - 16;       /* up to here a 64-bit refill stays inside the input */
     int rc;
 #define SKZ_SAVE()    do { s->in = in; s->bitbuf = bitbuf; s->bitcnt = bitcnt; s->out = out; } while (0)
 #define SKZ_LOAD()    do { out = s->out; } while (0)
@@ -504,12 +507,12 @@ static int skz_block(skz_stream *s, const skz_tables *t)
     int pre = 0;                                            /* enext = the entry after a match, looked up before its copy */
     for (;;) {
         uint32_t e;
-        if ((size_t)(s->out_end - out) < 6 + 2 * 258 + 16) {
+        if (out > out_lim) {
             SKZ_SAVE();
             if (skz_flush(s, 1)) return 1;
             SKZ_LOAD();
         }
-        if (pre || in_end - in >= 16) {                     /* (signed: `in` may already be past the end) */
+        if (pre || in <= in_fast) {
             if (pre) { e = enext; pre = 0; }
             else {
                 SKZ_FILL_FAST();
@@ -528,7 +531,7 @@ static int skz_block(skz_stream *s, const skz_tables *t)
                         continue;
                     }
                 }
-                if (in_end - in < 8) goto tail;             /* (after a preloaded entry the 16-byte margin may be gone) */
+                if (in > in_fast + 8) goto tail;            /* (after a preloaded entry the 16-byte margin may be gone) */
                 SKZ_FILL_FAST();                            /* (the low bits, hence e, are unchanged) */
             }
         } else {
@@ -560,8 +563,8 @@ tail:       /* within 16 bytes of the end of the input: real bits only from here
                 const uint32_t db = (d >> 8) & 255u;                             /* <= 13: 48 of the 56 bits at most */
                 dist = (d >> 16) + (uint32_t)(bitbuf & (((uint64_t)1 << db) - 1u)); bitbuf >>= db; bitcnt -= db;
             }
-            if (dist > (size_t)(out - s->out_base)) { rc = -1; break; }          /* before the start of the data */
-            if (in_end - in >= 16) {                        /* look the next entry up now: its latency hides behind the copy */
+            if (dist > (size_t)(out - out_base)) { rc = -1; break; }             /* before the start of the data */
+            if (in <= in_fast) {                            /* look the next entry up now: its latency hides behind the copy */
                 SKZ_FILL_FAST();
                 enext = lt[bitbuf & ((1u << SKZ_LITLEN_BITS) - 1u)];
                 pre = 1;
