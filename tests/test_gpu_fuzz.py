@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # SK_FUZZ_EXTRA=N: N more seeds per test on top of the ones that always run (a longer hunt, run by hand)
 EXTRA = int(os.environ.get("SK_FUZZ_EXTRA", "0"))
+BASE = int(os.environ.get("SK_FUZZ_BASE", "1000"))        # first seed of the extra worlds
 
 
 def world(seed):
@@ -45,7 +46,7 @@ def world(seed):
     return sstream, data
 
 
-@pytest.mark.parametrize("seed", list(range(36)) + list(range(1000, 1000 + EXTRA)))
+@pytest.mark.parametrize("seed", list(range(36)) + list(range(BASE, BASE + EXTRA)))
 def test_scan_count_fuzz(seed):
     sstream, data = world(seed)
     ks = sk.Keyset.from_stream(sstream)
@@ -69,7 +70,7 @@ def test_scan_count_fuzz(seed):
             assert np.array_equal(c.counts(col), ocounts[:, col]), (seed, col)
 
 
-@pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(5000, 5000 + EXTRA // 3)))
+@pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(4 * BASE + 1000, 4 * BASE + 1000 + EXTRA // 3)))
 def test_tally_fuzz(seed):
     """per-read tallies and the log of informative hits against counts derived from the oracle's scan of each
     read on its own"""
