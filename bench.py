@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (cfg 2: 10 M)")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--strain-bp", type=int, default=5_000_000, help="size of the synthetic strain (cfg 2: 5 Mbp); other sizes are for sweeps, not for `value`")
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of reads drawn from the strain (cfg 2: 0.02)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--bloom-bits-log2", type=int, default=None)
@@ -166,7 +167,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     from strainer2_amd import synth
-    contigs = synth.make_strain()
+    contigs = synth.make_strain(total_bp=args.strain_bp)
     sstream = synth.strain_stream(contigs)
     reads, nbases = synth.make_reads(contigs, args.reads, args.read_len, hit_frac=args.hit_frac, seed=synth.SEED + 1 + rank)
 

@@ -124,7 +124,10 @@ SK_HD uint32_t sk_minimizer62(uint64_t key)
  * clumps of ~8 per minimizer and linear-probe runs get long: 3.7x slower end to end.) */
 SK_HD uint32_t sk_slot0(uint32_t kh, uint32_t mask)
 {
-    return (kh >> 8) & mask;
+    /* bits 8..31 of the hash, and -- for tables of more than 2^24 slots (strains beyond ~8 M keys) -- its low byte on
+     * top of them: with 24 bits alone every key of a bigger table starts in the first 2^24 slots, and a 20 M-key strain
+     * (more keys than home slots) turned linear probing into a walk of millions of slots per key */
+    return ((kh >> 8) | (kh << 24)) & mask;
 }
 
 /* FNV-1a over the 31 bytes of a wide key */

@@ -431,3 +431,35 @@ def test_rccl_allreduce_on_the_counter_block_single_rank(repo):
     p = subprocess.run([sys.executable, os.path.join(repo, "tools", "nccl_single_rank_check.py")], cwd=repo,
                        capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT=str(port)))
     assert p.returncode == 0 and b"all-reduce on the library's counter block: ok" in p.stdout, p.stderr.decode()[-800:]
+
+
+def test_strain_with_more_keys_than_2_pow_24():
+    """A 20 Mbp strain: 20 M keys, 2^26 table slots.  (The home slot once took 24 bits of the hash: every key of such a
+    table started in the first 2^24 slots and the table load never finished.)  No oracle at this size -- the check is
+    exact all the same: reads cut out of the strain give 120 hits each, one per window, each on its own row with the
+    strain's own count; random reads give none."""
+    import time
+    rng = np.random.default_rng(2024)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    strain = acgt[rng.integers(0, 4, 20_000_000)]
+    t = time.time()
+    ks = sk.Keyset.from_stream(strain.tobytes() + b"\n")
+    assert ks.nrows > (1 << 24)
+    n = 20_000
+    starts = rng.integers(0, len(strain) - 150, n)
+    reads = strain[starts[:, None] + np.arange(150)[None, :]]
+    flip = rng.random(n) < 0.5
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    reads[flip] = comp[reads[flip]][:, ::-1]
+    noise = acgt[rng.integers(0, 4, (n, 150))]
+    stream = b"".join(r.tobytes() + b"\n" for r in np.concatenate([reads, noise]))
+    with sk.KmerContext(0) as c:
+        c.load_keyset(ks, 4)
+        assert time.time() - t < 120
+        c.scan_stream(stream, 2)
+        counts = c.counts(2)
+    assert int(counts.sum()) == 120 * n
+    # every window of read 0 (forward strand copy of the strain at starts[0]) is counted at least once
+    keys = ks.keys()
+    assert len(keys) == ks.nrows
