@@ -1319,11 +1319,14 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
                                d_in, nrows, (uint32_t *)c->d_bloom, 32u - blocks_log2);
             c->bloom_blocks_log2 = blocks_log2;
         }
-        {   // grid filters.  Level 1 is meant to stay in the L2 (4 MiB per XCD, shared with everything else):
-            // ~5 bits per key, capped at 3 MiB (measured: a 4 MiB filter only hits 60 % of the time).
+        {   // grid filters.  Level 1: ~5 bits per key -- 3 MiB for a 5 Mbp strain, which stays in the L2 (4 MiB per XCD,
+            // shared with everything else).  For bigger strains it is better to keep the 5 bits per key and leave the L2
+            // than to keep the size and let the filter fill up (tools/grid_size_sweep.sh, 20 Mbp strain: 3 MiB 540,
+            // 6 MiB 731, 12 MiB 850, 24 MiB 815 Gbase/s; 100 Mbp: 3 MiB 192, 64 MiB 465): misses of a sparse level 1
+            // are served by the 256 MB Infinity Cache, the level-2 lookups a full one lets through are not.
             // Level 2 settles what level 1 lets through: >= 32 bits per key, false positives ~1e-5.
             uint64_t kib = c->grid_kib > 0 ? (uint64_t)c->grid_kib : ((uint64_t)nrows * 5ull / 8ull + 1023ull) / 1024ull;
-            if (c->grid_kib <= 0 && kib > 3072ull) kib = 3072ull;
+            if (kib > (1ull << 22)) kib = 1ull << 22;
             if (kib < 4ull) kib = 4ull;
             c->grid1_blocks = (uint32_t)(kib * 1024ull / sizeof(uint2));
             uint32_t g2 = 12;
