@@ -16,7 +16,7 @@ NFILES = int(os.environ.get("NFILES", "16"))
 READS = int(os.environ.get("READS", "500000"))
 work = os.environ.get("WORK", "/tmp/sk_e2e")
 os.makedirs(work, exist_ok=True)
-contigs = synth.make_strain()
+contigs = synth.make_strain(total_bp=int(os.environ.get("STRAIN_BP", "5000000")))
 open(os.path.join(work, "strain.fa"), "wb").write(synth.strain_fasta(contigs))
 qual = b"I" * 150
 # QUAL=binned: quality strings drawn per base from four binned values (as current Illumina machines write them)

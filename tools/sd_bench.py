@@ -17,7 +17,7 @@ import strainer2_amd as sk  # noqa: E402
 READS = int(os.environ.get("READS", "4000000"))
 work = os.environ.get("WORK", "/tmp/sk_sd")
 os.makedirs(work, exist_ok=True)
-contigs = synth.make_strain()
+contigs = synth.make_strain(total_bp=int(os.environ.get("STRAIN_BP", "5000000")))
 open(os.path.join(work, "strain.fa"), "wb").write(synth.strain_fasta(contigs))
 ks = sk.Keyset.from_stream(synth.strain_stream(contigs))
 keys = ks.keys()
