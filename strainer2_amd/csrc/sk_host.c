@@ -808,6 +808,8 @@ static char *put_i32(char *p, int32_t v)             /* "%d" of an unsigned coun
     return p;
 }
 
+static int cmp_u64(const void *a, const void *b) { const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
+
 int skh_print_counts(sk_ctx *ctx, const skh_keyset *ks, FILE *out, int with_drug_column)
 {
     const uint32_t ncols = with_drug_column ? 4 : 3, n = ks->nrows;
@@ -821,12 +823,14 @@ int skh_print_counts(sk_ctx *ctx, const skh_keyset *ks, FILE *out, int with_drug
         cols[c] = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
         rc = sk_counts_fetch(ctx, c, cols[c]);
     }
-    /* wide keys in ascending row order (there are few of them) */
+    /* wide keys in ascending row order (an IUPAC-riddled strain has hundreds of thousands: sort, not insert) */
     worder = (uint32_t *)malloc((size_t)(ks->nwide ? ks->nwide : 1) * sizeof(uint32_t));
-    for (c = 0; c < ks->nwide; c++) {
-        uint32_t j = c;
-        while (j > 0 && ks->wide_rows[worder[j - 1]] > ks->wide_rows[c]) { worder[j] = worder[j - 1]; j--; }
-        worder[j] = c;
+    {
+        uint64_t *pair = (uint64_t *)malloc((size_t)(ks->nwide ? ks->nwide : 1) * sizeof(uint64_t));
+        for (c = 0; c < ks->nwide; c++) pair[c] = ((uint64_t)ks->wide_rows[c] << 32) | c;
+        qsort(pair, ks->nwide, sizeof *pair, cmp_u64);
+        for (c = 0; c < ks->nwide; c++) worder[c] = (uint32_t)pair[c];
+        free(pair);
     }
     if (rc == SK_OK) {
         buf = (char *)malloc(BUF + 256);
