@@ -35,6 +35,7 @@ reads[rng.random(nr) < 0.5] = acgt[rng.integers(0, 4, 150)]              # half 
 reads = sprinkle(reads, 1 / 600)
 for name, sel in (("g.fa", slice(0, 10_000)), ("m_1.fa", slice(10_000, 25_000)), ("m_2.fa", slice(25_000, 40_000))):
     open(f"{w}/{name}", "wb").write(b"".join(b">r%d\n%s\n" % (j, reads[j].tobytes()) for j in range(sel.start, sel.stop)))
+open(f"{w}/il.fa", "wb").write(b"".join(b">r%d\n%s\n>q%d\n%s\n" % (j, reads[10_000 + j].tobytes(), j, reads[25_000 + j].tobytes()) for j in range(15_000)))
 open(f"{w}/A.txt", "w").write(f"{w}/g.fa\n")
 open(f"{w}/B.txt", "w").write(f"{w}/m_1.fa\n{w}/m_2.fa\n")
 bad = 0
@@ -50,7 +51,7 @@ bad += not same
 # informative k-mers: every 7th row, byte-string keys included
 inf = [r.split(b"\t")[0] for r in rows[1::7]]
 open(f"{w}/inf.txt", "wb").write(b"#kmer\n" + b"\n".join(inf) + b"\n")
-for mode, files in (("PE", ["-b", f"{w}/m_1.fa", "-c", f"{w}/m_2.fa"]), ("SE", ["-b", f"{w}/m_1.fa"])):
+for mode, files in (("PE", ["-b", f"{w}/m_1.fa", "-c", f"{w}/m_2.fa"]), ("SE", ["-b", f"{w}/m_1.fa"]), ("PEI", ["-b", f"{w}/il.fa"])):
     outs = []
     for exe, tag in ((os.path.join(B, "strain_detect"), "gpu"), (os.path.join(O, "ksd_oracle"), "oracle")):
         o = f"{w}/s_m_{tag}{mode}.kmer_hits.gz"

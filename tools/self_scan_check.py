@@ -19,7 +19,8 @@ os.makedirs(w, exist_ok=True)
 rng = np.random.default_rng(99)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 bad = 0
-for name, contig, enn, iupac, lower in (("contigs of 100 kb", 100_000, 0, 0, 0), ("contigs of 100", 100, 0, 0, 0), ("contigs of 31", 31, 0, 0, 0),
+shapes = [("IUPAC letters every ~%d bases" % round(1 / float(os.environ["IUPAC_RATE"])), 50_000, 0, float(os.environ["IUPAC_RATE"]), 0)] if os.environ.get("IUPAC_RATE") else None
+for name, contig, enn, iupac, lower in shapes or (("contigs of 100 kb", 100_000, 0, 0, 0), ("contigs of 100", 100, 0, 0, 0), ("contigs of 31", 31, 0, 0, 0),
                                         ("contigs of 33..45", -1, 0, 0, 0), ("an N every ~150 bases", 50_000, 1 / 150, 0, 0),
                                         ("IUPAC letters every ~500 bases", 50_000, 0, 1 / 500, 0), ("lower case, N and IUPAC", 20_000, 1 / 2000, 1 / 2000, 1)):
     seq = acgt[rng.integers(0, 4, bp)]
