@@ -33,9 +33,14 @@ starts = rng.integers(0, n - 150, nr)
 reads = strain[starts[:, None] + np.arange(150)[None, :]].copy()
 reads[rng.random(nr) < 0.5] = acgt[rng.integers(0, 4, 150)]              # half of them not from the strain
 reads = sprinkle(reads, 1 / 600)
+# SHORT=1: a third of the reads cut to 5..60 bases -- reads shorter than k re-use (and re-emit) the tallies of the read before
+lens = np.full(nr, 150)
+if os.environ.get("SHORT"):
+    cut = rng.random(nr) < 0.33
+    lens[cut] = rng.integers(5, 61, int(cut.sum()))
 for name, sel in (("g.fa", slice(0, 10_000)), ("m_1.fa", slice(10_000, 25_000)), ("m_2.fa", slice(25_000, 40_000))):
-    open(f"{w}/{name}", "wb").write(b"".join(b">r%d\n%s\n" % (j, reads[j].tobytes()) for j in range(sel.start, sel.stop)))
-open(f"{w}/il.fa", "wb").write(b"".join(b">r%d\n%s\n>q%d\n%s\n" % (j, reads[10_000 + j].tobytes(), j, reads[25_000 + j].tobytes()) for j in range(15_000)))
+    open(f"{w}/{name}", "wb").write(b"".join(b">r%d\n%s\n" % (j, reads[j, :lens[j]].tobytes()) for j in range(sel.start, sel.stop)))
+open(f"{w}/il.fa", "wb").write(b"".join(b">r%d\n%s\n>q%d\n%s\n" % (j, reads[10_000 + j, :lens[10_000 + j]].tobytes(), j, reads[25_000 + j, :lens[25_000 + j]].tobytes()) for j in range(15_000)))
 open(f"{w}/A.txt", "w").write(f"{w}/g.fa\n")
 open(f"{w}/B.txt", "w").write(f"{w}/m_1.fa\n{w}/m_2.fa\n")
 bad = 0
