@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 B, O = os.path.join(REPO, "strainer2_amd", "bin"), os.path.join(REPO, "oracle")
 w = "/tmp/sk_iupac"
 os.makedirs(w, exist_ok=True)

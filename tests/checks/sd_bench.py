@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from strainer2_amd import synth  # noqa: E402
 import strainer2_amd as sk  # noqa: E402

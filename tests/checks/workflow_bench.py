@@ -15,7 +15,7 @@ import sys
 import tempfile
 import time
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 B = os.path.join(REPO, "tests", "golden", "bundled")
 BIN = os.path.join(REPO, "strainer2_amd", "bin")
 ORA = os.path.join(REPO, "oracle")
