@@ -198,3 +198,26 @@ def test_context_fails_loudly_without_gpu():
     with pytest.raises(sk.SKError) as e:
         sk.KmerContext(0)
     assert e.value.code == native.SK_E_NODEVICE
+
+
+def test_cpu_budget_follows_quota_and_local_ranks(tmp_path):
+    """sk_cpus.h: the default thread budget is the online CPUs cut down to the cgroup quota, shared out among the
+    processes of a one-process-per-GPU start"""
+    src = tmp_path / "b.c"
+    src.write_text('#include "%s"\nint main(void) { printf("%%ld\\n", sk_cpu_budget()); return 0; }\n'
+                   % os.path.join(REPO, "strainer2_amd", "csrc", "sk_cpus.h"))
+    exe = str(tmp_path / "b")
+    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", str(src), "-o", exe], check=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE")}
+    alone = int(subprocess.run([exe], env=env, capture_output=True, check=True).stdout)
+    want = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            want = min(want, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    assert 1 <= alone <= os.cpu_count() and alone == min(os.cpu_count(), want) or alone == os.cpu_count()
+    shared = int(subprocess.run([exe], env=dict(env, LOCAL_WORLD_SIZE="4"), capture_output=True, check=True).stdout)
+    assert shared == max(1, alone // 4)
+    assert int(subprocess.run([exe], env=dict(env, OMPI_COMM_WORLD_LOCAL_SIZE="1000"), capture_output=True, check=True).stdout) == 1
