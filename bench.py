@@ -4,10 +4,24 @@
 Metric (BASELINE.json): metagenome bases/sec scanned at k=31, bit-exact k-mer counts.
 Workload at every N (weak scaling): BASELINE configs[1] per GPU -- one 5 Mbp synthetic strain
 (-r) resident as the key table, 10 M x 150 bp synthetic reads (-B; 1.5 Gbase, SURVEY 8(d)
-recipe, seed 0x5EED31 + rank) resident in HBM as a record stream.  A "step" = one pass of the
-scan over that batch (sk_scan_device -> sk_scan_main [+ sk_scan_wide early-exit]).  After the
+recipe, seed 0x5EED31 + 1 + rank) resident in HBM as a record stream.  A "step" = one pass of the
+scan over that batch (sk_scan_device -> sk_scan_grid [+ sk_scan_wide early-exit]).  After the
 K timed steps the per-k-mer count vector of the scanned (-B) column is summed across ranks with one
 RCCL all-reduce (inside the timed region when N > 1).  value = bases all ranks scanned / max-over-ranks time.
+
+Bit-exactness is checked in the run that is timed: the counts of the K timed passes, divided by K, must be
+the vector the UNMODIFIED reference program produced for the same stream (tests/golden/cfg2_facts.json:
+sum, non-zero rows and md5 of the u32 column in the reference's row order, made by
+tests/golden/make_cfg2_facts.py); for N > 1 the reduced total must be the sum of the ranks' facts and every
+rank's own stream is checked once more by one untimed pass.
+
+roofline: bound = HBM.  achieved = COMPULSORY bytes per launch / average kernel time, where compulsory =
+the record stream read once (bases + separators) + 8 B per hit (the u32 counter's read-modify-write);
+frac = achieved / 8 TB/s.  SURVEY 8(d)'s model figure (7.4 B/base: one 8-byte probe per window) is carried
+beside it as `survey_model_*`: this kernel answers 16 windows with one filter block and never moves those
+bytes, so that figure is not a fraction of anything.  traffic = measured HBM bytes per launch from the PMC
+passes of tools/profile.sh, taken from profiles/traffic.json ONLY if that file was measured on this very
+sk_device.hip (sha256 stamp), else null.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu]
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -24,7 +38,11 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-ALG_BYTES_PER_BASE = 7.4          # 1 B base + 8 B key probe x 0.8 windows/base (p_hit -> 0)
+import hashlib
+
+SURVEY_MODEL_BYTES_PER_BASE = 7.4     # 1 B base + 8 B key probe x 0.8 windows/base (a model of a per-window-probe
+                                      # algorithm; reported as a side field only)
+HIT_BYTES = 8.0                       # u32 counter read-modify-write per hit
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -140,6 +158,41 @@ def cpu_baseline_reference(contigs, reads, read_len, reads_per_core=300_000):
                       f"({bases / 1e6:.0f} Mbase): {full:.1f} s wall, {how}; {bases / scan_s / cores / 1e6:.2f} Mbase/s per core"}
 
 
+# ----------------------------------------------------------------------------- facts and measured traffic
+def load_cfg2_facts(args):
+    """the committed facts of the reference's run on the cfg-2 stream, if this run IS cfg 2"""
+    p = os.path.join(REPO, "tests", "golden", "cfg2_facts.json")
+    if not os.path.exists(p) or args.strain_bp != 5_000_000 or args.hit_frac != 0.02:
+        return None
+    f = json.load(open(p))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if f.get("reads") != args.reads or f.get("read_len") != args.read_len or len(f.get("ranks", [])) < world:
+        return None
+    return f
+
+
+def device_source_sha():
+    with open(os.path.join(REPO, "strainer2_amd", "csrc", "sk_device.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def measured_traffic(args, kernel_name):
+    """HBM bytes per launch from the PMC passes (tools/profile.sh -> tools/save_profile.py), only if they were
+    taken on this very kernel source and workload; (None, why) otherwise"""
+    tp = os.path.join(REPO, "profiles", "traffic.json")
+    if not os.path.exists(tp):
+        return None, "no profiles/traffic.json"
+    try:
+        tj = json.load(open(tp))
+    except Exception as e:                                   # noqa: BLE001
+        return None, f"unreadable profiles/traffic.json ({e})"
+    if tj.get("reads") != args.reads or tj.get("kernel") != kernel_name:
+        return None, "profiles/traffic.json is for another workload/kernel"
+    if tj.get("sk_device_hip_sha256") != device_source_sha():
+        return None, "profiles/traffic.json was measured on another version of sk_device.hip (stale): re-run tools/profile.sh"
+    return tj.get("hbm_bytes_per_launch"), tj.get("correction")
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -151,13 +204,11 @@ def main():
     ap.add_argument("--strain-bp", type=int, default=5_000_000, help="size of the synthetic strain (cfg 2: 5 Mbp); other sizes are for sweeps, not for `value`")
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of reads drawn from the strain (cfg 2: 0.02)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--bloom-bits-log2", type=int, default=None)
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive host-buffer passes (keeps profiles clean)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--grid-kib", type=int, default=None, help="size of the grid kernel's level-1 filter in KiB (default: automatic)")
-    ap.add_argument("--kernel", type=int, default=None, help="0 = grid kernel (default), 1 = minimizer kernel (previous generation)")
+    ap.add_argument("--text-stage", type=int, default=None, help="0 = stage 2 without the strain's text (A/B)")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments: 1 = no filter/table memory, 2 = no table probes (counts are wrong)")
-    ap.add_argument("--stats", action="store_true", help="debug counters (slower kernel variant)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -197,14 +248,10 @@ def main():
 
     ks = sk.Keyset.from_stream(sstream)
     ctx = sk.KmerContext(device)
-    if args.bloom_bits_log2 is not None:
-        ctx.set_option("bloom_bits_log2", args.bloom_bits_log2)
     if args.grid_kib is not None:
         ctx.set_option("grid_kib", args.grid_kib)
-    if args.kernel is not None:
-        ctx.set_option("kernel", args.kernel)
-    if args.stats:
-        ctx.set_option("stats", 1)
+    if args.text_stage is not None:
+        ctx.set_option("text_stage", args.text_stage)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
     ctx.load_keyset(ks, 4)
@@ -242,9 +289,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # bit-exactness inside the same run: K passes over one batch => counts == K x one pass (and,
-    # for N > 1 after the all-reduce, the sum over ranks); one pass is checked against the oracle
-    # in tests/ and smoke().  Here: every count is a multiple of K and the total is sane.
+    # bit-exactness inside the same run: the K timed passes' counts / K must be the reference program's vector
+    # for this very stream (tests/golden/cfg2_facts.json); for N > 1 the reduced total must be the ranks' sum
     counts = ctx.counts(2)
     if world > 1:                                   # every rank must hold the same reduced table
         chk = torch.tensor([int(counts.astype(np.uint64).sum())], dtype=torch.int64, device="cuda")
@@ -253,12 +299,33 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert int(lo.item()) == int(hi.item()), "ranks disagree after the all-reduce"
     assert args.ablate or (int(counts.sum()) % args.steps == 0 and np.all(counts % args.steps == 0)), "counts not K x one pass"
-    hits_per_pass = int(counts.sum()) // args.steps
+    hits_per_pass = int(counts.astype(np.uint64).sum()) // args.steps
+    parity = {"facts": None, "checked": False}
+    facts = load_cfg2_facts(args)
+    if facts is not None and not args.ablate:
+        def fact_of(vec):
+            return {"sum": int(vec.astype(np.uint64).sum()), "nonzero_rows": int(np.count_nonzero(vec)),
+                    "md5_u32_le": hashlib.md5(vec.astype("<u4").tobytes()).hexdigest()}
+        if world == 1:
+            got, want = fact_of(counts // args.steps), facts["ranks"][0]
+            assert all(got[k] == want[k] for k in got), f"timed run differs from the reference: {got} vs {want}"
+        else:
+            want_sum = sum(f["sum"] for f in facts["ranks"][:world])
+            assert hits_per_pass == want_sum, f"reduced total {hits_per_pass} != the ranks' reference sum {want_sum}"
+            ctx.zero_counts(3)
+            ctx.scan_device(dev, nbytes, 3)                     # one untimed pass of this rank's own stream
+            got, want = fact_of(ctx.counts(3)), facts["ranks"][rank]
+            ok = torch.tensor([int(all(got[k] == want[k] for k in got))], dtype=torch.int64, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            assert int(ok.item()) == 1, f"a rank's pass differs from the reference (rank {rank}: {got} vs {want})"
+        parity = {"facts": "tests/golden/cfg2_facts.json", "checked": True, "producer": facts.get("producer"),
+                  "what": "counts of the timed passes / steps == the reference's metagenome_count column (sum, non-zero rows, md5)"
+                          if world == 1 else "reduced total == sum of the ranks' reference sums; every rank's own stream re-scanned once and md5-checked"}
 
     # PCIe-inclusive rate (host buffer -> pinned staging -> H2D -> scan), reported beside `value`,
     # never as it: 2 passes of sk_scan_stream over the same record stream
     host_rate = pinned_rate = None
-    if world == 1 and not args.ablate and not args.stats and not args.no_host_rate:
+    if world == 1 and not args.ablate and not args.no_host_rate:
         ctx.scan_stream(reads[: 64 << 20], 3)
         ctx.sync()
         t1 = time.perf_counter()
@@ -280,29 +347,15 @@ def main():
         pinned_rate = 2 * nbases / (time.perf_counter() - t1)
         ctx.pinned_free(pin)
 
-    if args.stats and rank == 0:
-        st = ctx.scan_stats()
-        n = args.steps + args.warmup
-        print("stats per pass:", {k: v / n for k, v in st.items()}, file=sys.stderr)
     if rank == 0:
         total_bases = nbases * args.steps * world
         value = total_bases / elapsed
         avg_ms = kern_ms / max(launches, 1)
-        achieved = ALG_BYTES_PER_BASE * nbases / (avg_ms * 1e-3) / 1e9
-        kernel_name = "sk_scan_main" if args.kernel == 1 else "sk_scan_grid"
-        # what THIS kernel has to move at the least: every base once, plus (grid kernel) one 8-byte filter
-        # block per 16-base chunk; the 7.4 B/base of SURVEY 8(d) assumes one 8-byte probe per window,
-        # which the grid kernel does not perform -- `frac` can therefore exceed 1
-        floor_bpb = 1.0 + (0.5 if args.kernel != 1 else 0.0)
-        traffic = None
-        tp = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                if tj.get("reads") == args.reads and tj.get("kernel") == kernel_name:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        hits_rank0 = hits_per_pass if world == 1 else (facts["ranks"][0]["sum"] if facts else hits_per_pass // world)
+        compulsory = float(nbytes) + HIT_BYTES * hits_rank0          # bytes one launch MUST move: stream once + counter RMW per hit
+        achieved = compulsory / (avg_ms * 1e-3) / 1e9
+        kernel_name = "sk_scan_grid"
+        traffic, traffic_note = measured_traffic(args, kernel_name)
         line = {
             "metric": "metagenome bases/sec scanned at k=31", "value": value, "unit": "bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -316,15 +369,16 @@ def main():
                        "pcie_inclusive_bases_per_s_host_buffers": host_rate,
                        "pcie_inclusive_bases_per_s_pinned_buffers": pinned_rate,
                        "sharding": "reads sharded by rank, table replicated, one RCCL all-reduce of counts" if world > 1 else "single GPU"},
+            "parity": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kernel_name, "avg_launch_ms": avg_ms, "launches": int(launches),
-                         "alg_bytes_per_base": ALG_BYTES_PER_BASE,
-                         "kernel_floor_bytes_per_base": floor_bpb,
-                         "frac_of_hbm_peak_at_kernel_floor": floor_bpb * nbases / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "achieved/frac use SURVEY 8(d)'s 7.4 B/base (1 B base + one 8 B probe per window); the grid "
-                                 "kernel replaces the per-window probe by one filter block per 16-base chunk, so frac > 1 "
-                                 "means it beats that algorithm's HBM bound; see DESIGN.md section 5"},
+                         "compulsory_bytes_per_launch": compulsory,
+                         "compulsory": "record stream read once (%d B incl. separators) + %g B x %d hits" % (nbytes, HIT_BYTES, hits_rank0),
+                         "survey_model_bytes_per_base": SURVEY_MODEL_BYTES_PER_BASE,
+                         "survey_model_gbs": SURVEY_MODEL_BYTES_PER_BASE * nbases / (avg_ms * 1e-3) / 1e9,
+                         "note": "frac = compulsory bytes / kernel time / 8 TB/s.  survey_model_* is SURVEY 8(d)'s 7.4 B/base "
+                                 "(one 8 B probe per window), a model of a different algorithm kept for continuity only"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

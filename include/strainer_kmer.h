@@ -90,6 +90,19 @@ int sk_table_load(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t nc
  * every rank that loaded the same key set. */
 int sk_table_load_ex(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t ncols, const uint32_t *locality);
 
+/* Strain text for the scan's "seed and verify" stage (optional; after sk_table_load_ex).  text2 = the
+ * strain's bases as the build phase read them, 2 bits each in the code of the keys, 16 bases per word with
+ * the first base in the most significant position, records laid end to end, nbases in all (bytes that are
+ * not A/C/G/T take any code).  first_pos[r] = text position of the first base of an all-ACGT window whose
+ * canonical form is row r's key, or UINT32_MAX for rows without one (wide keys; keys that only occur
+ * through a U).  Contract on the locality order given to sk_table_load_ex: the rows WITH a position come
+ * first, in ascending position order (then the counter index of such a row is the rank of its position, which
+ * the device recomputes from a bit per text position).  With the text resident, a window that hit the table
+ * tells where the read lies on the strain; its neighbours are then compared with the strain's text at the
+ * expected places (a 62-bit compare each, as exact as a table probe) instead of being probed one by one.
+ * Replaces nothing in the reference: BIO_searchHash per window (src/BIO_hash.c:161-172) stays the meaning. */
+int sk_table_load_text(sk_ctx *ctx, const uint32_t *text2, uint32_t nbases, const uint32_t *first_pos);
+
 /* Wide keys: rows whose 31-byte upper-cased oriented key contains bytes other than ACGT
  * (IUPAC letters in the strain: SURVEY 8(a) a3/a6).  keys31 = nwide * 32 bytes, each key
  * 31 bytes + NUL; rows[i] = row index of key i. */
@@ -167,15 +180,12 @@ int  sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);
  * around every scan kernel since the last reset: total milliseconds and launch count. */
 int sk_scan_timing(sk_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
 
-/* Tunables (before sk_table_load).  name: "bloom_bits_log2" (size of the prefilter in bits,
- * log2; -1 = automatic, 0 = no prefilter), "table_load_pct" (max load factor in percent),
- * "stats" (1 = count windows / prefilter loads / table probes, see sk_scan_stats), "ablate"
- * (timing experiments only: kernel variants that skip memory stages and give WRONG counts).
+/* Tunables (before sk_table_load).  name: "table_load_pct" (max load factor in percent), "grid_kib" (size of
+ * the level-1 filter in KiB, -1 = automatic), "text_stage" (0 = stage 2 probes every window on its own even
+ * when the strain's text is resident; for A/B runs and tests), "odd_list_cap" (tests), "ablate" (timing
+ * experiments only: kernel variants that skip memory stages and give WRONG counts).
  * Unknown name -> SK_E_ARG. */
 int sk_set_option(sk_ctx *ctx, const char *name, long value);
-/* Debug counters of the scan kernel since the last table load (needs option "stats"=1):
- * out[0] windows looked up, out[1] prefilter block loads, out[2] table probes. */
-int sk_scan_stats(sk_ctx *ctx, uint64_t out[3]);
 
 /* Device buffer helpers so that FFI callers need no HIP binding of their own. */
 int sk_dev_alloc(sk_ctx *ctx, void **dev, uint64_t nbytes);
@@ -197,6 +207,9 @@ typedef struct skh_keyset {
     uint32_t *wide_rows;    /* [nwide]                                                          */
     uint32_t  final_slots;  /* M of the replayed reference table                                */
     uint64_t  short_records;/* records skipped because shorter than k-1 (reference crashes)     */
+    uint32_t *text2;        /* the strain's bases, 2 bits each (sk_table_load_text)             */
+    uint32_t  text_bases;   /* how many                                                         */
+    uint32_t *first_pos;    /* [nrows] text position of the row's first all-ACGT occurrence, or UINT32_MAX */
 } skh_keyset;
 
 /* Build phase.  Reads a FASTA/FASTQ(.gz) strain file with the reference parser's grammar

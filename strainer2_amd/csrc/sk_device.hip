@@ -1,25 +1,27 @@
 // sk_device.hip -- device layer of libstrainer_kmer.so: hand-written HIP for CDNA4 / gfx950.
 //
-// Kernels (all integer/byte work; bound by VALU issue and random-access rate, no MFMA):
-//   sk_scan_main      THE hot kernel (replaces reference src/genome_compare.c:213-229 +
+// Kernels (all integer/byte work; bound by L2 request rate and random-access rate, no MFMA):
+//   sk_scan_grid      THE hot kernel (replaces reference src/genome_compare.c:213-229 +
 //                     src/BIO_hash.c:161-172; in TALLY mode src/strain_detect.c:471-485):
 //                       phase 1  bytes -> 2-bit code words + "not ACGT" masks in LDS (SWAR)
-//                       phase 2  per thread: 16-mers by v_alignbit, sliding-minimum minimizer,
-//                                live masks by bit tricks, runs of windows sharing a minimizer
-//                       stage 1  one L2 filter lookup per run, 64 runs at a time, pipelined
-//                       stage 2  windows of passing runs rebuilt from LDS (62-bit canonical key),
-//                                probed 64 at a time in the HBM table; atomicAdd on a hit
+//                       phase 2  one filter lookup per aligned 16-base chunk (a 31-base window holds exactly one)
+//                       stage 2  the windows of the surviving chunks: a few of them (anchors) are probed in the
+//                                HBM table; a hit tells where the read lies on the strain, and the other windows
+//                                are compared with the strain's 2-bit text there (seed and verify: 62-bit
+//                                compares, as exact as a probe); atomicAdd on the row counter on a hit
 //   sk_scan_wide      exact byte-string path for the rare windows that contain bytes other than
 //                     ACGT (U / IUPAC / junk): the reference's signed-char orientation compare
 //                     through its COMPLEMENT map.  Early exit unless phase 1 saw such a byte.
 //   sk_table_insert   open-addressed key table (atomicCAS on the key word)
-//   sk_bloom_insert   minimizer filter (both strands of every key)
+//   sk_grid_insert    the two filter levels (canonical 16-mers of every key)
 //   sk_gather/scatter counters <-> caller row order
 //
 // Data layout in HBM:
-//   slots  [S]  16 B  {u64 key, u32 counter index, u32 pad}: open addressing, linear probing,
-//                     S = 2^s >= 2 nrows, empty = key all ones (one random line per hit)
-//   filter      8 B   blocks of the minimizer Bloom set, 2^25 bits for a 5 Mbp strain (L2-resident)
+//   slots  [S]  16 B  {u64 key, u32 counter index, u32 text position << 1 | orientation}: open addressing,
+//                     linear probing, S = 2^s >= 2 nrows, empty = key all ones (one random line per hit)
+//   grid1/grid2 8 B   blocks of the Bloom sets of the strain's canonical 16-mers (level 1 sized for the L2)
+//   text2       u32   the strain's bases, 2 bits each, records end to end (1.25 MB for 5 Mbp)
+//   rank        16 B  per 64 text positions: {counter index of the first one, 64 "a row starts here" bits}
 //   counts [ncols][nrows] u32, in locality (first-occurrence) order: one read's hits are adjacent
 //   stream      u8    record stream: sequence bytes, records separated by '\n'
 //
@@ -57,31 +59,23 @@
 #define SK_AGG_LOG2     9
 #define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
-#ifndef SK_PUMP_EVERY
-#define SK_PUMP_EVERY   2                   // windows between two drain sites (power of two <= 16)
-#endif
-#define SK_EVQ          (64 + (SK_PUMP_EVERY + 1) * 64)   // minimizer-run events: below 64 after every drain site
 #ifndef SK_ANCHOR
 #define SK_ANCHOR       16u
 #endif
 //                 // stage 2: one hash probe per this many consecutive windows
-#define SK_WQ           (64 + 64)           // tile positions of windows waiting for their table probe
-#ifndef SK_BATCH
-#define SK_BATCH        2                   // x64 events per pipelined stage-1 batch
-#endif
 
 typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
 
 struct sk_table_view {
-    const sk_u4    *slots;           // {key lo, key hi, counter index, 1 if the key is strain text at its first occurrence}
+    const sk_u4    *slots;           // {key lo, key hi, counter index, text position << 1 | 1 if the key is strain text at its first occurrence}
     uint32_t        mask;
-    const uint64_t *keys_by_loc;     // the keys again, by counter index (strain order): neighbours of a hit
     uint32_t        nrows;
-    // L2-resident prefilter: a Bloom set of the MINIMIZER hashes that occur in the strain
-    // (about nrows/8 items).  64-bit blocks chosen by the low bits of the minimizer hash,
-    // two bits in each 32-bit half.
-    const uint2    *bloom;
-    uint32_t        bloom_shift;     // 32 - log2(number of 64-bit blocks)
+    // seed and verify: the strain's text (2 bits per base, 16 per word, first base on top) and, per 64 text
+    // positions, {counter index of the first row that starts in the block, bit p: a row's first all-ACGT
+    // occurrence starts at block + p, -}.  NULL: every window is probed on its own.
+    const uint32_t *text2;
+    const sk_u4    *rank;
+    uint32_t        text_bases;
     // grid kernel: Bloom sets of the canonical 16-mers of the strain, a small one for the L2 and a
     // large one that settles what the small one lets through
     const uint2    *grid1, *grid2;
@@ -204,15 +198,6 @@ __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t,
     }
 }
 
-// is minimizer hash `mz` (possibly) one of the strain's?  blk = its filter block
-__device__ __forceinline__ bool sk_filter_test(const uint2 blk, uint32_t mz)
-{
-    const uint32_t g = sk_filter_bits(mz);
-    const uint32_t t = (blk.x >> (g >> 27)) & (blk.x >> ((g >> 22) & 31u)) &
-                       (blk.y >> ((g >> 17) & 31u)) & (blk.y >> ((g >> 12) & 31u));
-    return (t & 1u) != 0u;
-}
-
 // ---- phase 1 helpers: 4 bytes at a time (SWAR) -------------------------------------------------
 // bit 7 of every byte of the result is set iff that byte of x is non-zero
 __device__ __forceinline__ uint32_t sk_nz_msb(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; }
@@ -253,8 +238,9 @@ __device__ __forceinline__ uint32_t sk_revcomp32(uint32_t x)              // 16 
     return ~y;
 }
 
-// canonical packed 31-mer of the window that ends at tile-relative position e, from the LDS records
-__device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_t e, bool &is_fwd)
+// both orientations of the window that ends at tile-relative position e, from the LDS records: packed 31-mers,
+// first base in bits 61..60; the canonical form is the larger (src/genome_compare.c:1100-1120)
+__device__ __forceinline__ void sk_window_keys(const uint32_t *rec, uint32_t e, uint64_t &fwd, uint64_t &rc)
 {
     const uint32_t b = e + SK_SPAN;                        // record 0 holds the 128 bases before the tile
     const uint32_t c = b >> 4, s = 2u * (15u - (b & 15u));
@@ -263,295 +249,36 @@ __device__ __forceinline__ uint64_t sk_window_canon(const uint32_t *rec, uint32_
     const uint32_t w2 = rec[((c - 2u) >> 3) * SK_REC_DW + ((c - 2u) & 7u)];
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, s);
     const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, s) & 0x3FFFFFFFu;
-    const uint64_t fwd = ((uint64_t)hi << 32) | lo;
+    fwd = ((uint64_t)hi << 32) | lo;
     uint64_t r = ((uint64_t)__builtin_bitreverse32(lo) << 32) | __builtin_bitreverse32(hi);
     r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
-    const uint64_t rc = (~r) >> 2;
-    is_fwd = fwd > rc;
-    return is_fwd ? fwd : rc;
+    rc = (~r) >> 2;
 }
 
-// THE hot kernel.  A workgroup owns SK_TILE consecutive window-end positions of the record stream.
-//
-//   phase 1  (cooperative, coalesced 16 B loads) every 16 stream bytes become one packed code
-//            word (2 bits/base) + a 16-bit "not ACGT" mask in LDS; bytes that are neither ACGT,
-//            N nor '\n' raise the batch's "needs the byte-string kernel" flag.
-//   phase 2  each thread walks its 128 positions in 16-base chunks, all in registers:
-//              16-mers        straight from two adjacent code words, one v_alignbit_b32 per base
-//              minimizer      sliding minimum of the (forward-strand) 16-mer hashes over the window
-//                             (prefix minima of this chunk + suffix minima of the previous one)
-//              live mask      "31 valid bases end here" for the 16 positions by bit tricks
-//              runs           maximal runs of live windows with one minimizer -> one EVENT each
-//   stage 1  events are queued per wave and judged 64 at a time: one 8 B load from the
-//            L2-resident filter "is this minimizer in the strain at all?".  Reads unrelated to
-//            the strain stop here (~1 % false positives).
-//   stage 2  windows of passing runs are rebuilt from LDS (full 62-bit canonical key), queued,
-//            and probed 64 at a time in the HBM table; atomicAdd on the row counter on a hit.
-template <bool FILTER, bool STATS, int ABLATE, bool TALLY>   // ABLATE (timing experiments only; wrong counts):
-__global__ __launch_bounds__(SK_THREADS)           // 1 = no filter/table memory at all, 2 = no table probes
-void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
-                  sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags)
+// the 31 bases of the strain's text that start at position q, packed like a key (q + 31 <= text_bases; the
+// text array has two spare words behind its last base)
+__device__ __forceinline__ uint64_t sk_text_key(const uint32_t *__restrict__ text2, uint32_t q)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t rec[SK_NREC * SK_REC_DW];
-    __shared__ uint2    evq_all[SK_WAVES][SK_EVQ];
-    __shared__ uint16_t wq_all[SK_WAVES][SK_WQ];
+    const uint32_t w = q >> 4, o2 = 2u * (q & 15u);
+    const uint32_t t0 = text2[w], t1 = text2[w + 1u], t2 = text2[w + 2u];
+    const uint64_t x = ((uint64_t)t0 << 32) | t1;
+    return ((x << o2) | ((uint64_t)t2 >> (32u - o2))) >> 2;
+}
 
-    const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // first window-end position
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
+__device__ __forceinline__ bool sk_grid_test(const uint2 blk, uint32_t bits)
+{
+    const uint32_t t = (blk.x >> (bits >> 27)) & (blk.x >> ((bits >> 22) & 31u)) &
+                       (blk.y >> ((bits >> 17) & 31u)) & (blk.y >> ((bits >> 12) & 31u));
+    return (t & 1u) != 0u;
+}
 
-    // ================= phase 1: bytes -> packed codes + invalid masks ==========================
-    uint32_t bad = 0;
-#pragma unroll
-    for (int it = 0; it < (SK_NCHUNK + SK_THREADS - 1) / SK_THREADS; it++) {
-        const uint32_t c = tid + (uint32_t)it * SK_THREADS;
-        if (c < SK_NCHUNK) {
-            const int64_t off = (int64_t)tile0 - SK_SPAN + (int64_t)c * 16;
-            sk_u4 v;
-            if (off >= 0 && (uint64_t)off + 16u <= nbytes) {
-                v = __builtin_nontemporal_load((const sk_u4 *)(stream + off));
-            } else {
-                uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};   // '\n' fill
-                for (int i = 0; i < 16; i++) {
-                    const int64_t p = off + i;
-                    if (p >= 0 && (uint64_t)p < nbytes)
-                        w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
-                }
-                v = (sk_u4){w[0], w[1], w[2], w[3]};
-            }
-            uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
-            sk_decode4(v.x, c0, i0);
-            sk_decode4(v.y, c1, i1);
-            sk_decode4(v.z, c2, i2);
-            sk_decode4(v.w, c3, i3);
-            const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
-            if (sk_chunk_has_odd_byte(v, inv16)) {
-                bad = 1;
-                if (c >= SK_SPAN_CH) {                                   // (the chunks before the tile are the previous tile's)
-                    const uint32_t at = atomicAdd(&flags[2], 1u);
-                    if (at < table.oddcap) table.oddlist[at] = (uint32_t)((uint64_t)off >> 4);
-                }
-            }
-            const uint32_t r = c >> 3, sl = c & 7u;
-            rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
-            ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
-        }
-    }
-    __syncthreads();
-
-    // ================= phase 2 ==================================================================
-    uint2    *const evq = evq_all[tid >> 6];
-    uint16_t *const wq  = wq_all[tid >> 6];
-    uint32_t qe = 0, qw = 0;                                      // queue fills (wave-uniform)
-    uint32_t n_live = 0, n_load = 0, n_probe = 0;                 // STATS only
-
-    // Stage 1 is software-pipelined: a batch of up to SK_BATCH*64 events has its filter blocks
-    // loaded (issue) and is judged one drain site later (complete), so the L2 latency hides
-    // behind the rolling work in between.
-    uint2    pev[SK_BATCH], pblk[SK_BATCH];
-    uint32_t pn = 0;                                              // events in the pending batch
-#pragma unroll
-    for (int b = 0; b < SK_BATCH; b++) { pev[b] = make_uint2(0u, 0u); pblk[b] = make_uint2(0u, 0u); }
-
-    // Stage 2 on the top n (<= 64) queued windows.  Queue entries of one read are consecutive tile
-    // positions, i.e. consecutive windows; if the strain contains them they are consecutive strain
-    // k-mers, whose keys sit next to each other in keys_by_loc.  So only every SK_ANCHOR-th window of
-    // such a stretch (and its first one) pays a random hash probe; the others first compare their
-    // key with the anchor's neighbour in strain order (one coalesced load) and fall back to the hash
-    // only when that fails (read error, repeated k-mer, contig end).  Every hit is a full 62-bit
-    // compare either way.
-    auto probe_some = [&](uint32_t n) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        qw -= n;
-        const bool act = lane < n;
-        const uint32_t e = act ? wq[qw + lane] : 0xFFFF0000u + lane * 2u;     // inactive: never consecutive
-        bool w_fwd = false;
-        const uint64_t cn = act ? sk_window_canon(rec, e, w_fwd) : 0ull;
-        const uint32_t pos = (uint32_t)tile0 + e;
-        if (ABLATE == 2) { __builtin_amdgcn_wave_barrier(); return; }
-        const uint32_t e_prev = (uint32_t)__shfl_up((int)e, 1);
-        const bool first = (lane == 0u) | (e != e_prev + 1u);                  // first window of a stretch
-        const unsigned long long fm = __ballot(first);
-        const uint32_t first_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
-        const uint32_t k = lane - first_lane;                                  // offset inside the stretch
-        const bool anchor = act & ((k & (SK_ANCHOR - 1u)) == 0u);
-        uint32_t hit = 0xFFFFFFFFu, a_dir = 0u;                                // counter index of this lane's hit
-        if (anchor) {
-            uint32_t is_text = 0u;
-            hit = sk_find(cn, table, &is_text);
-            a_dir = (uint32_t)w_fwd ^ is_text;                                 // 0: the read runs along the strain, 1: against it
-        }
-        const uint32_t my_anchor = lane - (k & (SK_ANCHOR - 1u));
-        const uint32_t n_idx = (uint32_t)__shfl((int)hit, (int)my_anchor);
-        const uint32_t n_dir = (uint32_t)__shfl((int)a_dir, (int)my_anchor);
-        if (act & !anchor) {
-            if (n_idx != 0xFFFFFFFFu && table.keys_by_loc) {
-                const uint32_t d = k & (SK_ANCHOR - 1u);
-                const uint32_t idx = n_dir ? n_idx - d : n_idx + d;            // wraps below 0 -> >= nrows
-                if (idx < table.nrows && table.keys_by_loc[idx] == cn) hit = idx;
-            }
-            if (hit == 0xFFFFFFFFu) { uint32_t unused; hit = sk_find(cn, table, &unused); }
-        }
-        // one atomic instruction for the whole batch: neighbouring counters coalesce
-        if (TALLY) sk_tally_wave(sink, act ? hit : 0xFFFFFFFFu, pos, lane);
-        else if (hit != 0xFFFFFFFFu) sk_on_hit<false, ABLATE == 3>(sink, hit, pos);
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto probe_batch = [&]() { probe_some(64u); };
-
-    auto complete = [&]() {                                       // judge the pending batch
-#pragma unroll
-        for (int b = 0; b < SK_BATCH; b++) {
-            const bool active = lane + 64u * (uint32_t)b < pn;
-            bool pass = false;
-            if (active) {
-                if (!FILTER) pass = pev[b].x != 0xFFFFFFFFu;
-                else if (ABLATE == 1) pass = pev[b].x == 0x12345u;
-                else pass = (pev[b].x != 0xFFFFFFFFu) && sk_filter_test(pblk[b], pev[b].x);
-            }
-            // passing runs (rare): one at a time, their windows' positions go to the wave's
-            // window queue, which stage 2 consumes 64 at a time with every lane busy
-            unsigned long long m = __ballot(pass);
-            while (m) {
-                const int l = __builtin_ctzll(m);
-                m &= m - 1ull;
-                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)pev[b].y, l);
-                const uint32_t len = (inf >> 15) + 1u, start = inf & 0x7FFFu;
-                for (uint32_t k = 0; k < len; k += 64u) {         // a run is at most one span (128) long
-                    const uint32_t n = len - k < 64u ? len - k : 64u;
-                    if (lane < n) wq[qw + lane] = (uint16_t)(start + k + lane);
-                    qw += n;
-                    if (STATS) n_probe += lane < n;
-                    if (qw >= 64u) probe_batch();
-                }
-            }
-        }
-        pn = 0;
-    };
-
-    auto issue = [&]() {                                          // start the next batch's filter loads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n = qe < 64u * SK_BATCH ? qe : 64u * SK_BATCH;
-        qe -= n;
-#pragma unroll
-        for (int b = 0; b < SK_BATCH; b++) {
-            if (lane + 64u * (uint32_t)b < n) {
-                pev[b] = evq[qe + lane + 64u * (uint32_t)b];
-                if (FILTER && ABLATE != 1 && pev[b].x != 0xFFFFFFFFu)
-                    pblk[b] = table.bloom[sk_filter_block(pev[b].x, table.bloom_shift) & (ABLATE == 4 ? 63u : 0xFFFFFFFFu)];
-                if (STATS) n_load += 1u;
-            }
-        }
-        pn = n;
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    // a drain site: judge what was issued at the previous site, issue what has queued up since
-    auto pump = [&]() {
-        do { complete(); issue(); } while (qe >= 64u);
-    };
-
-    // one event = one maximal run of windows that share a minimizer hash (0xFFFFFFFF: a dead
-    // stretch, judged "no" without a lookup): {mz, start | (len-1) << 15}.  With rel = chunk-relative
-    // offset of the run's first window (negative when it began in an earlier chunk) and o = offset of
-    // the first window after it, start = ebase + rel and len-1 = o-1-rel, so the info word is
-    // (ebase + ((o-1) << 15)) + rel * (1 - 2^15): the run state keeps rel pre-multiplied (`relx`).
-    auto push_event = [&](bool cond, uint32_t mz, uint32_t ebase, uint32_t relx, int o) {
-        const unsigned long long m = __ballot(cond);
-        if (m) {
-            if (cond)
-                evq[qe + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                    make_uint2(mz, ebase + (uint32_t)((o - 1) * 32768) + relx);
-            qe += (uint32_t)__popcll(m);
-        }
-    };
-#define SK_RELX(rel) ((uint32_t)((rel) * (1 - 32768)))
-
-    const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;           // this thread's record
-    const uint32_t *pv = rec + tid * SK_REC_DW;                   // the record before it
-    uint32_t cw_prev = pv[7];                                     // code word of the chunk before the span
-    uint32_t vlo = pv[11];                                        // invalid masks of the two chunks before
-    uint32_t S[17], H[16];
-    S[16] = 0xFFFFFFFFu;
-
-    // warm-up over chunk -1: hashes of the 16-mers that end in it, and their suffix minima
-    {
-        const uint32_t cw2 = pv[6];
-#pragma unroll
-        for (int o = 0; o < 16; o++)
-            H[o] = sk_mhash(o < 15 ? __builtin_amdgcn_alignbit(cw2, cw_prev, 30 - 2 * o) : cw_prev);
-        S[15] = H[15];
-#pragma unroll
-        for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
-    }
-
-    const uint64_t pos0 = tile0 + (uint64_t)tid * SK_SPAN;       // stream position of span window 0
-    uint32_t run_mz = 0xFFFFFFFFu;                                // minimizer hash of the current run
-    uint32_t run_relx = SK_RELX(0);                               // its first window, relative to the chunk (pre-multiplied)
-    const bool all_emit = tile0 >= emit_begin;                    // (wave-uniform) no position of this tile is masked
-
-#pragma unroll 1
-    for (uint32_t j = 0; j < SK_SPAN_CH; j++) {
-        const uint32_t cwj = my[j];
-        const uint32_t ipair = my[8u + (j >> 1)];
-        const uint32_t invj = (j & 1u) ? ipair >> 16 : ipair & 0xFFFFu;
-
-        // live mask: bit o <=> the 31 bases ending at chunk offset o are all ACGT
-        const uint64_t v = ~(((uint64_t)invj << 32) | vlo);       // valid bits: chunks j-2, j-1, j
-        vlo = (vlo >> 16) | (invj << 16);
-        uint64_t rr = v & (v << 1);
-        rr &= rr << 2;
-        rr &= rr << 4;
-        rr &= rr << 8;
-        rr &= rr << 15;                                            // runs of >= 31
-        uint32_t live16 = (uint32_t)(rr >> 32) & 0xFFFFu;
-        const uint64_t pbase = pos0 + (uint64_t)j * 16u;
-        if (!all_emit && pbase < emit_begin) {
-            const uint64_t dlt = emit_begin - pbase;
-            live16 = dlt >= 16u ? 0u : live16 & (0xFFFFu << (uint32_t)dlt);
-        }
-        if (STATS) n_live += (uint32_t)__popc(live16);
-        const uint32_t dead16 = ~live16;
-
-        const uint32_t ebase = tid * SK_SPAN + j * 16u;            // tile-relative index of offset 0
-        uint32_t P = 0xFFFFFFFFu;
-#pragma unroll
-        for (int o = 0; o < 16; o++) {
-            // the 16-mer that ends at offset o, straight from the two code words
-            const uint32_t h = sk_mhash(o < 15 ? __builtin_amdgcn_alignbit(cw_prev, cwj, 30 - 2 * o) : cwj);
-            H[o] = h;
-            P = h < P ? h : P;
-            uint32_t mz = S[o + 1] < P ? S[o + 1] : P;
-            mz |= (uint32_t)__builtin_amdgcn_sbfe((int)dead16, o, 1);          // dead window: all ones
-            const bool chg = mz != run_mz;
-            push_event(chg, run_mz, ebase, run_relx, o);
-            run_relx = chg ? SK_RELX(o) : run_relx;
-            run_mz = mz;
-            if ((o & (SK_PUMP_EVERY - 1)) == SK_PUMP_EVERY - 1 && o != 15 && qe >= 64u) pump();
-        }
-        if (qe >= 64u) pump();
-        run_relx -= SK_RELX(16);
-        cw_prev = cwj;
-
-        S[15] = H[15];
-#pragma unroll
-        for (int i = 14; i >= 0; i--) S[i] = H[i] < S[i + 1] ? H[i] : S[i + 1];
-    }
-
-    // ---- tail: the last run, then everything still queued or pending ---------------------------
-    push_event(true, run_mz, tid * SK_SPAN + SK_SPAN, run_relx, 0);
-    while (pn != 0u || qe != 0u) { complete(); issue(); }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (qw) probe_some(qw);
-    if (bad) atomicAdd(&flags[0], 1u);
-    if (STATS) {
-        atomicAdd((unsigned long long *)&flags[4], (unsigned long long)n_live);
-        atomicAdd((unsigned long long *)&flags[6], (unsigned long long)n_load);
-        atomicAdd((unsigned long long *)&flags[8], (unsigned long long)n_probe);
-    }
+// level-1 filter verdict on one packed 16-mer (either orientation): false = certainly not in the strain
+__device__ __forceinline__ bool sk_grid1_has(const sk_table_view &t, uint32_t w16)
+{
+    const uint32_t r = sk_revcomp32(w16);
+    const uint32_t g = sk_gmix(w16 < r ? w16 : r);
+    const uint2 q = t.grid1[sk_grid1_block(g, t.grid1_blocks)];
+    return sk_grid_test(q, sk_grid1_bits(g));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -574,13 +301,6 @@ void sk_scan_main(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 //            time exactly as in sk_scan_main: anchors through the hash, followers through their
 //            anchor's neighbour in strain order, every hit a full 62-bit compare.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool sk_grid_test(const uint2 blk, uint32_t bits)
-{
-    const uint32_t t = (blk.x >> (bits >> 27)) & (blk.x >> ((bits >> 22) & 31u)) &
-                       (blk.y >> ((bits >> 17) & 31u)) & (blk.y >> ((bits >> 12) & 31u));
-    return (t & 1u) != 0u;
-}
-
 // invalid mask of chunk c (index into the LDS records: record 0 = the 8 chunks before the tile)
 __device__ __forceinline__ uint32_t sk_chunk_inv(const uint32_t *rec, uint32_t c)
 {
@@ -691,14 +411,16 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         g[i] = sk_gmix(cw < rc ? cw : rc);
         okm |= (uint32_t)(inv == 0u) << i;
         b1[i] = make_uint2(0u, 0u);
-        if (ABLATE == 4) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks) & 4095u]; }   // timing: all lookups hit the L2
+        if (ABLATE == 4) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks) & 131071u]; }  // timing: all lookups in 1 MiB (L2 hits)
+        else if (ABLATE == 6) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks) & 2047u]; } // timing: all lookups in 16 KiB (L1 hits)
         else if (ABLATE != 1 && inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)];
     }
     uint32_t m = 0;                                               // chunks that may be in the strain
 #pragma unroll
     for (int i = 0; i < SK_SPAN_CH; i++)
-        m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) && ABLATE != 4) << i;
-    if (m) {                                                      // level 2 (rare for unrelated reads)
+        m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) &&
+                        ((ABLATE != 4 && ABLATE != 6) || g[i] == 0x9E3779B9u)) << i;     // (ablations: loads kept alive, verdicts dropped)
+    if (m && ABLATE != 5) {                                       // (ABLATE 5, exact: no level 2, stage 2 sorts it out)                                                      // level 2 (rare for unrelated reads)
         // A chunk right after one that passed level 2 is taken on its level-1 pass alone: inside a strain read
         // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
         // level 1 next to a level-2 pass is as rare as level 2's own false positives.  Pruning less is always
@@ -715,23 +437,30 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     }
 
     // ================= stage 2: the windows of the surviving chunks ==============================
-    // Up to 128 queued windows at a time, two per lane: the two dependent memory latencies of a batch
-    // (anchor probe in HBM, then the followers' strain-order key line) are what stage 2 waits for, so
-    // twice the windows per round trip is close to twice the rate.
+    // Up to 128 queued windows at a time, two per lane.  Seed and verify: every SK_ANCHOR-th window of a
+    // stretch of consecutive positions (and its first one) is an ANCHOR and pays a random probe of the HBM
+    // table; a hit comes back with the row's place in the strain's text and its orientation, i.e. with the
+    // diagonal the read lies on.  Every other window of the stretch then takes the nearest anchor that hit,
+    // reads the 31 bases of the strain's text where the diagonal puts it (2-bit text, 1.25 MB for 5 Mbp:
+    // neighbouring lanes share its lines) and compares all 62 bits with its own window -- as exact as a probe;
+    // the row is the rank of that text position (one 16-byte block of the rank map).  Windows the text does
+    // not settle (a read error, a repeat, no anchor hit in the stretch) fall back to the hash table, behind
+    // a question to the L2-resident level-1 filter about a 16-mer of theirs that holds the mismatch.
     auto probe_some = [&](uint32_t n) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         qw -= n;
-        bool act[2], w_fwd[2], anchor[2];
-        uint32_t e[2], pos[2], kk[2], hit[2], a_dir[2];
-        uint64_t cn[2];
+        bool act[2], anchor[2];
+        uint32_t e[2], pos[2], kk[2], hit[2], a_pos[2], a_dir[2], lo_lane[2], hi_lane[2];
+        uint64_t fwd[2], rc[2], cn[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
             const uint32_t idx = lane + 64u * (uint32_t)s2;
             act[s2] = idx < n;
             e[s2] = act[s2] ? wq[qw + idx] : 0xFFFF0000u + lane * 2u;           // inactive: never consecutive
-            w_fwd[s2] = false;
-            cn[s2] = act[s2] ? sk_window_canon(rec, e[s2], w_fwd[s2]) : 0ull;
+            fwd[s2] = rc[s2] = 0ull;
+            if (act[s2]) sk_window_keys(rec, e[s2], fwd[s2], rc[s2]);
+            cn[s2] = fwd[s2] > rc[s2] ? fwd[s2] : rc[s2];
             pos[s2] = (uint32_t)tile0 + e[s2];
         }
         if (ABLATE == 2) { __builtin_amdgcn_wave_barrier(); return; }
@@ -740,10 +469,12 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             const uint32_t e_prev = (uint32_t)__shfl_up((int)e[s2], 1);
             const bool first = (lane == 0u) | (e[s2] != e_prev + 1u);          // first window of a stretch
             const unsigned long long fm = __ballot(first);
-            const uint32_t first_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
-            kk[s2] = lane - first_lane;                                        // offset inside the stretch
+            lo_lane[s2] = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
+            const unsigned long long above = lane == 63u ? 0ull : fm & ~((2ull << lane) - 1ull);
+            hi_lane[s2] = above ? (uint32_t)__builtin_ctzll(above) - 1u : 63u; // last lane of the stretch
+            kk[s2] = lane - lo_lane[s2];                                       // offset inside the stretch
             anchor[s2] = act[s2] & ((kk[s2] & (SK_ANCHOR - 1u)) == 0u);
-            hit[s2] = 0xFFFFFFFFu; a_dir[s2] = 0u;
+            hit[s2] = 0xFFFFFFFFu; a_pos[s2] = 0x7FFFFFFFu; a_dir[s2] = 0u;
         }
         // both slots' anchors probe the hash table together
         uint32_t slot[2];
@@ -759,49 +490,75 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 uint32_t sl = slot[s2];
                 for (;;) {
                     const uint64_t key = sk_slot_key(en);
-                    if (key == cn[s2]) { hit[s2] = en.z; a_dir[s2] = (uint32_t)w_fwd[s2] ^ (en.w & 1u); break; }
+                    if (key == cn[s2]) {
+                        hit[s2] = en.z;
+                        a_pos[s2] = en.w >> 1;
+                        a_dir[s2] = (uint32_t)(fwd[s2] > rc[s2]) ^ (en.w & 1u);  // 0: the read runs along the strain, 1: against it
+                        break;
+                    }
                     if (key == SK_EMPTY64) break;
                     sl = (sl + 1u) & table.mask;
                     en = table.slots[sl];
                 }
             }
         }
-        // followers: the anchor's neighbour in strain order, both slots' key lines in flight together
-        uint32_t fidx[2];
-        uint64_t fkey[2];
+        // followers: the text at the place the nearest anchor that hit puts them
+        uint32_t need[2];                                                      // 0 settled, 1 probe the table, 2 ask the filter first
+        uint64_t diff[2], cmpk[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
-            const uint32_t my_anchor = lane - (kk[s2] & (SK_ANCHOR - 1u));
-            const uint32_t n_idx = (uint32_t)__shfl((int)hit[s2], (int)my_anchor);
-            const uint32_t n_dir = (uint32_t)__shfl((int)a_dir[s2], (int)my_anchor);
-            const uint32_t d = kk[s2] & (SK_ANCHOR - 1u);
-            fidx[s2] = 0xFFFFFFFFu;
-            fkey[s2] = 0ull;
-            if (act[s2] & !anchor[s2] && n_idx != 0xFFFFFFFFu && table.keys_by_loc) {
-                const uint32_t idx = n_dir ? n_idx - d : n_idx + d;            // wraps below 0 -> >= nrows
-                if (idx < table.nrows) { fidx[s2] = idx; fkey[s2] = table.keys_by_loc[idx]; }
+            const bool seed = anchor[s2] & (hit[s2] != 0xFFFFFFFFu) & (a_pos[s2] != 0x7FFFFFFFu);
+            const unsigned long long sm = __ballot(seed);
+            const unsigned long long span = (hi_lane[s2] == 63u ? ~0ull : ((2ull << hi_lane[s2]) - 1ull)) & ~((1ull << lo_lane[s2]) - 1ull);
+            const unsigned long long cand = table.text2 ? sm & span : 0ull;
+            const unsigned long long below = cand & ((1ull << lane) - 1ull);
+            const uint32_t src = below ? 63u - (uint32_t)__clzll(below) : cand ? (uint32_t)__builtin_ctzll(cand) : lane;
+            const uint32_t s_pos = (uint32_t)__shfl((int)a_pos[s2], (int)src);
+            const uint32_t s_dir = (uint32_t)__shfl((int)a_dir[s2], (int)src);
+            need[s2] = 0u; diff[s2] = 0ull; cmpk[s2] = 0ull;
+            if (act[s2] & !anchor[s2]) {
+                need[s2] = 2u;
+                const uint32_t d = lane - src;                                 // (two's complement when the anchor is above)
+                const uint32_t q = s_dir ? s_pos - d : s_pos + d;              // wraps below 0 -> beyond the text
+                if (cand && q < table.text_bases && q + SK_K <= table.text_bases) {
+                    const uint64_t tk = sk_text_key(table.text2, q);
+                    const sk_u4 rk = table.rank[q >> 6];
+                    cmpk[s2] = s_dir ? rc[s2] : fwd[s2];
+                    diff[s2] = tk ^ cmpk[s2];
+                    if (diff[s2] == 0ull) {
+                        const uint64_t m64 = ((uint64_t)rk.z << 32) | rk.y;
+                        const uint32_t bit = q & 63u;
+                        if ((m64 >> bit) & 1ull) { hit[s2] = rk.x + (uint32_t)__popcll(m64 & ((1ull << bit) - 1ull)); need[s2] = 0u; }
+                        else need[s2] = 1u;                                    // a repeat of an earlier k-mer (or a special row): its row is elsewhere
+                    }
+                }
             }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
-            if (act[s2] & !anchor[s2]) {
-                if (fidx[s2] != 0xFFFFFFFFu && fkey[s2] == cn[s2]) hit[s2] = fidx[s2];
-                if (hit[s2] == 0xFFFFFFFFu) {
-                    // Not where its neighbours are: mostly a read error, and then ~30 windows in a row end up
-                    // here.  Before the random table probe, ask the level-1 filter (L2-resident: free) about the
-                    // window's first and last 16-mer: they cover all 31 bases, so an erroneous base makes one of
-                    // them a stranger to the strain (no false negatives: a real k-mer always passes both).
-                    const uint32_t w0 = (uint32_t)(cn[s2] >> 30), w1 = (uint32_t)cn[s2];
-                    const uint32_t r0 = sk_revcomp32(w0), r1 = sk_revcomp32(w1);
-                    const uint32_t g0 = sk_gmix(w0 < r0 ? w0 : r0), g1 = sk_gmix(w1 < r1 ? w1 : r1);
-                    const uint2 q0 = table.grid1[sk_grid1_block(g0, table.grid1_blocks)];
-                    const uint2 q1 = table.grid1[sk_grid1_block(g1, table.grid1_blocks)];
-                    if (sk_grid_test(q0, sk_grid1_bits(g0)) && sk_grid_test(q1, sk_grid1_bits(g1))) {
-                        uint32_t unused;
-                        hit[s2] = sk_find(cn[s2], table, &unused);
-                    }
+            if (need[s2] == 2u) {
+                // Not where the diagonal says: mostly a read error, and then ~30 windows in a row end up here.  Before
+                // the random table probe, ask the level-1 filter (L2-resident) about 16-mers of the window: a real
+                // k-mer always passes (no false negatives), a window with a wrong base fails on a 16-mer that holds it.
+                bool maybe = true;
+                if (diff[s2]) {
+                    // the first mismatching base of the compared key (the window along or against the strain: a 16-mer
+                    // of either is a 16-mer of the window up to orientation, which the filter ignores) and a 16-mer of
+                    // that key around it
+                    const uint32_t xt = ((uint32_t)__clzll(diff[s2]) - 2u) >> 1;           // 0..30
+                    const uint32_t st = xt < 8u ? 0u : xt > 23u ? 15u : xt - 8u;            // bases st .. st+15 hold base xt
+                    maybe = sk_grid1_has(table, (uint32_t)(cmpk[s2] >> (30u - 2u * st)));
                 }
+                if (maybe) {
+                    // first and last 16-mer: together they cover all 31 bases
+                    maybe = sk_grid1_has(table, (uint32_t)(cn[s2] >> 30)) && sk_grid1_has(table, (uint32_t)cn[s2]);
+                }
+                if (maybe) need[s2] = 1u;
             }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (need[s2] == 1u) { uint32_t unused; hit[s2] = sk_find(cn[s2], table, &unused); }
         }
         if (TALLY) {
 #pragma unroll
@@ -989,13 +746,12 @@ __global__ void sk_fill64(uint64_t *p, uint64_t n, uint64_t v)
 }
 
 __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_u4 *slots, uint32_t mask, uint32_t *flags,
-                                const uint32_t *__restrict__ perm, const uint32_t *__restrict__ locality, uint64_t *keys_by_loc)
+                                const uint32_t *__restrict__ perm, const uint32_t *__restrict__ locality)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = in[i];
     const uint32_t idx = perm ? perm[i] : i;
-    if (keys_by_loc) keys_by_loc[idx] = k;             // (all ones for a wide row: never equals a packed window)
     if (k == SK_EMPTY64) return;                       // wide row: not in this table
     if (k > SK_KMASK62) { atomicAdd(&flags[1], 1u); return; }
     uint32_t slot = sk_slot0(sk_khash(k), mask);
@@ -1004,11 +760,22 @@ __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_
                                                 (unsigned long long)SK_EMPTY64, (unsigned long long)k);
         if (old == SK_EMPTY64) {
             ((uint32_t *)&slots[slot])[2] = idx;
-            ((uint32_t *)&slots[slot])[3] = locality ? locality[i] >> 31 : 0u;
+            ((uint32_t *)&slots[slot])[3] = 0xFFFFFFFEu | (locality ? locality[i] >> 31 : 0u);   // no text position (yet)
             return;
         }
         if (old == k) { atomicAdd(&flags[1], 1u); return; }     // duplicate key
         slot = (slot + 1u) & mask;
+    }
+}
+
+// text position of every row into its table slot (pos_by_idx: by counter index, 0xFFFFFFFF = none)
+__global__ void sk_table_setpos(sk_u4 *slots, uint64_t nslots, const uint32_t *__restrict__ pos_by_idx)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += stride) {
+        const sk_u4 e = slots[i];
+        if (sk_slot_key(e) == SK_EMPTY64) continue;
+        ((uint32_t *)&slots[i])[3] = (pos_by_idx[e.z] << 1) | (e.w & 1u);
     }
 }
 
@@ -1031,21 +798,6 @@ __global__ void sk_invert_perm(uint32_t *__restrict__ inv, const uint32_t *__res
     if (i >= n) return;
     if (perm[i] >= n) { atomicAdd(&flags[1], 1u); return; }
     inv[perm[i]] = i;
-}
-
-__global__ void sk_bloom_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *bloom_words, uint32_t bloom_shift)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = in[i];
-    if (k == SK_EMPTY64) return;
-    for (int strand = 0; strand < 2; strand++) {      // a read may carry the key in either orientation
-        const uint32_t mz = sk_minimizer62(strand ? sk_revcomp62(k) : k);
-        const uint32_t g = sk_filter_bits(mz);
-        uint32_t *blk = bloom_words + 2u * (size_t)sk_filter_block(mz, bloom_shift);
-        atomicOr(&blk[0], (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)));
-        atomicOr(&blk[1], (1u << ((g >> 17) & 31u)) | (1u << ((g >> 12) & 31u)));
-    }
 }
 
 // grid filters: the canonical form of every 16-mer of every key, into both levels
@@ -1085,18 +837,17 @@ struct sk_ctx {
     // table
     sk_u4       *d_keys;              // the slot array (name kept: "is a table loaded" checks)
     uint32_t     slots_log2;
-    uint2       *d_bloom;
-    uint32_t     bloom_blocks_log2;       // 0 = no prefilter
+    uint32_t    *d_text2;                 // seed and verify: the strain's text and the rank map (sk_table_load_text)
+    sk_u4       *d_rank;
+    uint32_t     text_bases;
     uint2       *d_grid1, *d_grid2;       // grid kernel's two filter levels
     uint32_t     grid1_blocks, grid2_blocks_log2;
     long         grid_kib;                // option: size of level 1 in KiB (-1 = automatic)
-    long         kernel;                  // option: 0 = grid kernel (default), 1 = minimizer kernel
     long         odd_cap;                 // option (tests): usable length of the odd-chunk list, 0 = all of it
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
     uint32_t    *d_perm, *d_inv;      // locality order of the counters (NULL = caller's row order)
     uint32_t    *d_locality;          // the caller's locality[] as given (with the orientation bit)
-    uint64_t    *d_keys_by_loc;
     uint32_t    *d_tmp;               // [nrows] scratch for fetch/set through the permutation
     std::vector<uint32_t> h_perm;     // host copy of the permutation (empty = identity)
     // wide keys
@@ -1120,9 +871,9 @@ struct sk_ctx {
     uint64_t     timed_launches;
     // options
     long         table_load_pct;
-    long         bloom_bits_log2;
-    long         stats;               // debug: count live windows / filter loads / table probes
     long         ablate;              // timing experiments: kernel variants that skip memory stages
+    long         dev_uncached;        // experiment: sk_dev_alloc hands out memory the L2 does not keep
+    long         no_text;             // option "text_stage"=0: stage 2 probes every window on its own (A/B, tests)
     void        *t_tally, *t_hits;    // grow-only device scratch of the tally path
     size_t       t_tally_cap, t_hits_cap;
     uint8_t     *h_tally;             // pinned landing area of the tallies (+ the hit counter)
@@ -1184,7 +935,6 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     if (!c) return SK_E_NOMEM;
     c->device = device;
     c->table_load_pct = 50;
-    c->bloom_bits_log2 = -1;          // -1 = automatic (sized for the L2), 0 = off
     c->grid_kib = -1;
     c->err[0] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SK_E_NODEVICE; }
@@ -1201,7 +951,9 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
 static void sk_table_release(sk_ctx *c)
 {
     hipFree(c->d_keys); c->d_keys = NULL;
-    hipFree(c->d_bloom); c->d_bloom = NULL;
+    hipFree(c->d_text2); c->d_text2 = NULL;
+    hipFree(c->d_rank); c->d_rank = NULL;
+    c->text_bases = 0;
     hipFree(c->d_grid1); c->d_grid1 = NULL;
     hipFree(c->d_grid2); c->d_grid2 = NULL;
     hipFree(c->d_counts); c->d_counts = NULL;
@@ -1209,7 +961,6 @@ static void sk_table_release(sk_ctx *c)
     c->h_perm.clear();
     hipFree(c->d_inv); c->d_inv = NULL;
     hipFree(c->d_locality); c->d_locality = NULL;
-    hipFree(c->d_keys_by_loc); c->d_keys_by_loc = NULL;
     hipFree(c->d_tmp); c->d_tmp = NULL;
     hipFree(c->d_wide_keys); c->d_wide_keys = NULL;
     hipFree(c->d_wide_rows); c->d_wide_rows = NULL;
@@ -1247,11 +998,10 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
 {
     if (!c || !name) return SK_E_ARG;
     if (!strcmp(name, "table_load_pct")) { if (value < 5 || value > 90) return SK_E_ARG; c->table_load_pct = value; return SK_OK; }
-    if (!strcmp(name, "bloom_bits_log2")) { if (value < -1 || value > 34 || (value > 0 && value < 10)) return SK_E_ARG; c->bloom_bits_log2 = value; return SK_OK; }
     if (!strcmp(name, "grid_kib")) { if (value < -1 || value == 0 || value > (1 << 22)) return SK_E_ARG; c->grid_kib = value; return SK_OK; }
     if (!strcmp(name, "odd_list_cap")) { if (value < 0 || value > (long)SK_ODDCAP) return SK_E_ARG; c->odd_cap = value; return SK_OK; }
-    if (!strcmp(name, "kernel")) { if (value < 0 || value > 1) return SK_E_ARG; c->kernel = value; return SK_OK; }
-    if (!strcmp(name, "stats")) { c->stats = value != 0; return SK_OK; }
+    if (!strcmp(name, "dev_alloc_uncached")) { c->dev_uncached = value != 0; return SK_OK; }
+    if (!strcmp(name, "text_stage")) { c->no_text = value == 0; return SK_OK; }
     if (!strcmp(name, "ablate")) { c->ablate = value; return SK_OK; }
     return sk_fail(c, SK_E_ARG, "unknown option %s", name);
 }
@@ -1297,28 +1047,13 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
             c->h_perm.resize(nrows);
             for (uint32_t i = 0; i < nrows; i++) c->h_perm[i] = locality[i] & 0x7FFFFFFFu;
             SK_HIP(c, hipMalloc((void **)&c->d_locality, (size_t)nrows * 4));
-            SK_HIP(c, hipMalloc((void **)&c->d_keys_by_loc, (size_t)nrows * 8));
             SK_HIP(c, hipMemcpyAsync(c->d_locality, locality, (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
             SK_HIP(c, hipMemcpyAsync(c->d_perm, c->h_perm.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
             SK_HIP(c, hipMemsetAsync(c->d_inv, 0xFF, (size_t)nrows * 4, c->stream));
             hipLaunchKernelGGL(sk_invert_perm, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, c->d_inv, c->d_perm, nrows, c->d_flags);
         }
         hipLaunchKernelGGL(sk_table_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
-                           d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags, c->d_perm, c->d_locality, c->d_keys_by_loc);
-        // minimizer filter: automatic size = smallest power of two >= 4 bits per key (the set holds
-        // ~nrows/8 minimizers, i.e. ~32 bits each: false positives ~0.1 %); 2 MiB for a 5 Mbp strain
-        long bb = c->bloom_bits_log2;
-        if (bb < 0) { bb = 12; while (bb < 30 && ((uint64_t)1 << bb) < (uint64_t)nrows * 4ull) bb++; }
-        c->bloom_blocks_log2 = 0;
-        if (bb > 0) {
-            const uint32_t blocks_log2 = (uint32_t)bb - 6u;
-            const size_t bbytes = ((size_t)1 << blocks_log2) * sizeof(uint2);
-            SK_HIP(c, hipMalloc((void **)&c->d_bloom, bbytes));
-            SK_HIP(c, hipMemsetAsync(c->d_bloom, 0, bbytes, c->stream));
-            hipLaunchKernelGGL(sk_bloom_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
-                               d_in, nrows, (uint32_t *)c->d_bloom, 32u - blocks_log2);
-            c->bloom_blocks_log2 = blocks_log2;
-        }
+                           d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags, c->d_perm, c->d_locality);
         {   // grid filters.  Level 1: ~5 bits per key -- 3 MiB for a 5 Mbp strain, which stays in the L2 (4 MiB per XCD,
             // shared with everything else).  For bigger strains it is better to keep the 5 bits per key and leave the L2
             // than to keep the size and let the filter fill up (tools/grid_size_sweep.sh, 20 Mbp strain: 3 MiB 540,
@@ -1382,6 +1117,51 @@ extern "C" int sk_table_load_wide(sk_ctx *c, const char *keys31, const uint32_t 
     return SK_OK;
 }
 
+extern "C" int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nbases, const uint32_t *first_pos)
+{
+    if (!c || !text2 || !first_pos) return SK_E_ARG;
+    if (!c->d_keys || !c->nrows) return sk_fail(c, SK_E_STATE, "sk_table_load_ex first");
+    if (c->h_perm.empty()) return sk_fail(c, SK_E_STATE, "the text stage needs the locality order of sk_table_load_ex");
+    if (nbases < SK_K || nbases > 0xFFFFFF00u) return sk_fail(c, SK_E_ARG, "text of %u bases", nbases);
+    const uint32_t nrows = c->nrows;
+    // by counter index; the contract: rows with a position first, positions ascending
+    std::vector<uint32_t> pos_by_idx(nrows, 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < nrows; r++) pos_by_idx[c->h_perm[r]] = first_pos[r];
+    uint32_t m = 0;
+    while (m < nrows && pos_by_idx[m] != 0xFFFFFFFFu) m++;
+    for (uint32_t i = 0; i < nrows; i++) {
+        const uint32_t p = pos_by_idx[i];
+        if (i >= m) { if (p != 0xFFFFFFFFu) return sk_fail(c, SK_E_ARG, "rows with a text position must come first in locality order"); continue; }
+        if (p > nbases - SK_K || (i && p <= pos_by_idx[i - 1])) return sk_fail(c, SK_E_ARG, "text positions must ascend with the locality order and lie inside the text");
+    }
+    // rank map: per 64 positions {counter index of the first row starting in the block, the 64 start bits}
+    const size_t nblk = (size_t)nbases / 64 + 2;
+    std::vector<sk_u4> rank(nblk, (sk_u4){0u, 0u, 0u, 0u});
+    for (uint32_t i = 0; i < m; i++) {
+        const uint32_t p = pos_by_idx[i];
+        if (p & 32u) rank[p >> 6].z |= 1u << (p & 31u); else rank[p >> 6].y |= 1u << (p & 31u);
+    }
+    uint32_t run = 0;
+    for (size_t b = 0; b < nblk; b++) { rank[b].x = run; run += (uint32_t)__builtin_popcount(rank[b].y) + (uint32_t)__builtin_popcount(rank[b].z); }
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    hipFree(c->d_text2); c->d_text2 = NULL;
+    hipFree(c->d_rank); c->d_rank = NULL;
+    c->text_bases = 0;
+    const size_t words = (size_t)nbases / 16 + 4, have = ((size_t)nbases + 15) / 16;
+    SK_HIP(c, hipMalloc((void **)&c->d_text2, words * 4));
+    SK_HIP(c, hipMalloc((void **)&c->d_rank, nblk * sizeof(sk_u4)));
+    SK_HIP(c, hipMemsetAsync(c->d_text2, 0, words * 4, c->stream));
+    SK_HIP(c, hipMemcpyAsync(c->d_text2, text2, have * 4, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(c, hipMemcpyAsync(c->d_rank, rank.data(), nblk * sizeof(sk_u4), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(c, hipMemcpyAsync(c->d_tmp, pos_by_idx.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(sk_table_setpos, dim3(4096), dim3(256), 0, c->stream, c->d_keys, (uint64_t)1 << c->slots_log2, c->d_tmp);
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    SK_HIP(c, hipGetLastError());
+    c->text_bases = nbases;
+    return SK_OK;
+}
+
 // launch main + wide kernels over one device-resident batch
 static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, uint64_t emit_begin, uint32_t col,
                           const sk_sink *tally_sink = NULL)
@@ -1390,10 +1170,9 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     const uint64_t ntiles = (nbytes + SK_TILE - 1) / SK_TILE;
     if (ntiles > 0x7FFFFFFFull) return sk_fail(c, SK_E_ARG, "batch too large");
     sk_table_view tv;
-    tv.keys_by_loc = c->d_keys_by_loc; tv.nrows = c->nrows;
+    tv.nrows = c->nrows;
+    tv.text2 = c->no_text ? NULL : c->d_text2; tv.rank = c->d_rank; tv.text_bases = c->text_bases;
     tv.slots = c->d_keys; tv.mask = (uint32_t)(((uint64_t)1 << c->slots_log2) - 1);
-    tv.bloom = c->d_bloom;
-    tv.bloom_shift = 32u - c->bloom_blocks_log2;
     tv.oddlist = c->d_oddlist; tv.oddcap = c->odd_cap ? (uint32_t)c->odd_cap : SK_ODDCAP;
     tv.grid1 = c->d_grid1; tv.grid2 = c->d_grid2;
     tv.grid1_blocks = c->grid1_blocks; tv.grid2_shift = 32u - c->grid2_blocks_log2;
@@ -1414,27 +1193,17 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         SK_HIP(c, hipEventCreate(&e1));
         SK_HIP(c, hipEventRecord(e0, c->stream));
     }
-#define SK_LAUNCH_MAIN(F, S, A, T) hipLaunchKernelGGL((sk_scan_main<F, S, A, T>), grid, block, 0, c->stream, \
-                                                      d_stream, nbytes, emit_begin, tv, sink, c->d_flags)
-    const bool filter = c->bloom_blocks_log2 != 0;
 #define SK_LAUNCH_GRID(T, A) hipLaunchKernelGGL((sk_scan_grid<T, A>), grid, block, 0, c->stream, \
                                                 d_stream, nbytes, emit_begin, tv, sink, c->d_flags)
-    const bool use_grid = c->kernel == 0 && c->d_grid1 && !c->stats;
-    if (use_grid && tally_sink)          SK_LAUNCH_GRID(true, 0);
-    else if (use_grid && c->ablate == 1) SK_LAUNCH_GRID(false, 1);
-    else if (use_grid && c->ablate == 2) SK_LAUNCH_GRID(false, 2);
-    else if (use_grid && c->ablate == 3) SK_LAUNCH_GRID(false, 3);
-    else if (use_grid && c->ablate == 4) SK_LAUNCH_GRID(false, 4);
-    else if (use_grid)                   SK_LAUNCH_GRID(false, 0);
-    else if (tally_sink)                 { if (filter) SK_LAUNCH_MAIN(true, false, 0, true); else SK_LAUNCH_MAIN(false, false, 0, true); }
-    else if (c->ablate == 1 && filter)   SK_LAUNCH_MAIN(true, false, 1, false);
-    else if (c->ablate == 2 && filter)   SK_LAUNCH_MAIN(true, false, 2, false);
-    else if (c->ablate == 3 && filter)   SK_LAUNCH_MAIN(true, false, 3, false);
-    else if (c->ablate == 4 && filter)   SK_LAUNCH_MAIN(true, false, 4, false);
-    else if (c->stats && filter)         SK_LAUNCH_MAIN(true, true, 0, false);
-    else if (filter)                     SK_LAUNCH_MAIN(true, false, 0, false);
-    else                                 SK_LAUNCH_MAIN(false, false, 0, false);
-#undef SK_LAUNCH_MAIN
+    if (!c->d_grid1) return sk_fail(c, SK_E_STATE, "no table loaded");
+    if (tally_sink)          SK_LAUNCH_GRID(true, 0);
+    else if (c->ablate == 1) SK_LAUNCH_GRID(false, 1);
+    else if (c->ablate == 2) SK_LAUNCH_GRID(false, 2);
+    else if (c->ablate == 3) SK_LAUNCH_GRID(false, 3);
+    else if (c->ablate == 4) SK_LAUNCH_GRID(false, 4);
+    else if (c->ablate == 5) SK_LAUNCH_GRID(false, 5);
+    else if (c->ablate == 6) SK_LAUNCH_GRID(false, 6);
+    else                     SK_LAUNCH_GRID(false, 0);
 #undef SK_LAUNCH_GRID
     if (timed) {
         SK_HIP(c, hipEventRecord(e1, c->stream));
@@ -1813,19 +1582,6 @@ extern "C" int sk_scan_timing(sk_ctx *c, double *total_ms, uint64_t *launches, i
     return SK_OK;
 }
 
-// debug statistics accumulated by sk_scan_main<.., STATS=true> since the table was loaded:
-// out[0] = windows looked up, out[1] = prefilter block loads, out[2] = table probes
-extern "C" int sk_scan_stats(sk_ctx *c, uint64_t out[3])
-{
-    if (!c || !out) return SK_E_ARG;
-    uint64_t raw[4];
-    SK_HIP(c, hipSetDevice(c->device));
-    SK_HIP(c, hipStreamSynchronize(c->stream));
-    SK_HIP(c, hipMemcpy(raw, c->d_flags + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    out[0] = raw[0]; out[1] = raw[1]; out[2] = raw[2];
-    return SK_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // RCCL (resolved lazily so that the library loads on hosts without it)
 // ---------------------------------------------------------------------------------------------
@@ -1932,7 +1688,8 @@ extern "C" int sk_dev_alloc(sk_ctx *c, void **dev, uint64_t nbytes)
 {
     if (!c || !dev) return SK_E_ARG;
     SK_HIP(c, hipSetDevice(c->device));
-    SK_HIP(c, hipMalloc(dev, nbytes ? nbytes : 16));
+    if (c->dev_uncached) SK_HIP(c, hipExtMallocWithFlags(dev, nbytes ? nbytes : 16, hipDeviceMallocUncached));
+    else SK_HIP(c, hipMalloc(dev, nbytes ? nbytes : 16));
     return SK_OK;
 }
 

@@ -197,14 +197,19 @@ typedef struct {
     /* wide-key set */
     char *wkeys; uint32_t *wv; uint32_t wn, wcap; uint32_t *windex; uint32_t wmask;
     /* insertion order */
-    uint64_t *order; uint32_t *count; uint8_t *fwd_first; uint32_t n, cap;
+    uint64_t *order; uint32_t *count; uint8_t *fwd_first; uint32_t *firstpos; uint32_t n, cap;
     uint32_t default_val, incr;
+    /* the strain's text, 2 bits per base (16 per word, first base on top), records end to end: the scan's
+     * seed-and-verify stage compares reads with it (sk_table_load_text) */
+    uint32_t *text2; uint64_t text_n, text_cap_words;
     uint64_t short_records;
     signed char comp[256];
     /* packed keys wait here for SK_RING more windows while their table line is fetched: the distinct-key
      * set of a 5 Mbp strain (100+ MB) lives in DRAM and every insert is a cache miss otherwise */
-    uint64_t ring_key[SK_RING]; uint8_t ring_fwd[SK_RING]; uint32_t ring_n, ring_pos;
+    uint64_t ring_key[SK_RING]; uint8_t ring_fwd[SK_RING]; uint32_t ring_tpos[SK_RING]; uint32_t ring_n, ring_pos;
 } builder;
+
+#define NO_POS 0xFFFFFFFFu
 
 /* hint_bases: about how many bases the strain has (0 = unknown): the distinct-key set starts at twice
  * that many slots instead of growing there by repeated rehashing */
@@ -226,7 +231,7 @@ static void builder_init(builder *b, uint32_t default_val, uint32_t incr, uint64
 static void builder_free(builder *b)
 {
     free(b->pk); free(b->pv); free(b->wkeys); free(b->wv); free(b->windex);
-    free(b->order); free(b->count); free(b->fwd_first);
+    free(b->order); free(b->count); free(b->fwd_first); free(b->firstpos); free(b->text2);
 }
 
 static uint32_t builder_append(builder *b, uint64_t entry)
@@ -236,10 +241,12 @@ static uint32_t builder_append(builder *b, uint64_t entry)
         b->order = (uint64_t *)realloc(b->order, (size_t)b->cap * sizeof(uint64_t));
         b->count = (uint32_t *)realloc(b->count, (size_t)b->cap * sizeof(uint32_t));
         b->fwd_first = (uint8_t *)realloc(b->fwd_first, (size_t)b->cap);
+        b->firstpos = (uint32_t *)realloc(b->firstpos, (size_t)b->cap * sizeof(uint32_t));
     }
     b->order[b->n] = entry;
     b->count[b->n] = b->default_val;
     b->fwd_first[b->n] = 0;
+    b->firstpos[b->n] = NO_POS;
     return b->n++;
 }
 
@@ -261,8 +268,9 @@ static void builder_grow_packed(builder *b)
     free(ok); free(ov);
 }
 
-/* is_fwd: the key is the strain's text itself at this occurrence (not its reverse complement) */
-static void builder_insert_packed(builder *b, uint64_t key, int is_fwd)
+/* is_fwd: the key is the strain's text itself at this occurrence (not its reverse complement);
+ * tpos: text position of the window's first base when the window is all ACGT, else NO_POS */
+static void builder_insert_packed(builder *b, uint64_t key, int is_fwd, uint32_t tpos)
 {
     uint64_t s = sk_hash62(key) & b->pmask;
     while (b->pk[s] != SK_EMPTY64) {
@@ -272,15 +280,16 @@ static void builder_insert_packed(builder *b, uint64_t key, int is_fwd)
     b->pk[s] = key;
     b->pv[s] = builder_append(b, key);
     b->fwd_first[b->pv[s]] = (uint8_t)is_fwd;
+    b->firstpos[b->pv[s]] = tpos;
     if (++b->pcount * 2 > b->pmask) builder_grow_packed(b);
 }
 
 /* queue a packed key: prefetch its table line now, insert it SK_RING windows later (order is kept) */
-static void builder_add_packed(builder *b, uint64_t key, int is_fwd)
+static void builder_add_packed(builder *b, uint64_t key, int is_fwd, uint32_t tpos)
 {
     uint32_t at;
     if (b->ring_n == SK_RING) {
-        builder_insert_packed(b, b->ring_key[b->ring_pos], b->ring_fwd[b->ring_pos]);
+        builder_insert_packed(b, b->ring_key[b->ring_pos], b->ring_fwd[b->ring_pos], b->ring_tpos[b->ring_pos]);
         b->ring_pos = (b->ring_pos + 1u) & (SK_RING - 1u);
         b->ring_n--;
     }
@@ -292,13 +301,14 @@ static void builder_add_packed(builder *b, uint64_t key, int is_fwd)
     }
     b->ring_key[at] = key;
     b->ring_fwd[at] = (uint8_t)is_fwd;
+    b->ring_tpos[at] = tpos;
     b->ring_n++;
 }
 
 static void builder_drain(builder *b)
 {
     while (b->ring_n) {
-        builder_insert_packed(b, b->ring_key[b->ring_pos], b->ring_fwd[b->ring_pos]);
+        builder_insert_packed(b, b->ring_key[b->ring_pos], b->ring_fwd[b->ring_pos], b->ring_tpos[b->ring_pos]);
         b->ring_pos = (b->ring_pos + 1u) & (SK_RING - 1u);
         b->ring_n--;
     }
@@ -344,14 +354,25 @@ static int builder_record(void *user, char *seq, size_t len)
     uint32_t run = 0, soft = 0;
     size_t i;
     if (len + 1 < SK_K) { b->short_records++; return 0; }   /* reference: size_t underflow, crash */
+    /* room for this record in the 2-bit text (positions beyond 2^32 - 2 are not recorded: first_pos stays NO_POS) */
+    if ((b->text_n + len + 64) / 16 + 1 > b->text_cap_words) {
+        uint64_t want = b->text_cap_words ? b->text_cap_words * 2 : 1u << 16;
+        while (want < (b->text_n + len + 64) / 16 + 1) want *= 2;
+        b->text2 = (uint32_t *)realloc(b->text2, want * sizeof(uint32_t));
+        memset(b->text2 + b->text_cap_words, 0, (want - b->text_cap_words) * sizeof(uint32_t));
+        b->text_cap_words = want;
+    }
+    const uint64_t tbase = b->text_n;
     for (i = 0; i < len; i++) {
         uint32_t c = (uint8_t)seq[i], code = sk_code(c);
+        b->text2[(tbase + i) >> 4] |= (code & 3u) << (2u * (15u - (uint32_t)((tbase + i) & 15u)));
         fwd = ((fwd << 2) | code) & SK_KMASK62;
         rc = (rc >> 2) | ((uint64_t)(3u - code) << 60);
         run = sk_is_acgt(c) ? run + 1 : 0;
         soft = sk_is_hard_break(c) ? 0 : soft + 1;
         if (run >= SK_K) {
-            builder_add_packed(b, fwd > rc ? fwd : rc, fwd > rc);
+            const uint64_t tp = tbase + i - (SK_K - 1);
+            builder_add_packed(b, fwd > rc ? fwd : rc, fwd > rc, tp < NO_POS - 64u ? (uint32_t)tp : NO_POS);
         } else if (soft >= SK_K) {
             char u[SK_K], o[SK_K + 1];
             const char *w = seq + i - (SK_K - 1);
@@ -368,12 +389,13 @@ static int builder_record(void *user, char *seq, size_t len)
             if (pure) {                              /* e.g. U in the strain whose revcomp wins */
                 uint64_t key = 0;
                 for (j = 0; j < SK_K; j++) key = (key << 2) | sk_code((uint8_t)o[j]);
-                builder_add_packed(b, key, sign >= 0);
+                builder_add_packed(b, key, sign >= 0, NO_POS);
             } else {
                 builder_add_wide(b, o);
             }
         }
     }
+    b->text_n = tbase + len;
     return 0;
 }
 
@@ -488,12 +510,30 @@ static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
     ks->locality = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
     ks->wide_keys = (char *)malloc((size_t)(b->wn ? b->wn : 1) * 32);
     ks->wide_rows = (uint32_t *)malloc((size_t)(b->wn ? b->wn : 1) * sizeof(uint32_t));
+    ks->first_pos = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
+    /* locality order = the device's counter order: entries with a text position first, in text order (that is
+     * their insertion order), then the others (wide keys, keys met only through a U) in insertion order --
+     * the contract of sk_table_load_text */
+    uint32_t *newloc = (uint32_t *)malloc((size_t)(b->n ? b->n : 1) * sizeof(uint32_t));
+    {
+        uint32_t e, m = 0;
+        for (e = 0; e < b->n; e++) if (b->firstpos[e] != NO_POS) newloc[e] = m++;
+        for (e = 0; e < b->n; e++) if (b->firstpos[e] == NO_POS) newloc[e] = m++;
+    }
+    ks->text_bases = b->text_n < NO_POS - 64u ? (uint32_t)b->text_n : 0u;      /* 0: too long, no text stage */
+    ks->text2 = NULL;
+    if (ks->text_bases) {
+        const size_t words = (size_t)ks->text_bases / 16 + 4;
+        ks->text2 = (uint32_t *)calloc(words, sizeof(uint32_t));
+        memcpy(ks->text2, b->text2, ((size_t)ks->text_bases + 15) / 16 * sizeof(uint32_t));
+    }
     for (r = 0; r < b->n; r++) {
         uint64_t ent;
         if (r + 32 < b->n) { __builtin_prefetch(&b->order[rows[r + 32]]); __builtin_prefetch(&b->count[rows[r + 32]]); __builtin_prefetch(&b->fwd_first[rows[r + 32]]); }
         ent = b->order[rows[r]];
         ks->first_count[r] = b->count[rows[r]];
-        ks->locality[r] = rows[r] | (b->fwd_first[rows[r]] ? SK_LOCALITY_FWD : 0u);
+        ks->locality[r] = newloc[rows[r]] | (b->fwd_first[rows[r]] ? SK_LOCALITY_FWD : 0u);
+        ks->first_pos[r] = ks->text_bases ? b->firstpos[rows[r]] : NO_POS;
         if (ent & WIDE_FLAG) { ks->packed[r] = SK_KEY_NONE; wide_newrow[ent & 0xFFFFFFFFu] = r; }
         else ks->packed[r] = ent;
     }
@@ -503,6 +543,7 @@ static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
     }
     free(wide_newrow);
     free(rows);
+    free(newloc);
     return SK_OK;
 }
 
@@ -553,6 +594,7 @@ void skh_keyset_free(skh_keyset *ks)
 {
     if (!ks) return;
     free(ks->packed); free(ks->first_count); free(ks->locality); free(ks->wide_keys); free(ks->wide_rows);
+    free(ks->text2); free(ks->first_pos);
     memset(ks, 0, sizeof *ks);
 }
 
@@ -570,6 +612,8 @@ int skh_keyset_load(sk_ctx *ctx, const skh_keyset *ks, uint32_t ncols)
     int rc = sk_table_load_ex(ctx, ks->packed, ks->nrows, ncols, ks->locality);
     if (rc) return rc;
     rc = sk_table_load_wide(ctx, ks->wide_keys, ks->wide_rows, ks->nwide);
+    if (rc) return rc;
+    if (ks->text2 && ks->text_bases && ks->nrows && !getenv("SK_NO_TEXT")) rc = sk_table_load_text(ctx, ks->text2, ks->text_bases, ks->first_pos);
     if (rc) return rc;
     if (ks->nrows) rc = sk_counts_set(ctx, 0, ks->first_count);
     return rc;

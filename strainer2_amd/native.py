@@ -40,10 +40,10 @@ SK_E_OPEN = -5
 # every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load", "sk_table_load_ex",
-    "sk_table_load_wide", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
+    "sk_table_load_wide", "sk_table_load_text", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
     "sk_ticket_wait", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
-    "sk_counts_allreduce", "sk_comm_init", "sk_comm_destroy", "sk_comm_sum_u32", "sk_scan_timing", "sk_set_option", "sk_scan_stats", "sk_dev_alloc", "sk_dev_free",
+    "sk_counts_allreduce", "sk_comm_init", "sk_comm_destroy", "sk_comm_sum_u32", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
     "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
@@ -60,7 +60,8 @@ class _KeysetStruct(C.Structure):
                 ("packed", C.POINTER(C.c_uint64)), ("first_count", C.POINTER(C.c_uint32)),
                 ("locality", C.POINTER(C.c_uint32)),
                 ("wide_keys", C.POINTER(C.c_char)), ("wide_rows", C.POINTER(C.c_uint32)),
-                ("final_slots", C.c_uint32), ("short_records", C.c_uint64)]
+                ("final_slots", C.c_uint32), ("short_records", C.c_uint64),
+                ("text2", C.POINTER(C.c_uint32)), ("text_bases", C.c_uint32), ("first_pos", C.POINTER(C.c_uint32))]
 
 
 _SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
@@ -75,6 +76,7 @@ lib.sk_strerror.restype = C.c_char_p
 lib.sk_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
 lib.sk_table_load_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
 lib.sk_table_load_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+lib.sk_table_load_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
 lib.sk_scan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.sk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.sk_pinned_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64]
@@ -96,7 +98,6 @@ lib.sk_table_cols.restype = C.c_uint32
 lib.sk_counts_allreduce.argtypes = [C.c_void_p, C.c_void_p]
 lib.sk_scan_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
 lib.sk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
-lib.sk_scan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 lib.sk_dev_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64]
 lib.sk_dev_free.argtypes = [C.c_void_p, C.c_void_p]
 lib.sk_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -321,11 +322,6 @@ class KmerContext:
         n = C.c_uint64(0)
         self._ck(lib.sk_scan_timing(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
-
-    def scan_stats(self):
-        out = (C.c_uint64 * 3)()
-        self._ck(lib.sk_scan_stats(self._h, out))
-        return {"windows": out[0], "filter_loads": out[1], "table_probes": out[2]}
 
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

@@ -16,10 +16,9 @@ def pytest_configure(config):
        not os.path.exists(os.path.join(REPO, "strainer2_amd", "bin", "kmer_scrub_count")):
         subprocess.run(["make", "-C", os.path.join(REPO, "strainer2_amd", "csrc")], check=True,
                        stdout=subprocess.DEVNULL)
-    if not os.path.exists(os.path.join(REPO, "oracle", "libkso_oracle.so")) or \
-       not os.path.exists(os.path.join(REPO, "oracle", "kso_oracle")):
-        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "kso_oracle", "libkso_oracle.so"],
-                       check=True, stdout=subprocess.DEVNULL)
+    # the checker (oracle restatement; the reference binaries where /root/reference exists) is rebuilt by
+    # dependency, not by existence: a stale binary must never stand in for the current sources
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "all"], check=True, stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")

@@ -16,14 +16,14 @@
 #include "../../include/strainer_kmer.h"
 #include "../../strainer2_amd/csrc/sk_common.h"
 
-struct sk_ctx { uint64_t *key; uint32_t *row; uint32_t n, ncols; uint32_t *cols; const struct sk_batch *inflight; uint32_t type_col, inf_value; uint64_t cap; };
+struct sk_ctx { uint64_t *key, *rawkey; uint32_t *row, *loc; uint32_t n, ncols; uint32_t *cols; const struct sk_batch *inflight; uint32_t type_col, inf_value; uint64_t cap; };
 struct sk_batch { uint8_t *bytes; uint64_t nbytes; uint32_t *start; uint32_t nrec; };
 
 static int die(const char *what) { fprintf(stderr, "device call %s is outside the test double\n", what); abort(); return -1; }
 const char *sk_strerror(int c) { (void)c; return "stub"; }
 const char *sk_last_error(const sk_ctx *c) { (void)c; return "stub"; }
 int sk_ctx_create(sk_ctx **o, int d) { (void)d; *o = calloc(1, sizeof **o); return *o ? SK_OK : SK_E_NOMEM; }
-void sk_ctx_destroy(sk_ctx *c) { if (c) { free(c->key); free(c->row); free(c->cols); free(c); } }
+void sk_ctx_destroy(sk_ctx *c) { if (c) { free(c->key); free(c->row); free(c->cols); free(c->loc); free(c->rawkey); free(c); } }
 uint32_t sk_table_rows(const sk_ctx *c) { return c->n; }
 uint32_t sk_table_cols(const sk_ctx *c) { return c->ncols; }
 
@@ -33,7 +33,8 @@ int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t n, uint32_t ncols
 {
     kr *t = malloc((n + 1) * sizeof *t);
     uint32_t i;
-    (void)loc;
+    c->loc = malloc((n + 1) * 4); c->rawkey = malloc((n + 1) * 8);
+    for (i = 0; i < n; i++) { c->loc[i] = loc ? loc[i] : i; c->rawkey[i] = keys[i]; }
     for (i = 0; i < n; i++) { t[i].k = keys[i]; t[i].r = i; }
     qsort(t, n, sizeof *t, kr_cmp);
     c->key = malloc((n + 1) * 8); c->row = malloc((n + 1) * 4); c->cols = calloc((size_t)n * ncols + 1, 4);
@@ -43,6 +44,30 @@ int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t n, uint32_t ncols
     return SK_OK;
 }
 int sk_table_load_wide(sk_ctx *c, const char *k, const uint32_t *r, uint32_t n) { (void)c; (void)k; (void)r; return n ? die("sk_table_load_wide") : SK_OK; }
+/* checks the contract of sk_table_load_text on what the host builder hands over: rows with a position first in
+ * locality order, positions ascending, and the text at a row's position IS the row's key (in the orientation
+ * the locality flag names) */
+int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nbases, const uint32_t *first_pos)
+{
+    uint32_t i, m = 0, *pos_by_loc = malloc((c->n + 1) * 4);
+    for (i = 0; i < c->n; i++) pos_by_loc[c->loc[i] & 0x7FFFFFFFu] = first_pos[i];
+    while (m < c->n && pos_by_loc[m] != 0xFFFFFFFFu) m++;
+    for (i = 0; i < c->n; i++) {
+        if (i >= m && pos_by_loc[i] != 0xFFFFFFFFu) return die("sk_table_load_text: rows with a position must come first");
+        if (i < m && (pos_by_loc[i] + 31u > nbases || (i && pos_by_loc[i] <= pos_by_loc[i - 1]))) return die("sk_table_load_text: positions must ascend");
+    }
+    for (i = 0; i < c->n; i++) {
+        uint64_t k = 0, rc;
+        uint32_t j;
+        if (first_pos[i] == 0xFFFFFFFFu) continue;
+        for (j = 0; j < 31; j++) { const uint32_t q = first_pos[i] + j; k = (k << 2) | ((text2[q >> 4] >> (2 * (15 - (q & 15)))) & 3u); }
+        rc = sk_revcomp62(k);
+        if ((k > rc ? k : rc) != c->rawkey[i]) return die("sk_table_load_text: the text at first_pos is not the row's key");
+        if (((c->loc[i] >> 31) != 0) != (k > rc)) return die("sk_table_load_text: orientation flag does not match the text");
+    }
+    free(pos_by_loc);
+    return SK_OK;
+}
 int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in) { memcpy(c->cols + (size_t)col * c->n, in, (size_t)c->n * 4); return SK_OK; }
 int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out) { memcpy(out, c->cols + (size_t)col * c->n, (size_t)c->n * 4); return SK_OK; }
 

@@ -13,6 +13,7 @@
 static int unreachable(const char *name) { fprintf(stderr, "device call %s in a host-only test\n", name); abort(); return -1; }
 int sk_table_load_ex(sk_ctx *c, const uint64_t *k, uint32_t n, uint32_t nc, const uint32_t *l) { (void)c; (void)k; (void)n; (void)nc; (void)l; return unreachable("sk_table_load_ex"); }
 int sk_table_load_wide(sk_ctx *c, const char *k, const uint32_t *r, uint32_t n) { (void)c; (void)k; (void)r; (void)n; return unreachable("sk_table_load_wide"); }
+int sk_table_load_text(sk_ctx *c, const uint32_t *t, uint32_t n, const uint32_t *f) { (void)c; (void)t; (void)n; (void)f; return unreachable("sk_table_load_text"); }
 int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in) { (void)c; (void)col; (void)in; return unreachable("sk_counts_set"); }
 int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out) { (void)c; (void)col; (void)out; return unreachable("sk_counts_fetch"); }
 int sk_scan_stream(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col) { (void)c; (void)s; (void)n; (void)col; return unreachable("sk_scan_stream"); }

@@ -54,7 +54,7 @@ def test_scan_count_fuzz(seed):
     assert t.build_stream(sstream, short_policy=1) == 0          # (records under k-1 bases: skipped, as the product does)
     with sk.KmerContext(0) as c:
         if seed % 5 == 0:
-            c.set_option("kernel", 1)                  # the previous-generation kernel now and then
+            c.set_option("text_stage", 0)              # every window probed on its own now and then
         c.load_keyset(ks, 4)
         third = len(data) // 3
         cuts = [0, data.rfind(b"\n", 0, third) + 1, data.rfind(b"\n", 0, 2 * third) + 1, len(data)]

@@ -125,11 +125,11 @@ def test_scan_stream_fuzz_vs_oracle(ctx, seed, junk):
     assert ocounts[:, 1:].sum() > 1000          # the test is not vacuous
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
-def test_both_scan_kernels_vs_oracle(kernel):
-    """the grid kernel (default) and the minimizer kernel of the previous generation, selected explicitly,
+@pytest.mark.parametrize("text_stage", [1, 0])
+def test_both_stage2_paths_vs_oracle(text_stage):
+    """stage 2 with the strain's text (seed and verify, default) and without it (every window probed on its own),
     on a stream that crosses several tiles with junk, short records and strain reads"""
-    rng = random.Random(77 + kernel)
+    rng = random.Random(77 + text_stage)
     strain = _synth.rand_dna(rng, 50_000)
     sstream = strain + b"\n"
     ks = sk.Keyset.from_stream(sstream)
@@ -138,7 +138,7 @@ def test_both_scan_kernels_vs_oracle(kernel):
     data = _synth.fuzz_stream(rng, strain, 3000, p_junk=0.003, min_len=0, max_len=400)
     assert len(data) > 5 * 32768
     with sk.KmerContext(0) as c:
-        c.set_option("kernel", kernel)
+        c.set_option("text_stage", text_stage)
         c.load_keyset(ks, 4)
         c.scan_stream(data, 2)
         t.scan_stream(data, 2)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""tools/exp_grid.py -- one process, many variants of the scan kernel (options, ablations, strain-read fractions).
+
+Prints, per variant, the average launch time of the scan kernel (HIP events on the library's stream).  Under
+`rocprofv3 --kernel-trace --pmc ...` the launches come out in the order of the variants, LAUNCHES per variant
+(tools/exp_grid_pmc.py assigns them).  Run on the GPU box.
+
+  python3 tools/exp_grid.py [--reads N] [--launches L] [--variants name,name,...]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+# name -> (hit_frac, options, uncached stream)
+VARIANTS = {
+    "base_h0":      (0.0,  {}, False),
+    "base_h2":      (0.02, {}, False),
+    "nol2_h0":      (0.0,  {"ablate": 5}, False),
+    "nol2_h2":      (0.02, {"ablate": 5}, False),
+    "l2hit_h2":     (0.02, {"ablate": 4}, False),
+    "l1hit_h2":     (0.02, {"ablate": 6}, False),
+    "nofilt_h2":    (0.02, {"ablate": 1}, False),
+    "g2048_h0":     (0.0,  {"grid_kib": 2048}, False),
+    "g2048_h2":     (0.02, {"grid_kib": 2048}, False),
+    "g1536_h2":     (0.02, {"grid_kib": 1536}, False),
+    "g4096_h2":     (0.02, {"grid_kib": 4096}, False),
+    "g8192_h2":     (0.02, {"grid_kib": 8192}, False),
+    "unc_h0":       (0.0,  {}, True),
+    "unc_h2":       (0.02, {}, True),
+    "unc_g2048_h2": (0.02, {"grid_kib": 2048}, True),
+    "base_h30":     (0.3,  {}, False),
+    "base_h100":    (1.0,  {}, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=4_000_000)
+    ap.add_argument("--launches", type=int, default=4)
+    ap.add_argument("--variants", default=",".join(VARIANTS))
+    args = ap.parse_args()
+    names = [v for v in args.variants.split(",") if v]
+    from strainer2_amd import synth
+    import strainer2_amd as sk
+
+    contigs = synth.make_strain()
+    sstream = synth.strain_stream(contigs)
+    ks = sk.Keyset.from_stream(sstream)
+    reads_by_frac = {}
+    out = []
+    for name in names:
+        frac, opts, unc = VARIANTS[name]
+        if frac not in reads_by_frac:
+            reads_by_frac[frac] = synth.make_reads(contigs, args.reads, 150, hit_frac=frac, seed=synth.SEED + 1)
+        reads, nbases = reads_by_frac[frac]
+        ctx = sk.KmerContext(0)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        if unc:
+            ctx.set_option("dev_alloc_uncached", 1)
+        ctx.load_keyset(ks, 4)
+        dev = ctx.dev_alloc(reads.size)
+        ctx.dev_upload(dev, reads)
+        ctx.scan_device(dev, int(reads.size), 2)           # warm-up (counted as a launch of the variant)
+        ctx.sync()
+        ctx.scan_timing(reset=True)
+        for _ in range(args.launches - 1):
+            ctx.scan_device(dev, int(reads.size), 2)
+        ctx.sync()
+        ms, n = ctx.scan_timing(reset=True)
+        hits = int(ctx.counts(2).astype(np.uint64).sum()) // args.launches
+        rec = {"variant": name, "ms": ms / max(n, 1), "gbase_s": nbases / (ms / max(n, 1) * 1e-3) / 1e9, "hits_per_pass": hits}
+        out.append(rec)
+        print(json.dumps(rec), flush=True)
+        ctx.dev_free(dev)
+        ctx.close()
+    print("ORDER " + ",".join(names), flush=True)
+
+
+if __name__ == "__main__":
+    main()
