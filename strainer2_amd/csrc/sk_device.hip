@@ -56,11 +56,11 @@
 #define SK_STREAM_POLICY 0
 #endif
 #define SK_NCHUNK_GRID  (SK_NCHUNK + 1)
-#define SK_AGG_LOG2     9
+#define SK_AGG_LOG2     8
 #define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
-#ifndef SK_ANCHOR
-#define SK_ANCHOR       16u
+#ifndef SK_ANCHOR_CH
+#define SK_ANCHOR_CH    4u                  // stage 2: one table probe per this many consecutive surviving chunks (and the first)
 #endif
 //                 // stage 2: one hash probe per this many consecutive windows
 
@@ -93,6 +93,7 @@ __device__ __forceinline__ uint64_t sk_slot_key(const sk_u4 e) { return ((uint64
 // hits on rows whose type column holds `inf_value`) and log the latter as (position, row).
 struct sk_sink {
     uint32_t       *counts;        // COUNT: counts + col * nrows
+    uint32_t       *diff;          // COUNT: difference array of the scanned column [nrows + 1] (sk_diff_flush folds it in)
     const uint32_t *rec_start;     // TALLY: batch offset of every record's first byte, ascending
     const uint32_t *tile_first;    // TALLY: per 32768-byte tile, index of the first record starting in or after it
     uint32_t        nrec;
@@ -238,6 +239,17 @@ __device__ __forceinline__ uint32_t sk_revcomp32(uint32_t x)              // 16 
     return ~y;
 }
 
+// x = XOR of two packed 16-mers (first base in the top two bits): bit i of the result <=> base i differs
+// (the bit order of the "not ACGT" masks)
+__device__ __forceinline__ uint32_t sk_mismatch16(uint32_t x)
+{
+    uint32_t z = __builtin_bitreverse32((x | (x >> 1)) & 0x55555555u) >> 1;      // base i at bit 2i
+    z = (z | (z >> 1)) & 0x33333333u;
+    z = (z | (z >> 2)) & 0x0F0F0F0Fu;
+    z = (z | (z >> 4)) & 0x00FF00FFu;
+    return (z | (z >> 8)) & 0xFFFFu;
+}
+
 // both orientations of the window that ends at tile-relative position e, from the LDS records: packed 31-mers,
 // first base in bits 61..60; the canonical form is the larger (src/genome_compare.c:1100-1120)
 __device__ __forceinline__ void sk_window_keys(const uint32_t *rec, uint32_t e, uint64_t &fwd, uint64_t &rc)
@@ -328,9 +340,10 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 {
     __shared__ __attribute__((aligned(16))) uint32_t rec[(SK_NREC + 1) * SK_REC_DW];
     __shared__ uint16_t wq_all[SK_WAVES][128 + 16];              // below 128 before a push of at most 16
-    // COUNT mode: rows this workgroup has already counted once in this tile; further hits on them are added
-    // up here and flushed with one atomic per row at the end.  Reads that repeat (duplicates, conserved or
-    // low-complexity k-mers) would otherwise serialise on a few counters in the L2 (same-address atomics).
+    __shared__ uint16_t cq_all[SK_WAVES][64 * SK_SPAN_CH];       // the wave's surviving chunks
+    // COUNT mode: difference-array indices this workgroup has already touched once in this tile; further updates
+    // of them are added up here and flushed with one atomic each at the end.  Reads that repeat (duplicates)
+    // would otherwise serialise on a few words in the L2 (same-address atomics).
     __shared__ uint2 agg[SK_AGG];
 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
@@ -437,219 +450,255 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     }
 
     // ================= stage 2: the windows of the surviving chunks ==============================
-    // Up to 128 queued windows at a time, two per lane.  Seed and verify: every SK_ANCHOR-th window of a
-    // stretch of consecutive positions (and its first one) is an ANCHOR and pays a random probe of the HBM
-    // table; a hit comes back with the row's place in the strain's text and its orientation, i.e. with the
-    // diagonal the read lies on.  Every other window of the stretch then takes the nearest anchor that hit,
-    // reads the 31 bases of the strain's text where the diagonal puts it (2-bit text, 1.25 MB for 5 Mbp:
-    // neighbouring lanes share its lines) and compares all 62 bits with its own window -- as exact as a probe;
-    // the row is the rank of that text position (one 16-byte block of the rank map).  Windows the text does
-    // not settle (a read error, a repeat, no anchor hit in the stretch) fall back to the hash table, behind
-    // a question to the L2-resident level-1 filter about a 16-mer of theirs that holds the mismatch.
-    auto probe_some = [&](uint32_t n) {
+    // Seed and verify, a CHUNK per lane (16 windows at a time, 64 chunks = up to 1024 windows per round).
+    //   seed    a few chunks of every stretch of consecutive surviving chunks (its first, then every
+    //           SK_ANCHOR_CH-th) probe ONE window in the HBM table; a hit comes back with the row's place in the
+    //           strain's text and its orientation: the diagonal the read lies on.
+    //   verify  every chunk of the stretch takes the nearest seed and compares its 48 bases (the chunk and its
+    //           two neighbours: all that its 16 windows cover) with the strain's 2-bit text on that diagonal,
+    //           three 32-bit XORs; mismatching and non-ACGT bases together give the verified windows by the same
+    //           31-run bit trick that gives the live ones.  A verified window IS the text's k-mer at its place
+    //           (all 62 bits were compared), and its row is the rank of that place (rank map: 16 bytes per 64
+    //           positions) -- unless that place is a repeat of an earlier k-mer (no bit there), which goes to
+    //   count   COUNT mode: verified windows with consecutive rows are consecutive counters, so a run of them is
+    //           "+1 at its first row, -1 behind its last" in a difference array that the host side folds into the
+    //           column by a prefix sum before anyone looks (sk_diff_flush); runs that continue in the next chunk
+    //           cancel their inner ends.  Two atomics per read and strand instead of one per window.
+    //           TALLY mode: the verified windows are spread over the lanes again, one each, for the per-read tallies.
+    //   rest    windows the diagonal does not explain (a read error, a repeat, no seed hit) are queued one by one,
+    //           asked about in the L2-resident level-1 filter (first and last 16-mer: they cover all 31 bases)
+    //           and only then probed in the table.
+    auto count_row = [&](uint32_t row, uint32_t pos) { sk_on_hit<false, ABLATE == 3>(sink, row, pos); };
+    // difference-array update through the workgroup's table of indices already touched in this tile
+    auto diff_add = [&](uint32_t idx, uint32_t delta) {
+        const uint32_t a = (idx * 0x9E3779B1u) >> (32 - SK_AGG_LOG2);
+        const uint32_t old = atomicCAS(&agg[a].x, 0xFFFFFFFFu, idx);
+        if (old == idx) atomicAdd(&agg[a].y, delta);
+        else if (ABLATE != 3) atomicAdd(&sink.diff[idx], delta);
+    };
+
+    auto probe_windows = [&](uint32_t n) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         qw -= n;
-        bool act[2], anchor[2];
-        uint32_t e[2], pos[2], kk[2], hit[2], a_pos[2], a_dir[2], lo_lane[2], hi_lane[2];
-        uint64_t fwd[2], rc[2], cn[2];
+        bool act[2];
+        uint32_t e[2], hit[2];
+        uint64_t cn[2];
+        uint2 q0[2], q1[2];
+        uint32_t g0[2], g1[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
             const uint32_t idx = lane + 64u * (uint32_t)s2;
             act[s2] = idx < n;
-            e[s2] = act[s2] ? wq[qw + idx] : 0xFFFF0000u + lane * 2u;           // inactive: never consecutive
-            fwd[s2] = rc[s2] = 0ull;
-            if (act[s2]) sk_window_keys(rec, e[s2], fwd[s2], rc[s2]);
-            cn[s2] = fwd[s2] > rc[s2] ? fwd[s2] : rc[s2];
-            pos[s2] = (uint32_t)tile0 + e[s2];
+            e[s2] = act[s2] ? wq[qw + idx] : 0u;
+            uint64_t fwd = 0ull, rc = 0ull;
+            if (act[s2]) sk_window_keys(rec, e[s2], fwd, rc);
+            cn[s2] = fwd > rc ? fwd : rc;
+            hit[s2] = 0xFFFFFFFFu;
+            const uint32_t w0 = (uint32_t)(cn[s2] >> 30), w1 = (uint32_t)cn[s2];
+            const uint32_t r0 = sk_revcomp32(w0), r1 = sk_revcomp32(w1);
+            g0[s2] = sk_gmix(w0 < r0 ? w0 : r0); g1[s2] = sk_gmix(w1 < r1 ? w1 : r1);
+            q0[s2] = q1[s2] = make_uint2(0u, 0u);
+            if (act[s2]) { q0[s2] = table.grid1[sk_grid1_block(g0[s2], table.grid1_blocks)]; q1[s2] = table.grid1[sk_grid1_block(g1[s2], table.grid1_blocks)]; }
         }
         if (ABLATE == 2) { __builtin_amdgcn_wave_barrier(); return; }
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            const uint32_t e_prev = (uint32_t)__shfl_up((int)e[s2], 1);
-            const bool first = (lane == 0u) | (e[s2] != e_prev + 1u);          // first window of a stretch
-            const unsigned long long fm = __ballot(first);
-            lo_lane[s2] = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
-            const unsigned long long above = lane == 63u ? 0ull : fm & ~((2ull << lane) - 1ull);
-            hi_lane[s2] = above ? (uint32_t)__builtin_ctzll(above) - 1u : 63u; // last lane of the stretch
-            kk[s2] = lane - lo_lane[s2];                                       // offset inside the stretch
-            anchor[s2] = act[s2] & ((kk[s2] & (SK_ANCHOR - 1u)) == 0u);
-            hit[s2] = 0xFFFFFFFFu; a_pos[s2] = 0x7FFFFFFFu; a_dir[s2] = 0u;
-        }
-        // both slots' anchors probe the hash table together
-        uint32_t slot[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) slot[s2] = sk_slot0(sk_khash(cn[s2]), table.mask);
-        sk_u4 ent[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) ent[s2] = anchor[s2] ? table.slots[slot[s2]] : (sk_u4){0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            if (anchor[s2]) {
-                sk_u4 en = ent[s2];
-                uint32_t sl = slot[s2];
-                for (;;) {
-                    const uint64_t key = sk_slot_key(en);
-                    if (key == cn[s2]) {
-                        hit[s2] = en.z;
-                        a_pos[s2] = en.w >> 1;
-                        a_dir[s2] = (uint32_t)(fwd[s2] > rc[s2]) ^ (en.w & 1u);  // 0: the read runs along the strain, 1: against it
-                        break;
-                    }
-                    if (key == SK_EMPTY64) break;
-                    sl = (sl + 1u) & table.mask;
-                    en = table.slots[sl];
-                }
-            }
-        }
-        // followers: the text at the place the nearest anchor that hit puts them
-        uint32_t need[2];                                                      // 0 settled, 1 probe the table, 2 ask the filter first
-        uint64_t diff[2], cmpk[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            const bool seed = anchor[s2] & (hit[s2] != 0xFFFFFFFFu) & (a_pos[s2] != 0x7FFFFFFFu);
-            const unsigned long long sm = __ballot(seed);
-            const unsigned long long span = (hi_lane[s2] == 63u ? ~0ull : ((2ull << hi_lane[s2]) - 1ull)) & ~((1ull << lo_lane[s2]) - 1ull);
-            const unsigned long long cand = table.text2 ? sm & span : 0ull;
-            const unsigned long long below = cand & ((1ull << lane) - 1ull);
-            const uint32_t src = below ? 63u - (uint32_t)__clzll(below) : cand ? (uint32_t)__builtin_ctzll(cand) : lane;
-            const uint32_t s_pos = (uint32_t)__shfl((int)a_pos[s2], (int)src);
-            const uint32_t s_dir = (uint32_t)__shfl((int)a_dir[s2], (int)src);
-            need[s2] = 0u; diff[s2] = 0ull; cmpk[s2] = 0ull;
-            if (act[s2] & !anchor[s2]) {
-                need[s2] = 2u;
-                const uint32_t d = lane - src;                                 // (two's complement when the anchor is above)
-                const uint32_t q = s_dir ? s_pos - d : s_pos + d;              // wraps below 0 -> beyond the text
-                if (cand && q < table.text_bases && q + SK_K <= table.text_bases) {
-                    const uint64_t tk = sk_text_key(table.text2, q);
-                    const sk_u4 rk = table.rank[q >> 6];
-                    cmpk[s2] = s_dir ? rc[s2] : fwd[s2];
-                    diff[s2] = tk ^ cmpk[s2];
-                    if (diff[s2] == 0ull) {
-                        const uint64_t m64 = ((uint64_t)rk.z << 32) | rk.y;
-                        const uint32_t bit = q & 63u;
-                        if ((m64 >> bit) & 1ull) { hit[s2] = rk.x + (uint32_t)__popcll(m64 & ((1ull << bit) - 1ull)); need[s2] = 0u; }
-                        else need[s2] = 1u;                                    // a repeat of an earlier k-mer (or a special row): its row is elsewhere
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            if (need[s2] == 2u) {
-                // Not where the diagonal says: mostly a read error, and then ~30 windows in a row end up here.  Before
-                // the random table probe, ask the level-1 filter (L2-resident) about 16-mers of the window: a real
-                // k-mer always passes (no false negatives), a window with a wrong base fails on a 16-mer that holds it.
-                bool maybe = true;
-                if (diff[s2]) {
-                    // the first mismatching base of the compared key (the window along or against the strain: a 16-mer
-                    // of either is a 16-mer of the window up to orientation, which the filter ignores) and a 16-mer of
-                    // that key around it
-                    const uint32_t xt = ((uint32_t)__clzll(diff[s2]) - 2u) >> 1;           // 0..30
-                    const uint32_t st = xt < 8u ? 0u : xt > 23u ? 15u : xt - 8u;            // bases st .. st+15 hold base xt
-                    maybe = sk_grid1_has(table, (uint32_t)(cmpk[s2] >> (30u - 2u * st)));
-                }
-                if (maybe) {
-                    // first and last 16-mer: together they cover all 31 bases
-                    maybe = sk_grid1_has(table, (uint32_t)(cn[s2] >> 30)) && sk_grid1_has(table, (uint32_t)cn[s2]);
-                }
-                if (maybe) need[s2] = 1u;
-            }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            if (need[s2] == 1u) { uint32_t unused; hit[s2] = sk_find(cn[s2], table, &unused); }
-        }
-        if (TALLY) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) sk_tally_wave(sink, act[s2] ? hit[s2] : 0xFFFFFFFFu, pos[s2], lane);
-        } else {
-            // first sighting of a row in this tile: count it in HBM now (neighbouring counters coalesce); seen
-            // before: add it up in LDS; its table slot taken by another row: count it in HBM as well.  Both
-            // slots' LDS round trips are in flight together.
-            uint32_t a[2], old[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                a[s2] = (hit[s2] * 0x9E3779B1u) >> (32 - SK_AGG_LOG2);
-                old[s2] = 0xFFFFFFFFu;
-                if (hit[s2] != 0xFFFFFFFFu) old[s2] = atomicCAS(&agg[a[s2]].x, 0xFFFFFFFFu, hit[s2]);
+        for (int s2 = 0; s2 < 2; s2++)
+            if (act[s2] && sk_grid_test(q0[s2], sk_grid1_bits(g0[s2])) && sk_grid_test(q1[s2], sk_grid1_bits(g1[s2]))) {
+                uint32_t unused;
+                hit[s2] = sk_find(cn[s2], table, &unused);
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                if (hit[s2] == 0xFFFFFFFFu) continue;
-                if (old[s2] == hit[s2]) atomicAdd(&agg[a[s2]].y, 1u);
-                else sk_on_hit<false, ABLATE == 3>(sink, hit[s2], pos[s2]);
-            }
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (TALLY) sk_tally_wave(sink, hit[s2], (uint32_t)tile0 + e[s2], lane);
+            else if (hit[s2] != 0xFFFFFFFFu) count_row(hit[s2], (uint32_t)tile0 + e[s2]);
         }
         __builtin_amdgcn_wave_barrier();
     };
 
-    // live windows of the surviving chunks, computed by their own threads (all lanes in parallel):
-    // bit o of a chunk's mask <=> the 31 bases ending at chunk start + 15 + o are all ACGT.  The masks
-    // of a thread's eight chunks are packed two to a register for the hand-over below.
-    uint32_t lv[4] = {0u, 0u, 0u, 0u};
-    if (m) {
-        uint32_t inv[SK_SPAN_CH + 2];                              // chunk before the span, the span, chunk after
-        inv[0] = sk_chunk_inv(rec, (tid + 1u) * SK_SPAN_CH - 1u);
-        inv[SK_SPAN_CH + 1] = sk_chunk_inv(rec, (tid + 2u) * SK_SPAN_CH);
+    // the wave's surviving chunks (index in the tile), compacted in stream order
+    uint16_t *const cq = cq_all[tid >> 6];
+    uint32_t nq;
+    {
+        uint32_t incl = (uint32_t)__popc(m);
 #pragma unroll
-        for (int i = 0; i < SK_SPAN_CH; i++) {
-            const uint32_t ipair = my[8 + (i >> 1)];
-            inv[i + 1] = (i & 1) ? ipair >> 16 : ipair & 0xFFFFu;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= (uint32_t)d) incl += up;
         }
-        uint32_t keep = 0;
+        nq = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t at = incl - (uint32_t)__popc(m);
 #pragma unroll
-        for (int i = 0; i < SK_SPAN_CH; i++) {
-            if (!((m >> i) & 1u)) continue;
-            const uint64_t v = ~((uint64_t)inv[i] | ((uint64_t)inv[i + 2] << 32)) & 0x0000FFFFFFFFFFFFull;   // (the chunk itself is clean)
+        for (int i = 0; i < SK_SPAN_CH; i++)
+            if ((m >> i) & 1u) cq[at++] = (uint16_t)(tid * SK_SPAN_CH + (uint32_t)i);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    for (uint32_t b0 = 0; b0 < nq; b0 += 64u) {                   // (wave-uniform)
+        const bool act = b0 + lane < nq;
+        const uint32_t ch = act ? cq[b0 + lane] : 0x7FFF0000u + 2u * lane;     // inactive: never consecutive
+        // live windows of the chunk: bit j <=> the 31 bases ending at chunk start + 15 + j are all ACGT (the chunk
+        // itself is clean: the masks of its two neighbours decide), and the window's end is not before emit_begin
+        uint32_t live = 0u, inv_prev = 0u, inv_next = 0u;
+        if (act) {
+            inv_prev = sk_chunk_inv(rec, ch + SK_SPAN_CH - 1u);
+            inv_next = sk_chunk_inv(rec, ch + SK_SPAN_CH + 1u);
+            const uint64_t v = ~((uint64_t)inv_prev | ((uint64_t)inv_next << 32)) & 0x0000FFFFFFFFFFFFull;
             uint64_t rr = v & (v << 1);
             rr &= rr << 2;
             rr &= rr << 4;
             rr &= rr << 8;
             rr &= rr << 15;                                        // runs of >= 31
-            uint32_t live16 = (uint32_t)(rr >> 31) & 0xFFFFu;
-            const uint64_t p0 = tile0 + tid * SK_SPAN + (uint32_t)i * 16u + 15u;   // END of the chunk's first window
+            live = (uint32_t)(rr >> 31) & 0xFFFFu;
+            const uint64_t p0 = tile0 + ch * 16u + 15u;            // END of the chunk's first window
             if (p0 < emit_begin) {
                 const uint64_t dlt = emit_begin - p0;
-                live16 = dlt >= 16u ? 0u : live16 & (0xFFFFu << (uint32_t)dlt);
+                live = dlt >= 16u ? 0u : live & (0xFFFFu << (uint32_t)dlt);
             }
-            lv[i >> 1] |= live16 << (16 * (i & 1));
-            keep |= (uint32_t)(live16 != 0u) << i;
         }
-        m = keep;
-    }
-
-    // hand-over to the wave's window queue: one thread's chunks after the other, so that consecutive
-    // windows sit in consecutive queue slots (everything in this loop is wave-uniform)
-    unsigned long long lanes = __ballot(m != 0u);
-    while (lanes) {
-        const int l = __builtin_ctzll(lanes);
-        lanes &= lanes - 1ull;
-        uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)lv[0], l), l1 = (uint32_t)__builtin_amdgcn_readlane((int)lv[1], l);
-        const uint32_t l2 = (uint32_t)__builtin_amdgcn_readlane((int)lv[2], l), l3 = (uint32_t)__builtin_amdgcn_readlane((int)lv[3], l);
-        const uint32_t t0 = (tid & ~63u) + (uint32_t)l;           // the thread whose chunks these are
-        while (mm) {
-            const uint32_t i = (uint32_t)__builtin_ctz(mm);
-            mm &= mm - 1u;
-            const uint32_t pair = (i >> 1) == 0u ? l0 : (i >> 1) == 1u ? l1 : (i >> 1) == 2u ? l2 : l3;
-            const uint32_t live16 = (pair >> (16u * (i & 1u))) & 0xFFFFu;
-            const uint32_t e0 = t0 * SK_SPAN + i * 16u + 15u;     // tile-relative END of the chunk's first window
-            if (lane < 16u && ((live16 >> lane) & 1u))
-                wq[qw + (uint32_t)__popc(live16 & ((1u << lane) - 1u))] = (uint16_t)(e0 + lane);
-            qw += (uint32_t)__popc(live16);
-            if (qw >= 128u) probe_some(128u);
+        uint32_t fb = live;                                       // windows left to the one-by-one path
+        if (table.text2 != nullptr) {
+            const uint32_t ch_prev = (uint32_t)__shfl_up((int)ch, 1);
+            const bool first = (lane == 0u) | (ch != ch_prev + 1u);
+            const unsigned long long fm = __ballot(first);
+            const uint32_t lo_lane = 63u - (uint32_t)__clzll(fm & (~0ull >> (63u - lane)));
+            const unsigned long long above = lane == 63u ? 0ull : fm & ~((2ull << lane) - 1ull);
+            const uint32_t hi_lane = above ? (uint32_t)__builtin_ctzll(above) - 1u : 63u;
+            const uint32_t kk = lane - lo_lane;
+            // ---- seed: one window of the chunk (its last live one: it reaches furthest into the read) in the table
+            const bool anchor = act & (live != 0u) & ((kk & (SK_ANCHOR_CH - 1u)) == 0u);
+            uint32_t a_dir = 0u, a_diag = 0u;
+            bool seed = false;
+            if (anchor) {
+                const uint32_t j = 31u - (uint32_t)__clz((int)live);
+                const uint32_t e = ch * 16u + 15u + j;                         // tile-relative END of that window
+                uint64_t fwd, rc;
+                sk_window_keys(rec, e, fwd, rc);
+                const uint64_t cn = fwd > rc ? fwd : rc;
+                uint32_t sl = sk_slot0(sk_khash(cn), table.mask);
+                for (;;) {
+                    const sk_u4 en = table.slots[sl];
+                    const uint64_t key = sk_slot_key(en);
+                    if (key == cn) {
+                        const uint32_t tp = en.w >> 1;
+                        if (tp != 0x7FFFFFFFu) {
+                            seed = true;
+                            a_dir = (uint32_t)(fwd > rc) ^ (en.w & 1u);        // 0: the read runs along the strain, 1: against it
+                            // text position of tile-relative stream offset x: along D + x, against D - x
+                            const uint32_t xs = e - 30u;                       // the window's first base (wraps below 0: fine, mod 2^32)
+                            a_diag = a_dir ? tp + 30u + xs : tp - xs;
+                        }
+                        break;
+                    }
+                    if (key == SK_EMPTY64) break;
+                    sl = (sl + 1u) & table.mask;
+                }
+            }
+            // ---- every chunk takes the nearest seed of its stretch
+            const unsigned long long sm = __ballot(seed);
+            const unsigned long long span = (hi_lane == 63u ? ~0ull : ((2ull << hi_lane) - 1ull)) & ~((1ull << lo_lane) - 1ull);
+            const unsigned long long cand = sm & span;
+            const unsigned long long below = cand & ((2ull << lane) - 1ull);   // (itself included)
+            const uint32_t src = below ? 63u - (uint32_t)__clzll(below) : cand ? (uint32_t)__builtin_ctzll(cand) : lane;
+            const uint32_t dg = (uint32_t)__shfl((int)a_diag, (int)src);
+            const uint32_t dir = (uint32_t)__shfl((int)a_dir, (int)src);
+            bool has = act & (cand != 0ull) & (live != 0u);
+            // ---- verify: the 48 bases of chunks ch-1, ch, ch+1 against the text on the diagonal
+            uint32_t hits = 0u, bits16 = 0u, r0 = 0u;                          // (in ascending text position: bit a)
+            const uint32_t x0 = ch * 16u - 16u;                                // tile-relative offset of chunk ch-1
+            const uint32_t tq = dir ? dg - x0 - 47u : dg + x0;                 // lowest text position of the 48
+            has = has && tq < table.text_bases && tq + 48u <= table.text_bases;
+            if (has) {
+                const uint32_t wi = tq >> 4, o2 = 2u * (tq & 15u);
+                const uint32_t t0 = table.text2[wi], t1 = table.text2[wi + 1u], t2 = table.text2[wi + 2u], t3 = table.text2[wi + 3u];
+                const uint32_t a0 = (uint32_t)(((((uint64_t)t0 << 32) | t1) << o2) >> 32);
+                const uint32_t a1 = (uint32_t)(((((uint64_t)t1 << 32) | t2) << o2) >> 32);
+                const uint32_t a2 = (uint32_t)(((((uint64_t)t2 << 32) | t3) << o2) >> 32);
+                const uint32_t cid = ch + SK_SPAN_CH;                          // record 0 = the 8 chunks before the tile
+                const uint32_t w0 = rec[((cid - 1u) >> 3) * SK_REC_DW + ((cid - 1u) & 7u)];
+                const uint32_t w1 = rec[(cid >> 3) * SK_REC_DW + (cid & 7u)];
+                const uint32_t w2 = rec[((cid + 1u) >> 3) * SK_REC_DW + ((cid + 1u) & 7u)];
+                const uint32_t m0 = sk_mismatch16(w0 ^ (dir ? sk_revcomp32(a2) : a0)) | inv_prev;
+                const uint32_t m1 = sk_mismatch16(w1 ^ (dir ? sk_revcomp32(a1) : a1));
+                const uint32_t m2 = sk_mismatch16(w2 ^ (dir ? sk_revcomp32(a0) : a2)) | inv_next;
+                const uint64_t good = ~((uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32)) & 0x0000FFFFFFFFFFFFull;
+                uint64_t rr = good & (good << 1);
+                rr &= rr << 2;
+                rr &= rr << 4;
+                rr &= rr << 8;
+                rr &= rr << 15;                                                // runs of >= 31
+                const uint32_t ver16 = (uint32_t)(rr >> 31) & live;            // bit j: the window ending at chunk start + 15 + j
+                // rank map: the 16 windows start at 16 consecutive text positions from qmin up
+                const uint32_t qmin = tq + 1u;
+                const sk_u4 ra = table.rank[qmin >> 6], rb = table.rank[(qmin >> 6) + 1u];
+                const uint32_t off = qmin & 63u;
+                const uint64_t ma = ((uint64_t)ra.z << 32) | ra.y, mb = ((uint64_t)rb.z << 32) | rb.y;
+                bits16 = (uint32_t)((ma >> off) | (off ? mb << (64u - off) : 0ull)) & 0xFFFFu;
+                r0 = ra.x + (uint32_t)__popcll(ma & ((1ull << off) - 1ull));
+                const uint32_t asc = dir ? __builtin_bitreverse32(ver16) >> 16 : ver16;
+                hits = asc & bits16;
+                const uint32_t dups = asc & ~bits16;                           // a k-mer of the strain, but its row is elsewhere
+                fb = (live & ~ver16) | (dir ? __builtin_bitreverse32(dups) >> 16 : dups);
+            }
+            if (TALLY) {
+                // one verified window per lane again: four chunks per round
+                const unsigned long long hm = __ballot(hits != 0u);
+                for (uint32_t gq = 0; gq < 16u; gq++) {
+                    if (!((hm >> (4u * gq)) & 0xFull)) continue;
+                    const uint32_t sl = 4u * gq + (lane >> 4), a = lane & 15u;
+                    const uint32_t h = (uint32_t)__shfl((int)hits, (int)sl), bb = (uint32_t)__shfl((int)bits16, (int)sl);
+                    const uint32_t rr0 = (uint32_t)__shfl((int)r0, (int)sl), cd = (uint32_t)__shfl((int)(ch | (dir << 31)), (int)sl);
+                    const bool is = ((h >> a) & 1u) != 0u;
+                    const uint32_t row = is ? rr0 + (uint32_t)__popc(bb & ((1u << a) - 1u)) : 0xFFFFFFFFu;
+                    const uint32_t j = (cd >> 31) ? 15u - a : a;
+                    sk_tally_wave(sink, row, (uint32_t)tile0 + (cd & 0x7FFFFFFFu) * 16u + 15u + j, lane);
+                }
+            } else {
+                // runs of verified windows -> the difference array; a run that goes on in the neighbouring chunk
+                // (same diagonal) leaves out the two ends that would cancel
+                const uint32_t lo_open = hits & 1u, hi_open = (hits >> 15) & 1u;
+                const uint32_t pack = (has ? 1u : 0u) | (dir << 1) | (lo_open << 2) | (hi_open << 3);
+                const uint32_t n_ch = (uint32_t)__shfl_down((int)ch, 1), n_dg = (uint32_t)__shfl_down((int)dg, 1), n_pk = (uint32_t)__shfl_down((int)pack, 1);
+                const uint32_t p_ch = (uint32_t)__shfl_up((int)ch, 1), p_dg = (uint32_t)__shfl_up((int)dg, 1), p_pk = (uint32_t)__shfl_up((int)pack, 1);
+                const bool cont_next = has && lane < 63u && n_ch == ch + 1u && n_dg == dg && (n_pk & 3u) == (1u | (dir << 1));
+                const bool cont_prev = has && lane > 0u && p_ch + 1u == ch && p_dg == dg && (p_pk & 3u) == (1u | (dir << 1));
+                // along the strain the next chunk lies at higher text positions, against it at lower ones
+                const bool merge_hi = dir ? (cont_prev && hi_open && ((p_pk >> 2) & 1u)) : (cont_next && hi_open && ((n_pk >> 2) & 1u));
+                const bool merge_lo = dir ? (cont_next && lo_open && ((n_pk >> 3) & 1u)) : (cont_prev && lo_open && ((p_pk >> 3) & 1u));
+                uint32_t h = hits;
+                while (h) {
+                    const uint32_t s0 = (uint32_t)__builtin_ctz(h);
+                    const uint32_t run = (uint32_t)__builtin_ctz(~(h >> s0));
+                    const uint32_t i0 = r0 + (uint32_t)__popc(bits16 & ((1u << s0) - 1u));
+                    if (!(s0 == 0u && merge_lo)) diff_add(i0, 1u);
+                    if (!(s0 + run == 16u && merge_hi)) diff_add(i0 + run, 0xFFFFFFFFu);
+                    h &= ~(((1u << run) - 1u) << s0);
+                }
+            }
+        }
+        // ---- the windows the diagonal did not settle: one by one (everything in this loop is wave-uniform)
+        unsigned long long lanes = __ballot(fb != 0u);
+        while (lanes) {
+            const int l = __builtin_ctzll(lanes);
+            lanes &= lanes - 1ull;
+            const uint32_t f16 = (uint32_t)__builtin_amdgcn_readlane((int)fb, l);
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ch, l) * 16u + 15u;
+            if (lane < 16u && ((f16 >> lane) & 1u))
+                wq[qw + (uint32_t)__popc(f16 & ((1u << lane) - 1u))] = (uint16_t)(e0 + lane);
+            qw += (uint32_t)__popc(f16);
+            if (qw >= 128u) probe_windows(128u);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (qw) probe_some(qw);
+    if (qw) probe_windows(qw);
     if (bad) atomicAdd(&flags[0], 1u);
-    if (!TALLY) {                                                 // the repeats of this tile, one atomic per row
+    if (!TALLY) {                                                 // the repeats of this tile, one atomic per index
         __syncthreads();
         for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) {
             const uint2 e = agg[i];
-            if (e.y != 0u && ABLATE != 3) atomicAdd(&sink.counts[e.x], e.y);
+            if (e.y != 0u && ABLATE != 3) atomicAdd(&sink.diff[e.x], e.y);
         }
     }
 }
@@ -779,6 +828,59 @@ __global__ void sk_table_setpos(sk_u4 *slots, uint64_t nslots, const uint32_t *_
     }
 }
 
+// ---- the difference array of the column being scanned, folded into it: counts[i] += diff[0] + ... + diff[i] ----
+#define SK_DIFF_PER_BLOCK 4096u                        // 256 threads x 16 entries
+__global__ __launch_bounds__(256) void sk_diff_block_sums(const uint32_t *__restrict__ diff, uint32_t n, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t base = blockIdx.x * SK_DIFF_PER_BLOCK + threadIdx.x * 16u;
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < 16u; i++) if (base + i < n) t += diff[base + i];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t d = 128u; d > 0u; d >>= 1) { if (threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0];
+}
+__global__ __launch_bounds__(1024) void sk_diff_scan_sums(uint32_t *sums, uint32_t nb)     // one block: exclusive scan in place
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nb + 1023u) / 1024u, lo = threadIdx.x * per;
+    uint32_t t = 0;
+    for (uint32_t i = lo; i < lo + per && i < nb; i++) t += sums[i];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t d = 1u; d < 1024u; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - t;              // exclusive prefix of this thread's slice
+    for (uint32_t i = lo; i < lo + per && i < nb; i++) { const uint32_t v = sums[i]; sums[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void sk_diff_apply(uint32_t *__restrict__ diff, uint32_t n, const uint32_t *__restrict__ sums,
+                                                      uint32_t *__restrict__ counts, uint32_t nrows)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t base = blockIdx.x * SK_DIFF_PER_BLOCK + threadIdx.x * 16u;
+    uint32_t v[16], t = 0;
+    for (uint32_t i = 0; i < 16u; i++) { v[i] = base + i < n ? diff[base + i] : 0u; t += v[i]; }
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t d = 1u; d < 256u; d <<= 1) {
+        const uint32_t u = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += u;
+        __syncthreads();
+    }
+    uint32_t run = sums[blockIdx.x] + part[threadIdx.x] - t;
+    for (uint32_t i = 0; i < 16u; i++) {
+        run += v[i];
+        if (base + i < nrows && run) counts[base + i] += run;
+        if (base + i < n && v[i]) diff[base + i] = 0u;
+    }
+}
+
 // counter columns live in "locality order" on the device (perm: caller's row -> counter index)
 __global__ void sk_gather_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t n)
 {
@@ -849,6 +951,8 @@ struct sk_ctx {
     uint32_t    *d_perm, *d_inv;      // locality order of the counters (NULL = caller's row order)
     uint32_t    *d_locality;          // the caller's locality[] as given (with the orientation bit)
     uint32_t    *d_tmp;               // [nrows] scratch for fetch/set through the permutation
+    uint32_t    *d_diff, *d_diff_sums;// difference array of the column being scanned [nrows + 1] and its block sums
+    int          diff_col;            // the column d_diff belongs to, -1 = nothing pending
     std::vector<uint32_t> h_perm;     // host copy of the permutation (empty = identity)
     // wide keys
     char        *d_wide_keys;
@@ -936,6 +1040,7 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     c->device = device;
     c->table_load_pct = 50;
     c->grid_kib = -1;
+    c->diff_col = -1;
     c->err[0] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SK_E_NODEVICE; }
     if (hipMalloc((void **)&c->d_flags, 16 * sizeof(uint32_t)) != hipSuccess) { delete c; return SK_E_NOMEM; }
@@ -962,6 +1067,9 @@ static void sk_table_release(sk_ctx *c)
     hipFree(c->d_inv); c->d_inv = NULL;
     hipFree(c->d_locality); c->d_locality = NULL;
     hipFree(c->d_tmp); c->d_tmp = NULL;
+    hipFree(c->d_diff); c->d_diff = NULL;
+    hipFree(c->d_diff_sums); c->d_diff_sums = NULL;
+    c->diff_col = -1;
     hipFree(c->d_wide_keys); c->d_wide_keys = NULL;
     hipFree(c->d_wide_rows); c->d_wide_rows = NULL;
     hipFree(c->d_wide_index); c->d_wide_index = NULL;
@@ -1151,6 +1259,12 @@ extern "C" int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nba
     const size_t words = (size_t)nbases / 16 + 4, have = ((size_t)nbases + 15) / 16;
     SK_HIP(c, hipMalloc((void **)&c->d_text2, words * 4));
     SK_HIP(c, hipMalloc((void **)&c->d_rank, nblk * sizeof(sk_u4)));
+    hipFree(c->d_diff); c->d_diff = NULL;
+    hipFree(c->d_diff_sums); c->d_diff_sums = NULL;
+    c->diff_col = -1;
+    SK_HIP(c, hipMalloc((void **)&c->d_diff, ((size_t)nrows + 2) * 4));
+    SK_HIP(c, hipMalloc((void **)&c->d_diff_sums, ((size_t)nrows / SK_DIFF_PER_BLOCK + 2) * 4));
+    SK_HIP(c, hipMemsetAsync(c->d_diff, 0, ((size_t)nrows + 2) * 4, c->stream));
     SK_HIP(c, hipMemsetAsync(c->d_text2, 0, words * 4, c->stream));
     SK_HIP(c, hipMemcpyAsync(c->d_text2, text2, have * 4, hipMemcpyHostToDevice, c->stream));
     SK_HIP(c, hipMemcpyAsync(c->d_rank, rank.data(), nblk * sizeof(sk_u4), hipMemcpyHostToDevice, c->stream));
@@ -1162,11 +1276,26 @@ extern "C" int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nba
     return SK_OK;
 }
 
+// Fold the pending difference array into its column (asynchronous on the context's stream).  Every entry point that
+// reads or writes the counters calls this first; scans into another column do too.
+static int sk_diff_flush(sk_ctx *c)
+{
+    if (c->diff_col < 0 || !c->d_diff) { c->diff_col = -1; return SK_OK; }
+    const uint32_t n = c->nrows + 1u, nb = (n + SK_DIFF_PER_BLOCK - 1u) / SK_DIFF_PER_BLOCK;
+    hipLaunchKernelGGL(sk_diff_block_sums, dim3(nb), dim3(256), 0, c->stream, c->d_diff, n, c->d_diff_sums);
+    hipLaunchKernelGGL(sk_diff_scan_sums, dim3(1), dim3(1024), 0, c->stream, c->d_diff_sums, nb);
+    hipLaunchKernelGGL(sk_diff_apply, dim3(nb), dim3(256), 0, c->stream, c->d_diff, n, c->d_diff_sums,
+                       c->d_counts + (size_t)c->diff_col * c->nrows, c->nrows);
+    c->diff_col = -1;
+    SK_HIP(c, hipGetLastError());
+    return SK_OK;
+}
+
 // launch main + wide kernels over one device-resident batch
 static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, uint64_t emit_begin, uint32_t col,
                           const sk_sink *tally_sink = NULL)
 {
-    if (nbytes <= emit_begin) return SK_OK;
+    if (nbytes <= emit_begin || c->nrows == 0) return SK_OK;        // (an empty key set: nothing can be counted)
     const uint64_t ntiles = (nbytes + SK_TILE - 1) / SK_TILE;
     if (ntiles > 0x7FFFFFFFull) return sk_fail(c, SK_E_ARG, "batch too large");
     sk_table_view tv;
@@ -1182,7 +1311,15 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     sk_sink sink;
     memset(&sink, 0, sizeof sink);
     if (tally_sink) sink = *tally_sink;
-    else sink.counts = c->d_counts + (size_t)col * c->nrows;
+    else {
+        sink.counts = c->d_counts + (size_t)col * c->nrows;
+        sink.diff = c->d_diff;
+        if (tv.text2 && c->diff_col != (int)col) {            // the difference array serves one column at a time
+            int rc = sk_diff_flush(c);
+            if (rc) return rc;
+            c->diff_col = (int)col;
+        }
+    }
     const dim3 grid((uint32_t)ntiles), block(SK_THREADS);
 
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(uint32_t), c->stream));     // [0] odd bytes seen, [2] listed chunks
@@ -1322,6 +1459,7 @@ extern "C" int sk_tally_launch(sk_ctx *c, const sk_batch *b, uint32_t type_col, 
     if (b->nrec == 0) return sk_fail(c, SK_E_STATE, "empty batch");
     SK_HIP(c, hipSetDevice(c->device));
     int rc;
+    if ((rc = sk_diff_flush(c)) != SK_OK) return rc;              // (the type column is read by the kernel)
     const uint32_t nrec = b->nrec;
     if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)nrec * 8 + 8)) != SK_OK) return rc;
     if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
@@ -1497,6 +1635,7 @@ extern "C" int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out)
     if (!c || !out) return SK_E_ARG;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
+    { int rc_ = sk_diff_flush(c); if (rc_) return rc_; }
     const uint32_t *src = c->d_counts + (size_t)col * c->nrows;
     if (c->d_perm && c->nrows) {
         hipLaunchKernelGGL(sk_gather_u32, dim3((c->nrows + 255) / 256), dim3(256), 0, c->stream, c->d_tmp, src, c->d_perm, c->nrows);
@@ -1512,6 +1651,7 @@ extern "C" int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in)
     if (!c || !in) return SK_E_ARG;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
+    { int rc_ = sk_diff_flush(c); if (rc_) return rc_; }
     uint32_t *dst = c->d_counts + (size_t)col * c->nrows;
     if (c->d_perm && c->nrows) {
         SK_HIP(c, hipMemcpyAsync(c->d_tmp, in, (size_t)c->nrows * 4, hipMemcpyHostToDevice, c->stream));
@@ -1528,11 +1668,18 @@ extern "C" int sk_counts_zero(sk_ctx *c, uint32_t col)
     if (!c) return SK_E_ARG;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
+    { int rc_ = sk_diff_flush(c); if (rc_) return rc_; }
     SK_HIP(c, hipMemsetAsync(c->d_counts + (size_t)col * c->nrows, 0, (size_t)c->nrows * 4, c->stream));
     return SK_OK;
 }
 
-extern "C" void *sk_counts_device_ptr(sk_ctx *c) { return c ? (void *)c->d_counts : NULL; }
+extern "C" void *sk_counts_device_ptr(sk_ctx *c)
+{
+    if (!c) return NULL;
+    // whoever takes the pointer reads the block on a stream of their own: fold the pending increments in and wait
+    if (hipSetDevice(c->device) != hipSuccess || sk_diff_flush(c) != SK_OK || hipStreamSynchronize(c->stream) != hipSuccess) return NULL;
+    return (void *)c->d_counts;
+}
 
 // ---- for the other translation units of the library (sk_internal.h)
 extern "C" int sk_fail_(sk_ctx *c, int code, const char *fmt, ...)
@@ -1551,6 +1698,7 @@ extern "C" int sk_counts_rows_to_device_(sk_ctx *c, uint32_t col, uint32_t *d_ou
     if (!c || !d_out) return SK_E_ARG;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
+    { int rc_ = sk_diff_flush(c); if (rc_) return rc_; }
     const uint32_t *src = c->d_counts + (size_t)col * c->nrows;
     if (c->d_perm && c->nrows)
         hipLaunchKernelGGL(sk_gather_u32, dim3((c->nrows + 255) / 256), dim3(256), 0, c->stream, d_out, src, c->d_perm, c->nrows);
@@ -1677,6 +1825,7 @@ extern "C" int sk_counts_allreduce(sk_ctx *c, void *rccl_comm)
     int rc = sk_rccl_load(c);
     if (rc) return rc;
     SK_HIP(c, hipSetDevice(c->device));
+    if ((rc = sk_diff_flush(c)) != SK_OK) return rc;
     const int ncclUint32 = 3, ncclSum = 0;            // rccl.h: ncclDataType_t / ncclRedOp_t
     if (g_rccl.allreduce(c->d_counts, c->d_counts, (size_t)c->nrows * c->ncols, ncclUint32, ncclSum, rccl_comm, c->stream) != 0)
         return sk_fail(c, SK_E_RCCL, "ncclAllReduce failed");

@@ -34,6 +34,8 @@ VARIANTS = {
     "unc_h0":       (0.0,  {}, True),
     "unc_h2":       (0.02, {}, True),
     "unc_g2048_h2": (0.02, {"grid_kib": 2048}, True),
+    "notext_h2":    (0.02, {"text_stage": 0}, False),
+    "notext_h100":  (1.0,  {"text_stage": 0}, False),
     "base_h30":     (0.3,  {}, False),
     "base_h100":    (1.0,  {}, False),
 }
