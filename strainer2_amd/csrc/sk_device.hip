@@ -59,6 +59,11 @@
 #define SK_AGG_LOG2     8
 #define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
+#ifndef SK_SHIFTED_TEST
+#define SK_SHIFTED_TEST 0                   // phase 2: ask the level-1 filter about the half-shifted 16-mers before level 2.  Measured
+                                            // (profiles/r02_phase2_experiments.txt): it halves the kernel's L2 misses and changes nothing
+                                            // (+2 %): the kernel is bound by the L2's REQUEST rate, and the question costs two requests
+#endif
 #ifndef SK_ANCHOR_CH
 #define SK_ANCHOR_CH    4u                  // stage 2: one table probe per this many consecutive surviving chunks (and the first)
 #endif
@@ -333,10 +338,26 @@ __device__ __forceinline__ sk_u4 sk_stream_load(const sk_u4 *p)
 #endif
 }
 
-template <bool TALLY, int ABLATE>
+// one 16-byte chunk of the stream at byte offset off (may start before 0 or end beyond nbytes: '\n' fill there)
+__device__ __forceinline__ sk_u4 sk_load_chunk(const uint8_t *__restrict__ stream, uint64_t nbytes, int64_t off)
+{
+    if (off >= 0 && (uint64_t)off + 16u <= nbytes) return sk_stream_load((const sk_u4 *)(stream + off));
+    uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+    for (int i = 0; i < 16; i++) {
+        const int64_t p = off + i;
+        if (p >= 0 && (uint64_t)p < nbytes)
+            w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
+    }
+    return (sk_u4){w[0], w[1], w[2], w[3]};
+}
+
+// CAND: third pass of the partitioned pipeline (sk_bin -> sk_lds_probe -> this): `cand` holds one byte per chunk of the
+// batch, non-zero for the chunks the LDS-resident filter slices could not rule out; only those chunks (and the lines
+// around them) are read and looked at.
+template <bool TALLY, int ABLATE, bool CAND>
 __global__ __launch_bounds__(SK_THREADS)
 void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
-                  sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags)
+                  sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags, const uint8_t *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) uint32_t rec[(SK_NREC + 1) * SK_REC_DW];
     __shared__ uint16_t wq_all[SK_WAVES][128 + 16];              // below 128 before a push of at most 16
@@ -356,56 +377,111 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     // All of a thread's 16-byte loads are issued before the first is decoded (nine HBM latencies in
     // flight instead of one after the other); tiles at the ends of the batch take the byte-wise path.
     uint32_t bad = 0;
-    constexpr int NIT = (SK_NCHUNK_GRID + SK_THREADS - 1) / SK_THREADS;
-    sk_u4 vv[NIT];
-    const bool inside = tile0 >= SK_SPAN && tile0 + SK_TILE + 16u <= nbytes;      // (workgroup-uniform)
-    if (inside) {
-#pragma unroll
+    uint32_t candm = 0xFFu;                                        // this thread's chunks that are candidates (CAND)
+    if (!CAND) {
+        constexpr int NIT = (SK_NCHUNK_GRID + SK_THREADS - 1) / SK_THREADS;
+        sk_u4 vv[NIT];
+        const bool inside = tile0 >= SK_SPAN && tile0 + SK_TILE + 16u <= nbytes;      // (workgroup-uniform)
+        if (inside) {
+    #pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+                vv[it] = (sk_u4){0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+                if (c < SK_NCHUNK_GRID) vv[it] = sk_stream_load((const sk_u4 *)(stream + (tile0 - SK_SPAN) + (uint64_t)c * 16u));
+            }
+        } else {
+    #pragma unroll
+            for (int it = 0; it < NIT; it++) {                         // (unrolled: vv must stay in registers)
+                const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+                const int64_t off = (int64_t)tile0 - SK_SPAN + (int64_t)c * 16;
+                uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};       // '\n' fill
+                if (c < SK_NCHUNK_GRID)
+                    for (int i = 0; i < 16; i++) {
+                        const int64_t p = off + i;
+                        if (p >= 0 && (uint64_t)p < nbytes)
+                            w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
+                    }
+                vv[it] = (sk_u4){w[0], w[1], w[2], w[3]};
+            }
+        }
+    #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const uint32_t c = tid + (uint32_t)it * SK_THREADS;
-            vv[it] = (sk_u4){0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-            if (c < SK_NCHUNK_GRID) vv[it] = sk_stream_load((const sk_u4 *)(stream + (tile0 - SK_SPAN) + (uint64_t)c * 16u));
+            if (c < SK_NCHUNK_GRID) {
+                const sk_u4 v = vv[it];
+                uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+                sk_decode4(v.x, c0, i0);
+                sk_decode4(v.y, c1, i1);
+                sk_decode4(v.z, c2, i2);
+                sk_decode4(v.w, c3, i3);
+                const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+                // bytes of the chunk after the tile belong to the next tile, which reports them itself
+                if (c < SK_NCHUNK && sk_chunk_has_odd_byte(v, inv16)) {
+                    bad = 1;
+                    if (c >= SK_SPAN_CH) {                                   // (the chunks before the tile are the previous tile's)
+                        const uint32_t at = atomicAdd(&flags[2], 1u);
+                        if (at < table.oddcap) table.oddlist[at] = (uint32_t)((tile0 - SK_SPAN + (uint64_t)c * 16u) >> 4);
+                    }
+                }
+                const uint32_t r = c >> 3, sl = c & 7u;
+                rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+                ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
+            }
         }
     } else {
+        // the candidate bytes of this thread's eight chunks and of the two chunks next to them
+        const uint64_t nch = (nbytes + 15u) >> 4, c8 = (tile0 >> 4) + (uint64_t)tid * SK_SPAN_CH;
+        uint64_t own = 0ull;
+        if (c8 + SK_SPAN_CH <= nch) own = *(const uint64_t *)(cand + c8);
+        else for (uint32_t i = 0; i < SK_SPAN_CH; i++) if (c8 + i < nch) own |= (uint64_t)cand[c8 + i] << (8u * i);
+        own = (own | (own >> 1) | (own >> 2) | (own >> 4)) & 0x0101010101010101ull;          // (any non-zero byte value of 1..0x17)
+        candm = (uint32_t)((own * 0x0102040810204080ull) >> 56);
+        const uint32_t before = c8 > 0 && c8 - 1u < nch ? cand[c8 - 1u] : 0u, after = c8 + SK_SPAN_CH < nch ? cand[c8 + SK_SPAN_CH] : 0u;
+        if (ABLATE == 7) { if (own == 0x123456789ull && before + after == 77u) flags[3] = 1u; return; }    // timing: the candidate map alone
+        // only the chunks next to a candidate are read (a candidate needs itself and its two neighbours)
+        const int64_t off0 = (int64_t)tile0 + (int64_t)tid * SK_SPAN;
+        const uint32_t needm = (candm | (candm << 1) | (candm >> 1) | (before ? 1u : 0u) | (after ? 0x80u : 0u)) & 0xFFu;
+        if (needm) {
+            sk_u4 vv[SK_SPAN_CH];
+            if (tile0 + SK_TILE + 16u <= nbytes) {                 // (workgroup-uniform) plain predicated loads, all in flight together
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {                         // (unrolled: vv must stay in registers)
-            const uint32_t c = tid + (uint32_t)it * SK_THREADS;
-            const int64_t off = (int64_t)tile0 - SK_SPAN + (int64_t)c * 16;
-            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};       // '\n' fill
-            if (c < SK_NCHUNK_GRID)
-                for (int i = 0; i < 16; i++) {
-                    const int64_t p = off + i;
-                    if (p >= 0 && (uint64_t)p < nbytes)
-                        w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
+                for (int i = 0; i < SK_SPAN_CH; i++) {
+                    vv[i] = (sk_u4){0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+                    if ((needm >> i) & 1u) vv[i] = sk_stream_load((const sk_u4 *)(stream + off0) + i);
                 }
-            vv[it] = (sk_u4){w[0], w[1], w[2], w[3]};
-        }
-    }
+            } else {
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const uint32_t c = tid + (uint32_t)it * SK_THREADS;
-        if (c < SK_NCHUNK_GRID) {
-            const sk_u4 v = vv[it];
+                for (int i = 0; i < SK_SPAN_CH; i++)
+                    if ((needm >> i) & 1u) vv[i] = sk_load_chunk(stream, nbytes, off0 + 16 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < SK_SPAN_CH; i++) {
+                if (!((needm >> i) & 1u)) continue;
+                uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+                sk_decode4(vv[i].x, c0, i0);
+                sk_decode4(vv[i].y, c1, i1);
+                sk_decode4(vv[i].z, c2, i2);
+                sk_decode4(vv[i].w, c3, i3);
+                rec[(tid + 1u) * SK_REC_DW + i] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+                ((uint16_t *)rec)[(tid + 1u) * (2 * SK_REC_DW) + 16 + i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+            }
+        }
+        // the chunk before the tile and the one after it (other tiles' chunks, needed next to a candidate at the edge)
+        if ((tid == 0u && (candm & 1u)) || (tid == SK_THREADS - 1u && (candm >> 7))) {
+            const bool lead = tid == 0u;
+            const sk_u4 v = sk_load_chunk(stream, nbytes, lead ? (int64_t)tile0 - 16 : (int64_t)tile0 + SK_TILE);
             uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
             sk_decode4(v.x, c0, i0);
             sk_decode4(v.y, c1, i1);
             sk_decode4(v.z, c2, i2);
             sk_decode4(v.w, c3, i3);
-            const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
-            // bytes of the chunk after the tile belong to the next tile, which reports them itself
-            if (c < SK_NCHUNK && sk_chunk_has_odd_byte(v, inv16)) {
-                bad = 1;
-                if (c >= SK_SPAN_CH) {                                   // (the chunks before the tile are the previous tile's)
-                    const uint32_t at = atomicAdd(&flags[2], 1u);
-                    if (at < table.oddcap) table.oddlist[at] = (uint32_t)((tile0 - SK_SPAN + (uint64_t)c * 16u) >> 4);
-                }
-            }
-            const uint32_t r = c >> 3, sl = c & 7u;
+            const uint32_t r = lead ? 0u : SK_NREC, sl = lead ? 7u : 0u;
             rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
-            ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
+            ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
         }
     }
     __syncthreads();
+    if (ABLATE == 8) { if (rec[tid] == 0x12345u && candm == 0x77u) flags[3] = 1u; return; }               // timing: phase 1 alone
 
     // ================= phase 2: one filter lookup per chunk ======================================
     uint16_t *const wq = wq_all[tid >> 6];
@@ -422,18 +498,46 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         const uint32_t inv = (i & 1) ? ipair >> 16 : ipair & 0xFFFFu;
         const uint32_t rc = sk_revcomp32(cw);
         g[i] = sk_gmix(cw < rc ? cw : rc);
-        okm |= (uint32_t)(inv == 0u) << i;
+        okm |= (uint32_t)(inv == 0u && (!CAND || ((candm >> i) & 1u))) << i;
         b1[i] = make_uint2(0u, 0u);
         if (ABLATE == 4) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks) & 131071u]; }  // timing: all lookups in 1 MiB (L2 hits)
         else if (ABLATE == 6) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks) & 2047u]; } // timing: all lookups in 16 KiB (L1 hits)
-        else if (ABLATE != 1 && inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)];
+        else if (ABLATE != 1 && ((okm >> i) & 1u)) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)];
     }
     uint32_t m = 0;                                               // chunks that may be in the strain
 #pragma unroll
     for (int i = 0; i < SK_SPAN_CH; i++)
         m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) &&
                         ((ABLATE != 4 && ABLATE != 6) || g[i] == 0x9E3779B9u)) << i;     // (ablations: loads kept alive, verdicts dropped)
-    if (m && ABLATE != 5) {                                       // (ABLATE 5, exact: no level 2, stage 2 sorts it out)                                                      // level 2 (rare for unrelated reads)
+    if (m && SK_SHIFTED_TEST && !CAND) {                          // (CAND: the LDS slice and the L2 block have both said maybe -- 0.3 % false positives left)
+        // Second question to the same L2-resident filter: every window of a chunk also holds the 16-mer that starts
+        // 8 bases before the chunk (the windows that begin 8..15 bases before it) or the one that starts 8 bases into
+        // it (the others).  A chunk both of whose half-shifted 16-mers are strangers to the strain (or hold a
+        // non-ACGT byte) has no window left.  Cuts the false positives of one lookup (~7 %) to about 1 %, for two
+        // more lookups per pass -- which mostly hit the L2, where the level-2 lookup they save never does.
+        uint32_t keep = 0;
+        const uint32_t *pv = rec + tid * SK_REC_DW;               // the thread before this one
+        const uint32_t *nx = rec + (tid + 2u) * SK_REC_DW;        // and the one after
+#pragma unroll
+        for (int i = 0; i < SK_SPAN_CH; i++)
+            if ((m >> i) & 1u) {
+                const uint32_t cw = my[i];
+                const uint32_t cwp = i > 0 ? my[i - 1] : pv[7], cwn = i < SK_SPAN_CH - 1 ? my[i + 1] : nx[0];
+                const uint32_t ivp = i > 0 ? (((i - 1) & 1) ? my[8 + ((i - 1) >> 1)] >> 16 : my[8 + ((i - 1) >> 1)] & 0xFFFFu) : pv[11] >> 16;
+                const uint32_t ivn = i < SK_SPAN_CH - 1 ? (((i + 1) & 1) ? my[8 + ((i + 1) >> 1)] >> 16 : my[8 + ((i + 1) >> 1)] & 0xFFFFu) : nx[8] & 0xFFFFu;
+                const bool lv_ok = (ivp >> 8) == 0u, rv_ok = (ivn & 0xFFu) == 0u;   // the 8 bases they borrow from the neighbours are ACGT
+                const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
+                const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr);
+                const uint32_t gl = sk_gmix(wl < rl ? wl : rl), gr = sk_gmix(wr < rr ? wr : rr);
+                uint2 bl = make_uint2(0u, 0u), br = make_uint2(0u, 0u);                  // (both lookups in flight together)
+                if (lv_ok) bl = table.grid1[sk_grid1_block(gl, table.grid1_blocks)];
+                if (rv_ok) br = table.grid1[sk_grid1_block(gr, table.grid1_blocks)];
+                const bool any = (lv_ok && sk_grid_test(bl, sk_grid1_bits(gl))) || (rv_ok && sk_grid_test(br, sk_grid1_bits(gr)));
+                keep |= (uint32_t)any << i;
+            }
+        m = keep;
+    }
+    if (m && ABLATE != 5 && !CAND) {                              // (ABLATE 5, exact: no level 2, stage 2 sorts it out)                                                      // level 2 (rare for unrelated reads)
         // A chunk right after one that passed level 2 is taken on its level-1 pass alone: inside a strain read
         // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
         // level 1 next to a level-2 pass is as rare as level 2's own false positives.  Pruning less is always
@@ -448,6 +552,8 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             }
         m = m2;
     }
+
+    if (ABLATE == 9) { if (m == 0x77u && tid == 1000u) flags[3] = 1u; return; }                            // timing: phases 1 and 2 alone
 
     // ================= stage 2: the windows of the surviving chunks ==============================
     // Seed and verify, a CHUNK per lane (16 windows at a time, 64 chunks = up to 1024 windows per round).
@@ -699,6 +805,142 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) {
             const uint2 e = agg[i];
             if (e.y != 0u && ABLATE != 3) atomicAdd(&sink.diff[e.x], e.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The partitioned pipeline for large batches (the "LDS-staged probe"): the level-1 question "is this chunk's 16-mer in the
+// strain at all?" costs one L2 request per chunk in sk_scan_grid, and the L2's request rate (about 270 G/s over its 128
+// channels), not HBM, is what bounds that kernel.  Here the question is answered from LDS instead:
+//   sk_bin        reads the stream once (the only full pass), decodes every chunk, hashes its canonical 16-mer and deals
+//                 (chunk index in the tile, 20 hash bits) to one of SK_BIN_P partitions by 7 more hash bits: a fixed-size
+//                 segment per (partition, tile) in HBM, 4 bytes per clean chunk = a quarter of the stream's bytes.
+//   sk_lds_probe  one workgroup per partition (and share of the tiles) keeps that partition's slice of the filter
+//                 -- a plain bitmap over the 20 bits, 128 KiB -- in LDS and streams the partition's segments past it;
+//                 survivors (the strain's chunks plus a few per cent) set their byte in a per-chunk candidate map.
+//   sk_scan_grid<.., CAND>  as before, but reading only the lines around candidates and asking the L2 filter only
+//                 about them.
+// Exactness is untouched: the filters only prune (no false negatives), stage 2 verifies what is left.
+// ---------------------------------------------------------------------------------------------
+#define SK_BIN_TILE   65536u
+#define SK_BIN_CH     (SK_BIN_TILE / 16u)          // 4096 chunks: 12 bits
+#define SK_BIN_P      128u                         // partitions: 7 bits
+#define SK_BIN_CAP    40u                          // entries per (partition, tile): mean 28.5 clean chunks, +2 sigma; the rest go straight to the candidates
+#define SK_BIN_WORDS  32768u                       // 2^20 bits per partition slice
+
+// partition (7 bits) and in-partition key (20 bits) of a canonical 16-mer's mix; multiplier of its own, so that the slices'
+// false positives are not the L2 filter's
+__device__ __forceinline__ uint32_t sk_grid3_hash(uint32_t g) { return (g ^ (g >> 13)) * 0x5BD1E995u; }
+
+__global__ void sk_grid3_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ w3)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = in[i];
+    if (k == SK_EMPTY64) return;
+    for (int off = 0; off < 16; off++) {
+        const uint32_t f = (uint32_t)(k >> (2 * (15 - off)));
+        const uint32_t r = sk_revcomp16(f);
+        const uint32_t h = sk_grid3_hash(sk_gmix(f < r ? f : r));
+        const uint32_t key = (h >> 5) & 0xFFFFFu;
+        uint32_t *w = w3 + (size_t)(h >> 25) * SK_BIN_WORDS + (key >> 5);
+        const uint32_t bit = 1u << (key & 31u);
+        if (!(__builtin_nontemporal_load(w) & bit)) atomicOr(w, bit);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void sk_bin(const uint8_t *__restrict__ stream, uint64_t nbytes, sk_table_view table, uint32_t *__restrict__ bins,
+            uint8_t *__restrict__ bin_n, uint32_t ntiles, uint8_t *__restrict__ cand, uint32_t *__restrict__ flags)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage[SK_BIN_P * SK_BIN_CAP];
+    __shared__ uint32_t cnt[SK_BIN_P];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    const uint64_t tile0 = (uint64_t)tile * SK_BIN_TILE;
+    if (tid < SK_BIN_P) cnt[tid] = 0u;
+    for (uint32_t i = tid; i < SK_BIN_P * SK_BIN_CAP; i += 256u) stage[i] = 0xFFFFFFFFu;     // "no entry"
+    __syncthreads();
+    uint32_t bad = 0;
+    const bool inside = tile0 + SK_BIN_TILE <= nbytes;            // (workgroup-uniform)
+#pragma unroll 1
+    for (uint32_t half = 0; half < 2u; half++) {                  // 2 x 8 loads in flight per thread
+        sk_u4 vv[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const uint32_t c = tid + (half * 8u + (uint32_t)it) * 256u;
+            vv[it] = inside ? sk_stream_load((const sk_u4 *)(stream + tile0 + (uint64_t)c * 16u))
+                            : sk_load_chunk(stream, nbytes, (int64_t)(tile0 + (uint64_t)c * 16u));
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const uint32_t c = tid + (half * 8u + (uint32_t)it) * 256u;
+            if (tile0 + (uint64_t)c * 16u >= nbytes) continue;
+            const sk_u4 v = vv[it];
+            uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+            sk_decode4(v.x, c0, i0);
+            sk_decode4(v.y, c1, i1);
+            sk_decode4(v.z, c2, i2);
+            sk_decode4(v.w, c3, i3);
+            const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+            if (inv16) {
+                if (sk_chunk_has_odd_byte(v, inv16)) {            // a byte for the byte-string kernel: note the chunk
+                    bad = 1;
+                    const uint32_t at = atomicAdd(&flags[2], 1u);
+                    if (at < table.oddcap) table.oddlist[at] = (uint32_t)((tile0 >> 4) + c);
+                }
+                continue;
+            }
+            const uint32_t cw = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+            const uint32_t rc = sk_revcomp32(cw);
+            const uint32_t h = sk_grid3_hash(sk_gmix(cw < rc ? cw : rc));
+            const uint32_t p = h >> 25;
+            const uint32_t ent = (c << 20) | ((h >> 5) & 0xFFFFFu);
+            const uint32_t r = ent != 0xFFFFFFFFu ? atomicAdd(&cnt[p], 1u) : SK_BIN_CAP;
+            if (r < SK_BIN_CAP) stage[p * SK_BIN_CAP + r] = ent;
+            else cand[(tile0 >> 4) + c] = 1u;                     // no room in the segment: a candidate without being asked
+        }
+    }
+    __syncthreads();
+    // whole segments go out, 16 bytes per lane (SK_BIN_CAP is a multiple of 4): unused slots say "no entry"
+    for (uint32_t i = tid; i < SK_BIN_P * SK_BIN_CAP / 4u; i += 256u) {
+        const uint32_t p = i / (SK_BIN_CAP / 4u), r4 = i - p * (SK_BIN_CAP / 4u);
+        ((sk_u4 *)(bins + ((size_t)p * ntiles + tile) * SK_BIN_CAP))[r4] = ((const sk_u4 *)stage)[i];
+    }
+    (void)bin_n;
+    if (bad) atomicAdd(&flags[0], 1u);
+}
+
+__global__ __launch_bounds__(1024)
+void sk_lds_probe(const uint32_t *__restrict__ w3, const uint32_t *__restrict__ bins, const uint8_t *__restrict__ bin_n,
+                  uint32_t ntiles, uint32_t splits, uint8_t *__restrict__ cand)
+{
+    extern __shared__ uint32_t slice[];                           // SK_BIN_WORDS words = 128 KiB
+    const uint32_t p = blockIdx.x / splits, sp = blockIdx.x % splits, tid = threadIdx.x;
+    const sk_u4 *src = (const sk_u4 *)(w3 + (size_t)p * SK_BIN_WORDS);
+    for (uint32_t i = tid; i < SK_BIN_WORDS / 4u; i += 1024u) ((sk_u4 *)slice)[i] = src[i];
+    __syncthreads();
+    const uint32_t t_lo = (uint32_t)((uint64_t)ntiles * sp / splits), t_hi = (uint32_t)((uint64_t)ntiles * (sp + 1u) / splits);
+    const sk_u4 *seg = (const sk_u4 *)(bins + ((size_t)p * ntiles + t_lo) * SK_BIN_CAP);
+    (void)bin_n;
+    const uint32_t total4 = (t_hi - t_lo) * (SK_BIN_CAP / 4u);    // 16-byte groups of four entries
+    uint8_t *const cbase = cand + (size_t)t_lo * SK_BIN_CH;
+    auto judge = [&](uint32_t ent, uint32_t t) {
+        const uint32_t key = ent & 0xFFFFFu;
+        if (ent != 0xFFFFFFFFu && ((slice[key >> 5] >> (key & 31u)) & 1u)) cbase[(size_t)t * SK_BIN_CH + (ent >> 20)] = 1u;
+    };
+    for (uint32_t i0 = 0; i0 < total4; i0 += 4096u) {
+        sk_u4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + tid + 1024u * (uint32_t)k;
+            v[k] = (sk_u4){0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (i < total4) v[k] = __builtin_nontemporal_load(seg + i);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t t = (i0 + tid + 1024u * (uint32_t)k) / (SK_BIN_CAP / 4u);
+            judge(v[k].x, t); judge(v[k].y, t); judge(v[k].z, t); judge(v[k].w, t);
         }
     }
 }
@@ -977,6 +1219,10 @@ struct sk_ctx {
     long         table_load_pct;
     long         ablate;              // timing experiments: kernel variants that skip memory stages
     long         dev_uncached;        // experiment: sk_dev_alloc hands out memory the L2 does not keep
+    uint32_t    *d_grid3;             // partitioned pipeline: the SK_BIN_P filter slices (bitmaps) of sk_lds_probe
+    void        *p_bins, *p_binn, *p_cand;    // its grow-only scratch: segments, segment fills, candidate bytes
+    size_t       p_bins_cap, p_binn_cap, p_cand_cap;
+    long         pipeline;            // option: 0/1 = the single kernel (default), 2 = the partitioned pipeline (experiment)
     long         no_text;             // option "text_stage"=0: stage 2 probes every window on its own (A/B, tests)
     void        *t_tally, *t_hits;    // grow-only device scratch of the tally path
     size_t       t_tally_cap, t_hits_cap;
@@ -1061,6 +1307,7 @@ static void sk_table_release(sk_ctx *c)
     c->text_bases = 0;
     hipFree(c->d_grid1); c->d_grid1 = NULL;
     hipFree(c->d_grid2); c->d_grid2 = NULL;
+    hipFree(c->d_grid3); c->d_grid3 = NULL;
     hipFree(c->d_counts); c->d_counts = NULL;
     hipFree(c->d_perm); c->d_perm = NULL;
     c->h_perm.clear();
@@ -1095,6 +1342,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
     for (int i = 0; i < 64; i++) if (c->copied[i]) hipEventDestroy(c->copied[i]);
     if (c->own_batch) sk_batch_destroy(c->own_batch);
     hipFree(c->t_tally); hipFree(c->t_hits);
+    hipFree(c->p_bins); hipFree(c->p_binn); hipFree(c->p_cand);
     if (c->h_tally) hipHostFree(c->h_tally);
     hipFree(c->d_flags);
     hipFree(c->d_oddlist);
@@ -1110,6 +1358,7 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
     if (!strcmp(name, "odd_list_cap")) { if (value < 0 || value > (long)SK_ODDCAP) return SK_E_ARG; c->odd_cap = value; return SK_OK; }
     if (!strcmp(name, "dev_alloc_uncached")) { c->dev_uncached = value != 0; return SK_OK; }
     if (!strcmp(name, "text_stage")) { c->no_text = value == 0; return SK_OK; }
+    if (!strcmp(name, "pipeline")) { if (value < 0 || value > 2) return SK_E_ARG; c->pipeline = value; return SK_OK; }
     if (!strcmp(name, "ablate")) { c->ablate = value; return SK_OK; }
     return sk_fail(c, SK_E_ARG, "unknown option %s", name);
 }
@@ -1182,6 +1431,11 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
             SK_HIP(c, hipMemsetAsync(c->d_grid2, 0, b2, c->stream));
             hipLaunchKernelGGL(sk_grid_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, d_in, nrows,
                                (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+            // the partitioned pipeline's filter slices: SK_BIN_P bitmaps of 2^20 bits (16 MiB)
+            const size_t b3 = (size_t)SK_BIN_P * SK_BIN_WORDS * 4;
+            SK_HIP(c, hipMalloc((void **)&c->d_grid3, b3));
+            SK_HIP(c, hipMemsetAsync(c->d_grid3, 0, b3, c->stream));
+            hipLaunchKernelGGL(sk_grid3_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, d_in, nrows, c->d_grid3);
         }
         uint32_t flags[2] = {0, 0};
         SK_HIP(c, hipMemcpyAsync(flags, c->d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
@@ -1291,6 +1545,8 @@ static int sk_diff_flush(sk_ctx *c)
     return SK_OK;
 }
 
+static int sk_scratch(sk_ctx *c, void **p, size_t *cap, size_t need);
+
 // launch main + wide kernels over one device-resident batch
 static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, uint64_t emit_begin, uint32_t col,
                           const sk_sink *tally_sink = NULL)
@@ -1321,6 +1577,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         }
     }
     const dim3 grid((uint32_t)ntiles), block(SK_THREADS);
+    if (!c->d_grid1) return sk_fail(c, SK_E_STATE, "no table loaded");
 
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(uint32_t), c->stream));     // [0] odd bytes seen, [2] listed chunks
     hipEvent_t e0 = NULL, e1 = NULL;
@@ -1330,17 +1587,48 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         SK_HIP(c, hipEventCreate(&e1));
         SK_HIP(c, hipEventRecord(e0, c->stream));
     }
-#define SK_LAUNCH_GRID(T, A) hipLaunchKernelGGL((sk_scan_grid<T, A>), grid, block, 0, c->stream, \
-                                                d_stream, nbytes, emit_begin, tv, sink, c->d_flags)
-    if (!c->d_grid1) return sk_fail(c, SK_E_STATE, "no table loaded");
-    if (tally_sink)          SK_LAUNCH_GRID(true, 0);
-    else if (c->ablate == 1) SK_LAUNCH_GRID(false, 1);
-    else if (c->ablate == 2) SK_LAUNCH_GRID(false, 2);
-    else if (c->ablate == 3) SK_LAUNCH_GRID(false, 3);
-    else if (c->ablate == 4) SK_LAUNCH_GRID(false, 4);
-    else if (c->ablate == 5) SK_LAUNCH_GRID(false, 5);
-    else if (c->ablate == 6) SK_LAUNCH_GRID(false, 6);
-    else                     SK_LAUNCH_GRID(false, 0);
+    // The partitioned pipeline (the level-1 question answered from LDS) is an experiment kept selectable (option
+    // "pipeline" = 2; parity-tested): as measured it LOSES to the single kernel (0.43 against 0.34 ms per 0.6 Gbase at
+    // 2 % strain reads; profiles/r02_lds_pipeline.txt) -- its one full pass over the stream plus the
+    // bin write already costs half of the single kernel's time, and the re-read of the candidates' neighbourhoods pays
+    // the fabric's random-line rate.  The default is the single kernel for every batch size.
+    const bool piped = c->d_grid3 && (!c->ablate || c->ablate >= 7) && c->pipeline == 2;
+    const uint8_t *d_cand = NULL;
+    if (piped) {
+        const uint64_t ntiles_bin = (nbytes + SK_BIN_TILE - 1) / SK_BIN_TILE;
+        int rc;
+        if ((rc = sk_scratch(c, &c->p_bins, &c->p_bins_cap, (size_t)ntiles_bin * SK_BIN_P * SK_BIN_CAP * 4)) != SK_OK) return rc;
+        if ((rc = sk_scratch(c, &c->p_binn, &c->p_binn_cap, (size_t)ntiles_bin * SK_BIN_P)) != SK_OK) return rc;
+        if ((rc = sk_scratch(c, &c->p_cand, &c->p_cand_cap, (size_t)ntiles_bin * SK_BIN_CH + 64)) != SK_OK) return rc;
+        SK_HIP(c, hipMemsetAsync(c->p_cand, 0, (size_t)ntiles_bin * SK_BIN_CH + 64, c->stream));
+        hipLaunchKernelGGL(sk_bin, dim3((uint32_t)ntiles_bin), dim3(256), 0, c->stream, d_stream, nbytes, tv,
+                           (uint32_t *)c->p_bins, (uint8_t *)c->p_binn, (uint32_t)ntiles_bin, (uint8_t *)c->p_cand, c->d_flags);
+        // one workgroup per CU at a time (128 KiB of LDS each): a few shares per partition keep all 256 CUs busy
+        uint32_t splits = ntiles_bin >= 4096 ? 4u : ntiles_bin >= 1024 ? 2u : 1u;
+        static bool lds_attr = false;
+        if (!lds_attr) {
+            SK_HIP(c, hipFuncSetAttribute((const void *)sk_lds_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SK_BIN_WORDS * 4)));
+            lds_attr = true;
+        }
+        hipLaunchKernelGGL(sk_lds_probe, dim3(SK_BIN_P * splits), dim3(1024), SK_BIN_WORDS * 4, c->stream, (const uint32_t *)c->d_grid3,
+                           (const uint32_t *)c->p_bins, (const uint8_t *)c->p_binn, (uint32_t)ntiles_bin, splits, (uint8_t *)c->p_cand);
+        d_cand = (const uint8_t *)c->p_cand;
+    }
+#define SK_LAUNCH_GRID(T, A, C) hipLaunchKernelGGL((sk_scan_grid<T, A, C>), grid, block, 0, c->stream, \
+                                                   d_stream, nbytes, emit_begin, tv, sink, c->d_flags, d_cand)
+    if (piped && tally_sink) SK_LAUNCH_GRID(true, 0, true);
+    else if (piped && c->ablate == 7) SK_LAUNCH_GRID(false, 7, true);
+    else if (piped && c->ablate == 8) SK_LAUNCH_GRID(false, 8, true);
+    else if (piped && c->ablate == 9) SK_LAUNCH_GRID(false, 9, true);
+    else if (piped)          SK_LAUNCH_GRID(false, 0, true);
+    else if (tally_sink)     SK_LAUNCH_GRID(true, 0, false);
+    else if (c->ablate == 1) SK_LAUNCH_GRID(false, 1, false);
+    else if (c->ablate == 2) SK_LAUNCH_GRID(false, 2, false);
+    else if (c->ablate == 3) SK_LAUNCH_GRID(false, 3, false);
+    else if (c->ablate == 4) SK_LAUNCH_GRID(false, 4, false);
+    else if (c->ablate == 5) SK_LAUNCH_GRID(false, 5, false);
+    else if (c->ablate == 6) SK_LAUNCH_GRID(false, 6, false);
+    else                     SK_LAUNCH_GRID(false, 0, false);
 #undef SK_LAUNCH_GRID
     if (timed) {
         SK_HIP(c, hipEventRecord(e1, c->stream));

@@ -55,6 +55,7 @@ def test_scan_count_fuzz(seed):
     with sk.KmerContext(0) as c:
         if seed % 5 == 0:
             c.set_option("text_stage", 0)              # every window probed on its own now and then
+        c.set_option("pipeline", 2 if seed % 2 else 1)  # the partitioned pipeline on the odd seeds, the single kernel on the even ones
         c.load_keyset(ks, 4)
         third = len(data) // 3
         cuts = [0, data.rfind(b"\n", 0, third) + 1, data.rfind(b"\n", 0, 2 * third) + 1, len(data)]
@@ -84,6 +85,7 @@ def test_tally_fuzz(seed):
     stream = b"\n".join(reads) + b"\n"
     starts = np.cumsum([0] + [len(r) + 1 for r in reads[:-1]])
     with sk.KmerContext(0) as c:
+        c.set_option("pipeline", 2 if seed % 2 else 1)
         c.load_keyset(ks, 6)
         typ = np.ones(ks.nrows, dtype=np.uint32)
         typ[inf_rows] = 2

@@ -125,8 +125,8 @@ def test_scan_stream_fuzz_vs_oracle(ctx, seed, junk):
     assert ocounts[:, 1:].sum() > 1000          # the test is not vacuous
 
 
-@pytest.mark.parametrize("text_stage", [1, 0])
-def test_both_stage2_paths_vs_oracle(text_stage):
+@pytest.mark.parametrize("text_stage,pipeline", [(1, 1), (0, 1), (1, 2), (0, 2)])
+def test_both_stage2_paths_vs_oracle(text_stage, pipeline):
     """stage 2 with the strain's text (seed and verify, default) and without it (every window probed on its own),
     on a stream that crosses several tiles with junk, short records and strain reads"""
     rng = random.Random(77 + text_stage)
@@ -139,6 +139,7 @@ def test_both_stage2_paths_vs_oracle(text_stage):
     assert len(data) > 5 * 32768
     with sk.KmerContext(0) as c:
         c.set_option("text_stage", text_stage)
+        c.set_option("pipeline", pipeline)         # 1 = the single kernel, 2 = sk_bin -> sk_lds_probe -> candidates only
         c.load_keyset(ks, 4)
         c.scan_stream(data, 2)
         t.scan_stream(data, 2)

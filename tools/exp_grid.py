@@ -36,6 +36,13 @@ VARIANTS = {
     "unc_g2048_h2": (0.02, {"grid_kib": 2048}, True),
     "notext_h2":    (0.02, {"text_stage": 0}, False),
     "notext_h100":  (1.0,  {"text_stage": 0}, False),
+    "pipe7_h2":     (0.02, {"ablate": 7}, False),
+    "pipe8_h2":     (0.02, {"ablate": 8}, False),
+    "pipe9_h2":     (0.02, {"ablate": 9}, False),
+    "single_h0":    (0.0,  {"pipeline": 1}, False),
+    "single_h2":    (0.02, {"pipeline": 1}, False),
+    "single_h30":   (0.3,  {"pipeline": 1}, False),
+    "single_h100":  (1.0,  {"pipeline": 1}, False),
     "base_h30":     (0.3,  {}, False),
     "base_h100":    (1.0,  {}, False),
 }
