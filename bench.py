@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of reads drawn from the strain (cfg 2: 0.02)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive host-buffer passes (keeps profiles clean)")
+    ap.add_argument("--file-reads", type=int, default=400_000, help="reads per FASTQ file of the file-fed, rank-sharded side measurement (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--grid-kib", type=int, default=None, help="size of the grid kernel's level-1 filter in KiB (default: automatic)")
     ap.add_argument("--text-stage", type=int, default=None, help="0 = stage 2 without the strain's text (A/B)")
@@ -349,6 +350,69 @@ def main():
         pinned_rate = 2 * nbases / (time.perf_counter() - t1)
         ctx.pinned_free(pin)
 
+    # File-fed, rank-sharded side measurement (never `value`): every rank writes 2 FASTQ files of its own reads under
+    # /dev/shm (or TMPDIR), ONE list names them all plus one file four times the size, and every rank scans its share of
+    # that list through the product's list walk (skh_scan_list: items dealt by size, the big file cut at checked record
+    # boundaries, decode threads -> pinned buffers -> H2D -> kernel).  This is where N ranks share the host's cores.
+    file_fed = None
+    if args.file_reads > 0 and not args.ablate:
+        import shutil
+        import tempfile
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        root = os.path.join(base or tempfile.gettempdir(), "sk_bench_files_%s" % os.environ.get("MASTER_PORT", str(os.getuid())))
+        rec = args.read_len + 1
+        try:
+            os.makedirs(root, exist_ok=True)
+            def write_fastq(path, rows):
+                n = rows.shape[0]
+                q = np.full((n, rec), ord("I"), dtype=np.uint8)
+                q[:, args.read_len] = ord("\n")
+                fq = np.empty((n, 3 + rec + 2 + rec), dtype=np.uint8)
+                fq[:, :3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+                fq[:, 3:3 + rec] = rows
+                fq[:, 3 + rec:5 + rec] = np.frombuffer(b"+\n", dtype=np.uint8)
+                fq[:, 5 + rec:] = q
+                fq.tofile(path)
+            n_small = min(args.file_reads, args.reads // 8)
+            for k in range(2):
+                write_fastq(os.path.join(root, f"r{rank}_{k}.fq"), reads[k * n_small * rec:(k + 1) * n_small * rec].reshape(n_small, rec))
+            if rank == 0:
+                write_fastq(os.path.join(root, "big.fq"), reads[:4 * n_small * rec].reshape(4 * n_small, rec))
+            if world > 1:
+                dist.barrier()
+            lst = os.path.join(root, "list.txt")
+            if rank == 0:
+                with open(lst, "w") as f:
+                    f.write(os.path.join(root, "big.fq") + "\n")
+                    for r in range(world):
+                        for k in range(2):
+                            f.write(os.path.join(root, f"r{r}_{k}.fq") + "\n")
+            barrier()
+            ctx.zero_counts(1)
+            t1 = time.perf_counter()
+            fb = ctx.scan_list(lst, 1, rank=rank, world=world)
+            ctx.sync()
+            if world > 1:
+                allreduce_counts(ctx, 1)
+            barrier()
+            dt = time.perf_counter() - t1
+            fb_total, dt_max = fb, dt
+            if world > 1:
+                tt = torch.tensor([float(fb), dt], dtype=torch.float64, device="cuda")
+                tsum, tmax2 = tt.clone(), tt.clone()
+                dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                dist.all_reduce(tmax2, op=dist.ReduceOp.MAX)
+                fb_total, dt_max = float(tsum[0].item()), float(tmax2[1].item())
+            file_fed = {"bases_per_s": fb_total / dt_max, "bases": int(fb_total), "seconds": dt_max,
+                        "what": "plain FASTQ under %s: 2 files x %d reads per rank + one file of %d reads, ONE list scanned by "
+                                "all ranks through skh_scan_list (items dealt by size, the big file cut at checked record "
+                                "boundaries), counts all-reduced; decode threads per rank = SK_THREADS or the CPU budget / ranks"
+                                % (root, n_small, 4 * n_small)}
+        finally:
+            barrier()
+            if rank == 0:
+                shutil.rmtree(root, ignore_errors=True)
+
     if rank == 0:
         total_bases = nbases * args.steps * world
         value = total_bases / elapsed
@@ -370,6 +434,7 @@ def main():
                        "bases_per_step_per_gpu": nbases, "hits_per_pass_rank0_or_sum": hits_per_pass,
                        "pcie_inclusive_bases_per_s_host_buffers": host_rate,
                        "pcie_inclusive_bases_per_s_pinned_buffers": pinned_rate,
+                       "file_fed_rank_sharded": file_fed,
                        "sharding": "reads sharded by rank, table replicated, one RCCL all-reduce of counts" if world > 1 else "single GPU"},
             "parity": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

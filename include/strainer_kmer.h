@@ -57,6 +57,7 @@ extern "C" {
 #define SK_E_DUPKEY     -6   /* duplicate key passed to sk_table_load                        */
 #define SK_E_STATE      -7   /* call out of order (e.g. scan before table load)              */
 #define SK_E_RCCL       -8
+#define SK_E_SPLIT      -9   /* a big text file could not be cut at record boundaries: the run fails rather than count something else */
 
 typedef struct sk_ctx sk_ctx;
 
@@ -149,6 +150,12 @@ void sk_batch_destroy(sk_batch *b);
 int  sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec);
 int  sk_tally_launch(sk_ctx *ctx, const sk_batch *b, uint32_t type_col, uint32_t informative_value, uint64_t hits_cap);
 int  sk_tally_collect(sk_ctx *ctx, uint32_t *out_tally /* 2*nrec */, sk_hit *out_hits /* hits_cap */, uint64_t *out_nhits);
+/* The same collection, sparse: only records with at least one hit, compacted on the device, as {record, all hits,
+ * informative hits} in no particular order (*n of them; at most cap are stored).  What comes back over PCIe is then
+ * proportional to the reads that hit this strain, not to the reads of the batch (many strains x one metagenome:
+ * src/strain_detect.c:443-626 keeps two counters per read and strain). */
+typedef struct sk_tally_rec { uint32_t rec, all, inf; } sk_tally_rec;
+int  sk_tally_collect_sparse(sk_ctx *ctx, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *out_hits /* hits_cap */, uint64_t *out_nhits);
 
 /* Wait for all queued work of the context. */
 int sk_sync(sk_ctx *ctx);
@@ -172,6 +179,15 @@ uint32_t sk_table_cols(const sk_ctx *ctx);
  * sk_counts_allreduce: in-place sum (u32, wrapping) of the whole counter block over xGMI;
  * rccl_comm = an ncclComm_t, or NULL for the context's own communicator. */
 int  sk_comm_init(sk_ctx *ctx, int rank, int world, const char *id_file, int timeout_s);
+/* The same, with this rank's set-up status in the exchange that precedes the collective: setup_failed != 0 (ctx may then
+ * be NULL: no device, no key set) makes EVERY rank return SK_E_RCCL before anyone blocks in RCCL.  The exchange proves
+ * freshness (a file left by a crashed launch is ignored), every wait is bounded by timeout_s, and a watchdog ends the
+ * process (exit status 3) if ncclCommInitRank itself does not return in that time.  id_file must be visible to all
+ * ranks (node-local /tmp serves one node only). */
+int  sk_comm_init_ex(sk_ctx *ctx, int rank, int world, const char *id_file, int timeout_s, int setup_failed);
+/* The file exchange alone (no GPU, no RCCL): returns 0 = go, 1 = somebody failed, 2 = timed out, 3 = cannot write.
+ * payload128: in on rank 0, out elsewhere.  Exported for the multi-process CPU tests of the protocol. */
+int  sk_rendezvous_exchange(int rank, int world, const char *base_path, int my_status, unsigned char *payload128, double timeout_s);
 void sk_comm_destroy(sk_ctx *ctx);
 int  sk_comm_sum_u32(sk_ctx *ctx, uint32_t value, uint32_t *sum);
 int  sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);

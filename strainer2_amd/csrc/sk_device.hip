@@ -35,8 +35,12 @@
 #include <string>
 #include <vector>
 #include <unistd.h>
+#include <pthread.h>
+#include <errno.h>
+#include <time.h>
 
 #include "../../include/strainer_kmer.h"
+#include "sk_rendezvous.h"
 #include "sk_common.h"
 #include "sk_internal.h"
 
@@ -104,6 +108,7 @@ struct sk_sink {
     uint32_t        nrec;
     uint32_t       *tally;         // TALLY: [2 * nrec]
     const uint32_t *type;          // TALLY: type column
+    const uint32_t *infbits;       // TALLY: bit i <=> type[i] == inf_value (by counter index; two spare words behind)
     uint32_t        inf_value;
     const uint32_t *inv;           // TALLY: counter index -> caller's row (NULL = identity)
     uint2          *hits;          // TALLY: (window-end offset in batch, caller's row)
@@ -748,17 +753,68 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 fb = (live & ~ver16) | (dir ? __builtin_bitreverse32(dups) >> 16 : dups);
             }
             if (TALLY) {
-                // one verified window per lane again: four chunks per round
-                const unsigned long long hm = __ballot(hits != 0u);
-                for (uint32_t gq = 0; gq < 16u; gq++) {
-                    if (!((hm >> (4u * gq)) & 0xFull)) continue;
-                    const uint32_t sl = 4u * gq + (lane >> 4), a = lane & 15u;
-                    const uint32_t h = (uint32_t)__shfl((int)hits, (int)sl), bb = (uint32_t)__shfl((int)bits16, (int)sl);
-                    const uint32_t rr0 = (uint32_t)__shfl((int)r0, (int)sl), cd = (uint32_t)__shfl((int)(ch | (dir << 31)), (int)sl);
-                    const bool is = ((h >> a) & 1u) != 0u;
-                    const uint32_t row = is ? rr0 + (uint32_t)__popc(bb & ((1u << a) - 1u)) : 0xFFFFFFFFu;
-                    const uint32_t j = (cd >> 31) ? 15u - a : a;
-                    sk_tally_wave(sink, row, (uint32_t)tile0 + (cd & 0x7FFFFFFFu) * 16u + 15u + j, lane);
+                // A chunk's windows all lie in the record that holds the chunk, and their rows are consecutive ranks:
+                // the chunk adds popcount(hits) to its record's tally, and the informative ones among them come from 16
+                // bits of the "row is informative" bitmap.  Lanes of one read are neighbours: one atomic per run.
+                const uint32_t nh = (uint32_t)__popc(hits);
+                uint32_t rcd = 0xFFFFFF00u | lane, ih = 0u;                // record (distinct per lane without a hit)
+                if (nh) {
+                    const uint32_t p0 = (uint32_t)tile0 + ch * 16u, t = p0 >> 15;
+                    uint32_t lo = sink.tile_first[t], hi = sink.tile_first[t + 1u];
+                    lo = lo ? lo - 1u : 0u;
+                    if (hi <= lo) hi = lo + 1u;
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (sink.rec_start[mid] <= p0) lo = mid; else hi = mid;
+                    }
+                    rcd = lo;
+                    const uint32_t w = r0 >> 5, sh = r0 & 31u;
+                    const uint64_t two = ((uint64_t)sink.infbits[w + 1u] << 32) | sink.infbits[w];
+                    const uint32_t byrank = (uint32_t)(two >> sh) & 0xFFFFu;            // bit k: row r0 + k is informative
+                    uint32_t bypos = byrank;                                             // bit a: the row of position a is
+                    if (bits16 != 0xFFFFu) {
+                        bypos = 0u;
+                        for (uint32_t a = 0, k = 0; a < 16u; a++)
+                            if ((bits16 >> a) & 1u) { bypos |= ((byrank >> k) & 1u) << a; k++; }
+                    }
+                    ih = hits & bypos;
+                }
+                const uint32_t ni = (uint32_t)__popc(ih);
+                // sums over the run of lanes with the same record, and the offsets into the log: bit-sliced ballots
+                const uint32_t prev = (uint32_t)__shfl_up((int)rcd, 1);
+                const bool first = (lane == 0u) | (rcd != prev);
+                const unsigned long long fm = __ballot(first);
+                const unsigned long long above = lane == 63u ? 0ull : fm & ~((2ull << lane) - 1ull);
+                const uint32_t end = above ? (uint32_t)__builtin_ctzll(above) : 64u;
+                const unsigned long long seg = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+                const unsigned long long ltm = (1ull << lane) - 1ull;
+                uint32_t sum_h = 0u, sum_i = 0u, off_i = 0u, tot_i = 0u;
+#pragma unroll
+                for (int b = 0; b < 5; b++) {
+                    const unsigned long long bh = __ballot((nh >> b) & 1u), bi = __ballot((ni >> b) & 1u);
+                    sum_h += (uint32_t)__popcll(bh & seg) << b;
+                    sum_i += (uint32_t)__popcll(bi & seg) << b;
+                    off_i += (uint32_t)__popcll(bi & ltm) << b;
+                    tot_i += (uint32_t)__popcll(bi) << b;
+                }
+                if (first && nh) {
+                    atomicAdd(&sink.tally[2u * rcd], sum_h);
+                    if (sum_i) atomicAdd(&sink.tally[2u * rcd + 1u], sum_i);
+                }
+                if (tot_i) {                                                             // (wave-uniform)
+                    unsigned long long base = 0;
+                    if (lane == 0u) base = atomicAdd(sink.nhits, (unsigned long long)tot_i);
+                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                    uint32_t h = ih;
+                    unsigned long long at = base + off_i;
+                    while (h) {
+                        const uint32_t a = (uint32_t)__builtin_ctz(h);
+                        h &= h - 1u;
+                        const uint32_t row = r0 + (uint32_t)__popc(bits16 & ((1u << a) - 1u));
+                        if (at < sink.hits_cap) sink.hits[at] = make_uint2((uint32_t)tile0 + ch * 16u + 15u + (dir ? 15u - a : a), sink.inv ? sink.inv[row] : row);
+                        at++;
+                    }
                 }
             } else {
                 // runs of verified windows -> the difference array; a run that goes on in the neighbouring chunk
@@ -1059,6 +1115,32 @@ __global__ void sk_table_insert(const uint64_t *__restrict__ in, uint32_t n, sk_
     }
 }
 
+// TALLY: the records with at least one hit, as {record, all hits, informative hits} (unordered); *n counts them
+__global__ void sk_tally_compact(const uint32_t *__restrict__ tally, uint32_t nrec, uint32_t *__restrict__ out, unsigned long long *n)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint2 t = r < nrec ? ((const uint2 *)tally)[r] : make_uint2(0u, 0u);
+    const unsigned long long m = __ballot(t.x != 0u);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(m);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(n, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), (int)leader) << 32) | (uint32_t)__shfl((int)(uint32_t)base, (int)leader);
+    if (t.x != 0u) {
+        uint32_t *o = out + 3ull * (base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull)));
+        o[0] = r; o[1] = t.x; o[2] = t.y;
+    }
+}
+
+// TALLY: one bit per counter index, set where the type column holds `value`
+__global__ void sk_inf_bitmap(const uint32_t *__restrict__ type, uint32_t n, uint32_t value, uint32_t *__restrict__ bits)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool is = i < n && type[i] == value;
+    const unsigned long long m = __ballot(is);
+    if ((threadIdx.x & 63u) == 0u && i < n + 64u) { bits[2u * (i >> 6)] = (uint32_t)m; bits[2u * (i >> 6) + 1u] = (uint32_t)(m >> 32); }
+}
+
 // text position of every row into its table slot (pos_by_idx: by counter index, 0xFFFFFFFF = none)
 __global__ void sk_table_setpos(sk_u4 *slots, uint64_t nslots, const uint32_t *__restrict__ pos_by_idx)
 {
@@ -1193,6 +1275,8 @@ struct sk_ctx {
     uint32_t    *d_perm, *d_inv;      // locality order of the counters (NULL = caller's row order)
     uint32_t    *d_locality;          // the caller's locality[] as given (with the orientation bit)
     uint32_t    *d_tmp;               // [nrows] scratch for fetch/set through the permutation
+    uint32_t    *d_infbits;           // TALLY: informative-row bitmap of (infbits_col, infbits_val); valid while infbits_ok
+    uint32_t     infbits_col, infbits_val; bool infbits_ok;
     uint32_t    *d_diff, *d_diff_sums;// difference array of the column being scanned [nrows + 1] and its block sums
     int          diff_col;            // the column d_diff belongs to, -1 = nothing pending
     std::vector<uint32_t> h_perm;     // host copy of the permutation (empty = identity)
@@ -1224,8 +1308,8 @@ struct sk_ctx {
     size_t       p_bins_cap, p_binn_cap, p_cand_cap;
     long         pipeline;            // option: 0/1 = the single kernel (default), 2 = the partitioned pipeline (experiment)
     long         no_text;             // option "text_stage"=0: stage 2 probes every window on its own (A/B, tests)
-    void        *t_tally, *t_hits;    // grow-only device scratch of the tally path
-    size_t       t_tally_cap, t_hits_cap;
+    void        *t_tally, *t_hits, *t_compact;    // grow-only device scratch of the tally path
+    size_t       t_tally_cap, t_hits_cap, t_compact_cap;
     uint8_t     *h_tally;             // pinned landing area of the tallies (+ the hit counter)
     size_t       h_tally_cap;
     uint32_t     t_inflight_nrec;     // a sk_tally_launch waiting for its sk_tally_collect
@@ -1267,6 +1351,7 @@ extern "C" const char *sk_strerror(int code)
     case SK_E_DUPKEY: return "duplicate or malformed key in table load";
     case SK_E_STATE: return "call out of order";
     case SK_E_RCCL: return "RCCL error";
+    case SK_E_SPLIT: return "a file could not be cut at record boundaries";
     default: return "unknown error";
     }
 }
@@ -1317,6 +1402,7 @@ static void sk_table_release(sk_ctx *c)
     hipFree(c->d_diff); c->d_diff = NULL;
     hipFree(c->d_diff_sums); c->d_diff_sums = NULL;
     c->diff_col = -1;
+    hipFree(c->d_infbits); c->d_infbits = NULL; c->infbits_ok = false;
     hipFree(c->d_wide_keys); c->d_wide_keys = NULL;
     hipFree(c->d_wide_rows); c->d_wide_rows = NULL;
     hipFree(c->d_wide_index); c->d_wide_index = NULL;
@@ -1341,7 +1427,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 64; i++) if (c->copied[i]) hipEventDestroy(c->copied[i]);
     if (c->own_batch) sk_batch_destroy(c->own_batch);
-    hipFree(c->t_tally); hipFree(c->t_hits);
+    hipFree(c->t_tally); hipFree(c->t_hits); hipFree(c->t_compact);
     hipFree(c->p_bins); hipFree(c->p_binn); hipFree(c->p_cand);
     if (c->h_tally) hipHostFree(c->h_tally);
     hipFree(c->d_flags);
@@ -1568,6 +1654,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     memset(&sink, 0, sizeof sink);
     if (tally_sink) sink = *tally_sink;
     else {
+        c->infbits_ok = false;                                 // (a column is about to change)
         sink.counts = c->d_counts + (size_t)col * c->nrows;
         sink.diff = c->d_diff;
         if (tv.text2 && c->diff_col != (int)col) {            // the difference array serves one column at a time
@@ -1749,9 +1836,10 @@ extern "C" int sk_tally_launch(sk_ctx *c, const sk_batch *b, uint32_t type_col, 
     int rc;
     if ((rc = sk_diff_flush(c)) != SK_OK) return rc;              // (the type column is read by the kernel)
     const uint32_t nrec = b->nrec;
-    if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)nrec * 8 + 8)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)nrec * 8 + 16)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_compact, &c->t_compact_cap, (size_t)nrec * 12 + 16)) != SK_OK) return rc;
     if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
-    if ((size_t)nrec * 8 + 8 > c->h_tally_cap) {
+    if ((size_t)nrec * 8 + 16 > c->h_tally_cap) {
         if (c->h_tally) { SK_HIP(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_tally); c->h_tally = NULL; c->h_tally_cap = 0; }
         const size_t want = (size_t)nrec * 10 + 4096;
         SK_HIP(c, hipHostMalloc((void **)&c->h_tally, want, hipHostMallocDefault));
@@ -1759,16 +1847,27 @@ extern "C" int sk_tally_launch(sk_ctx *c, const sk_batch *b, uint32_t type_col, 
     }
     unsigned long long *d_n = (unsigned long long *)((uint8_t *)c->t_tally + (size_t)nrec * 8);   // hit counter behind the tallies
     SK_HIP(c, hipStreamWaitEvent(c->stream, b->ready, 0));
-    SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)nrec * 8 + 8, c->stream));
+    SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)nrec * 8 + 16, c->stream));
     sk_sink sink;
     memset(&sink, 0, sizeof sink);
     sink.rec_start = (const uint32_t *)b->d_rec; sink.nrec = nrec; sink.tally = (uint32_t *)c->t_tally;
     sink.tile_first = (const uint32_t *)b->d_rec + nrec;
     sink.type = c->d_counts + (size_t)type_col * c->nrows; sink.inf_value = informative_value;
     sink.hits = (uint2 *)c->t_hits; sink.nhits = d_n; sink.hits_cap = hits_cap; sink.inv = c->d_inv;
+    if (!c->infbits_ok || c->infbits_col != type_col || c->infbits_val != informative_value) {
+        if (!c->d_infbits) SK_HIP(c, hipMalloc((void **)&c->d_infbits, ((size_t)c->nrows / 32 + 8) * 4));
+        SK_HIP(c, hipMemsetAsync(c->d_infbits, 0, ((size_t)c->nrows / 32 + 8) * 4, c->stream));
+        hipLaunchKernelGGL(sk_inf_bitmap, dim3((c->nrows + 255) / 256), dim3(256), 0, c->stream, sink.type, c->nrows, informative_value, c->d_infbits);
+        c->infbits_ok = true; c->infbits_col = type_col; c->infbits_val = informative_value;
+    }
+    sink.infbits = c->d_infbits;
     rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink);
     if (rc) return rc;
-    SK_HIP(c, hipMemcpyAsync(c->h_tally, c->t_tally, (size_t)nrec * 8 + 8, hipMemcpyDeviceToHost, c->stream));
+    // the records that were hit at all, compacted on the device (sk_tally_collect_sparse); only the two counters come
+    // back now, the tallies themselves when they are asked for
+    hipLaunchKernelGGL(sk_tally_compact, dim3((nrec + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)c->t_tally, nrec,
+                       (uint32_t *)c->t_compact, d_n + 1);
+    SK_HIP(c, hipMemcpyAsync(c->h_tally, d_n, 16, hipMemcpyDeviceToHost, c->stream));
     c->t_inflight_nrec = nrec;
     c->t_inflight_cap = hits_cap;
     return SK_OK;
@@ -1784,13 +1883,35 @@ extern "C" int sk_tally_collect(sk_ctx *c, uint32_t *out_tally, sk_hit *out_hits
     SK_HIP(c, hipStreamSynchronize(c->stream));
     const uint32_t nrec = c->t_inflight_nrec;
     c->t_inflight_nrec = 0;
-    memcpy(out_tally, c->h_tally, (size_t)nrec * 8);
+    SK_HIP(c, hipMemcpy(out_tally, c->t_tally, (size_t)nrec * 8, hipMemcpyDeviceToHost));
     unsigned long long nh;
-    memcpy(&nh, (uint8_t *)c->h_tally + (size_t)nrec * 8, 8);
+    memcpy(&nh, c->h_tally, 8);
     const unsigned long long take = nh < c->t_inflight_cap ? nh : c->t_inflight_cap;
     if (take && !out_hits) return SK_E_ARG;
     if (take) SK_HIP(c, hipMemcpy(out_hits, c->t_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost));
     *out_nhits = nh;
+    return SK_OK;
+}
+
+// Like sk_tally_collect, but only the records with at least one hit come back: out[i] = {record, all hits, informative
+// hits}, unordered, *n of them (if *n > cap only cap were stored: collect again is not possible -- size cap to the batch's
+// record count to be safe, or to what the workload allows).
+extern "C" int sk_tally_collect_sparse(sk_ctx *c, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *out_hits, uint64_t *out_nhits)
+{
+    if (!c || !n || !out_nhits || (cap && !out)) return SK_E_ARG;
+    if (!c->t_inflight_nrec) return sk_fail(c, SK_E_STATE, "no tally in flight");
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    c->t_inflight_nrec = 0;
+    unsigned long long two[2];
+    memcpy(two, c->h_tally, 16);
+    const unsigned long long take_r = two[1] < cap ? two[1] : cap;
+    if (take_r) SK_HIP(c, hipMemcpy(out, c->t_compact, (size_t)take_r * sizeof(sk_tally_rec), hipMemcpyDeviceToHost));
+    *n = two[1];
+    const unsigned long long take = two[0] < c->t_inflight_cap ? two[0] : c->t_inflight_cap;
+    if (take && !out_hits) return SK_E_ARG;
+    if (take) SK_HIP(c, hipMemcpy(out_hits, c->t_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost));
+    *out_nhits = two[0];
     return SK_OK;
 }
 
@@ -1937,6 +2058,7 @@ extern "C" int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out)
 extern "C" int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in)
 {
     if (!c || !in) return SK_E_ARG;
+    c->infbits_ok = false;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
     { int rc_ = sk_diff_flush(c); if (rc_) return rc_; }
@@ -1954,6 +2076,7 @@ extern "C" int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in)
 extern "C" int sk_counts_zero(sk_ctx *c, uint32_t col)
 {
     if (!c) return SK_E_ARG;
+    c->infbits_ok = false;
     if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
     SK_HIP(c, hipSetDevice(c->device));
     { int rc_ = sk_diff_flush(c); if (rc_) return rc_; }
@@ -2043,44 +2166,72 @@ static int sk_rccl_load(sk_ctx *c)
     return SK_OK;
 }
 
-// One process per GPU: rank 0 creates the RCCL unique id and publishes it through `id_file`
-// (written to a temporary name, then renamed); the other ranks wait for the file.  New relative to
-// the reference, which is single-process.
-extern "C" int sk_comm_init(sk_ctx *c, int rank, int world, const char *id_file, int timeout_s)
+// One process per GPU.  The ranks first exchange, through files next to `id_file` (sk_rendezvous.h: fresh-token handshake,
+// every wait bounded), whether their own set-up worked and rank 0's RCCL unique id; only if everybody is fine does anyone
+// enter ncclCommInitRank, and a watchdog ends the process if that call does not return in time (a rank that died after
+// the exchange would otherwise hang the rest for good).  New relative to the reference, which is single-process.
+struct sk_watchdog { pthread_mutex_t mu; pthread_cond_t cv; int done; int timeout_s; int rank; };
+static void *sk_watchdog_main(void *arg)
 {
-    if (!c || world < 1 || rank < 0 || rank >= world || !id_file) return SK_E_ARG;
-    int rc = sk_rccl_load(c);
-    if (rc) return rc;
-    SK_HIP(c, hipSetDevice(c->device));
-    sk_nccl_id id;
-    memset(&id, 0, sizeof id);
-    if (rank == 0) {
-        if (g_rccl.getid(&id) != 0) return sk_fail(c, SK_E_RCCL, "ncclGetUniqueId failed");
-        std::string tmp = std::string(id_file) + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, sizeof id, 1, f) != 1) { if (f) fclose(f); return sk_fail(c, SK_E_RCCL, "cannot write %s", tmp.c_str()); }
-        fclose(f);
-        if (rename(tmp.c_str(), id_file) != 0) return sk_fail(c, SK_E_RCCL, "cannot publish %s", id_file);
-    } else {
-        int waited_ms = 0;
-        for (;;) {
-            FILE *f = fopen(id_file, "rb");
-            if (f) {
-                const size_t got = fread(&id, 1, sizeof id, f);
-                fclose(f);
-                if (got == sizeof id) break;
-            }
-            if (waited_ms >= timeout_s * 1000) return sk_fail(c, SK_E_RCCL, "timed out waiting for %s", id_file);
-            usleep(20000);
-            waited_ms += 20;
+    sk_watchdog *w = (sk_watchdog *)arg;
+    struct timespec until;
+    clock_gettime(CLOCK_REALTIME, &until);
+    until.tv_sec += w->timeout_s;
+    pthread_mutex_lock(&w->mu);
+    while (!w->done) {
+        if (pthread_cond_timedwait(&w->cv, &w->mu, &until) == ETIMEDOUT && !w->done) {
+            fprintf(stderr, "sk_comm_init: ncclCommInitRank did not return within %d s on rank %d (did a rank die after the rendezvous?) -- giving up\n",
+                    w->timeout_s, w->rank);
+            fflush(stderr);
+            _exit(3);                                  // (never an exec: this process has touched the GPU)
         }
     }
+    pthread_mutex_unlock(&w->mu);
+    return NULL;
+}
+
+extern "C" int sk_comm_init_ex(sk_ctx *c, int rank, int world, const char *id_file, int timeout_s, int setup_failed)
+{
+    if (world < 1 || world > SKR_MAX_WORLD || rank < 0 || rank >= world || !id_file || (!c && !setup_failed)) return SK_E_ARG;
+    if (timeout_s < 1) timeout_s = 1;
+    sk_nccl_id id;
+    memset(&id, 0, sizeof id);
+    int failed = setup_failed != 0;
+    if (!failed && sk_rccl_load(c) != SK_OK) failed = 1;
+    if (!failed && hipSetDevice(c->device) != hipSuccess) failed = 1;
+    if (!failed && rank == 0 && g_rccl.getid(&id) != 0) { sk_fail(c, SK_E_RCCL, "ncclGetUniqueId failed"); failed = 1; }
+    static_assert(sizeof id == SKR_PAYLOAD, "RCCL unique id size");
+    const int x = skr_exchange(rank, world, id_file, failed, (unsigned char *)&id, (double)timeout_s);
+    if (rank == 0) {                                   // (the others remove their own hello files)
+        // the board stays until the ranks have read it; it carries this launch's tokens, so a later launch ignores it
+    }
+    if (x == SKR_ABORT) return sk_fail(c, SK_E_RCCL, failed ? "set-up failed on this rank; the other ranks were told to leave"
+                                                            : "another rank reported a failed set-up: leaving before the collective");
+    if (x == SKR_TIMEOUT) return sk_fail(c, SK_E_RCCL, "rendezvous through %s timed out after %d s (rank %d of %d)", id_file, timeout_s, rank, world);
+    if (x != SKR_OK) return sk_fail(c, SK_E_RCCL, "rendezvous through %s failed (cannot write there?)", id_file);
+    sk_watchdog w;
+    pthread_mutex_init(&w.mu, NULL); pthread_cond_init(&w.cv, NULL);
+    w.done = 0; w.timeout_s = timeout_s; w.rank = rank;
+    pthread_t th;
+    const bool watched = pthread_create(&th, NULL, sk_watchdog_main, &w) == 0;
     void *comm = NULL;
-    if (g_rccl.initrank(&comm, world, id, rank) != 0) return sk_fail(c, SK_E_RCCL, "ncclCommInitRank failed (rank %d of %d)", rank, world);
+    const int nrc = g_rccl.initrank(&comm, world, id, rank);
+    if (watched) {
+        pthread_mutex_lock(&w.mu); w.done = 1; pthread_cond_signal(&w.cv); pthread_mutex_unlock(&w.mu);
+        pthread_join(th, NULL);
+    }
+    pthread_mutex_destroy(&w.mu); pthread_cond_destroy(&w.cv);
+    if (nrc != 0) return sk_fail(c, SK_E_RCCL, "ncclCommInitRank failed (rank %d of %d)", rank, world);
     c->comm = comm;
     c->comm_rank = rank;
     c->comm_world = world;
     return SK_OK;
+}
+
+extern "C" int sk_comm_init(sk_ctx *c, int rank, int world, const char *id_file, int timeout_s)
+{
+    if (!c) return SK_E_ARG;
+    return sk_comm_init_ex(c, rank, world, id_file, timeout_s, 0);
 }
 
 extern "C" void sk_comm_destroy(sk_ctx *c)

@@ -17,6 +17,7 @@
 #include <ctype.h>
 #include <errno.h>
 #include <pthread.h>
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <stdio.h>
@@ -34,6 +35,12 @@
 #include "sk_ctxjob.h"
 #include "sk_gzpipe.h"
 #include "sk_cpus.h"
+#include "sk_rendezvous.h"
+
+int sk_rendezvous_exchange(int rank, int world, const char *base_path, int my_status, unsigned char *payload128, double timeout_s)
+{
+    return skr_exchange(rank, world, base_path, my_status, payload128, timeout_s);
+}
 
 /* tables of tens of MB that are touched at random: 2 MiB-aligned and offered to transparent huge pages
  * (fewer page faults while they are filled, fewer TLB misses while they are probed) */
@@ -642,17 +649,26 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases)
 
 /* ---- list walk: files are decoded by a small pool of host threads (gz inflate + record parsing is
  * the slow part of the whole program), batches are submitted to the one device context under a lock.
- * SK_THREADS sets the pool size (default: min(16, usable CPUs, sk_cpus.h); 1 = the reference's strict sequence). */
+ * SK_THREADS sets the pool size (default: min(16, usable CPUs, sk_cpus.h); 1 = the reference's strict sequence).
+ *
+ * Work items.  A list line is one item, or -- a big plain-text file -- several: pieces [a, b) of its bytes, each
+ * starting at a record boundary (scan_item).  Items are dealt to the ranks by size (longest processing time first: the
+ * biggest item to the least loaded rank), the same plan on every rank from the same list and file sizes; inside a
+ * rank the decode threads take them from a queue.  The counters are sums (src/genome_compare.c:220-223), so neither
+ * the dealing nor the cutting changes a count -- provided every piece really starts at a record boundary, which is
+ * CHECKED, not assumed (parse_range). */
+typedef struct { char *path; uint64_t a, b, size; uint32_t line; int ranged; } scan_item;
+
 typedef struct {
     sk_ctx         *ctx;
     uint32_t        col;
     int             pipe;              /* fewer files than cores: each file's inflate gets a helper thread (> 1: that many) */
     pthread_mutex_t submit_mu;         /* sk_scan_stream is one-caller-at-a-time per context */
     pthread_mutex_t queue_mu;
-    char          **path;              /* work list of this call (files this rank scans), in list order */
-    uint32_t        npath, next;
+    scan_item      *item;              /* work list of this call (what this rank scans), in list order */
+    uint32_t        nitem, next;
     int             rc;                /* first failure ...                                         */
-    uint32_t        rc_index;          /* ... and the list position it belongs to                   */
+    uint32_t        rc_index;          /* ... and the item it belongs to                            */
     uint64_t        bases;
 } scan_pool;
 
@@ -706,8 +722,77 @@ static void worker_done(scan_worker *w)
     pthread_mutex_unlock(&w->pool->submit_mu);
 }
 
-/* decode one file into the worker's pinned buffers; returns records or a negative SK_E_* */
-static int64_t worker_file(scan_worker *w, const char *path, uint64_t *bases)
+/* First offset >= x of a plain FASTA/FASTQ text at which a record may start: a '>' or '@' at the start of a line --
+ * for '@' with a '+' line two lines on, which sets it apart from a quality line that happens to begin with '@'
+ * (src/kseq.h:171-211 has no such check, it reads from the top; a guess that is wrong is caught by parse_range). */
+static uint64_t guess_record_start(const unsigned char *t, uint64_t size, uint64_t x)
+{
+    uint64_t i = x;
+    if (x == 0) return 0;
+    while (i < size) {
+        const unsigned char *nl = (const unsigned char *)memchr(t + i - 1, '\n', (size_t)(size - (i - 1)));
+        uint64_t s;
+        if (!nl) return size;
+        s = (uint64_t)(nl - t) + 1;
+        if (s >= size) return size;
+        if (t[s] == '>') {
+            /* not if the line before begins with '+': then this is a FASTQ quality line that happens to begin with '>'
+             * (no line of a FASTA file begins with '+') */
+            uint64_t q = s >= 2 ? s - 2 : 0;
+            while (q > 0 && t[q] != '\n') q--;
+            if (!(s >= 2 && t[q == 0 && t[0] != '\n' ? 0 : q + 1] == '+')) return s;
+        }
+        if (t[s] == '@') {
+            const unsigned char *l1 = (const unsigned char *)memchr(t + s, '\n', (size_t)(size - s));
+            const unsigned char *l2 = l1 && (uint64_t)(l1 - t) + 1 < size ? (const unsigned char *)memchr(l1 + 1, '\n', (size_t)(size - ((uint64_t)(l1 - t) + 1))) : NULL;
+            if (!l2 || (uint64_t)(l2 - t) + 1 >= size) return s;          /* too close to the end to tell: the check decides */
+            if (l2[1] == '+') return s;
+        }
+        i = s + 1;
+    }
+    return size;
+}
+
+/* One piece [a, b) of a plain-text file: the records that START in it.  The piece's own start s(a) and end s(b) come from
+ * guess_record_start; its bytes are parsed as a file of their own, and afterwards the parser must stand between two records
+ * (P_SEEK after a FASTQ record, P_LINE_START after a FASTA line) with a header character next -- then s(b) is a true record
+ * boundary GIVEN that s(a) was one.  Piece 0 starts at 0, which is one; every later piece's start is the previous piece's
+ * checked end.  So if every piece passes, the pieces' records are exactly the file's records; if any piece fails, the
+ * caller fails the run (SK_E_SPLIT) instead of counting something else. */
+static int parse_range(const scan_item *it, rec_fn fn, void *user, int64_t *nrecords)
+{
+    enum { BLK = 4 << 20 };
+    int fd = open(it->path, O_RDONLY);
+    struct stat st;
+    const unsigned char *t;
+    uint64_t sa, sb, i;
+    parser ps;
+    int ok = 1;
+    if (fd < 0) return SK_E_OPEN;
+    if (fstat(fd, &st) != 0 || (uint64_t)st.st_size != it->size) { close(fd); return SK_E_SPLIT; }     /* (changed since the plan) */
+    t = (const unsigned char *)mmap(NULL, (size_t)it->size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (t == MAP_FAILED) return SK_E_OPEN;
+    madvise((void *)t, (size_t)it->size, MADV_SEQUENTIAL);
+    sa = guess_record_start(t, it->size, it->a);
+    sb = it->b >= it->size ? it->size : guess_record_start(t, it->size, it->b);
+    parser_init(&ps, fn, user);
+    for (i = sa; i < sb && ps.state != P_STOP; i += BLK) parser_feed(&ps, t + i, (size_t)(sb - i < BLK ? sb - i : BLK));
+    if (ps.state != P_STOP && sb < it->size && sb > sa)
+        ok = (ps.state == P_SEEK || ps.state == P_LINE_START) && (t[sb] == '>' || t[sb] == '@');
+    if (ps.state != P_STOP) parser_eof(&ps);
+    if (nrecords) *nrecords = ps.nrecords;
+    {
+        const int sink_rc = ps.sink_rc;
+        parser_free(&ps);
+        munmap((void *)t, (size_t)it->size);
+        if (sink_rc) return sink_rc;
+    }
+    return ok ? SK_OK : SK_E_SPLIT;
+}
+
+/* decode one item into the worker's pinned buffers; returns records or a negative SK_E_* */
+static int64_t worker_item(scan_worker *w, const scan_item *it, uint64_t *bases)
 {
     stream_writer sw;
     int64_t nrec = 0;
@@ -718,8 +803,8 @@ static int64_t worker_file(scan_worker *w, const char *path, uint64_t *bases)
     sw.sink = worker_sink;
     sw.user = w;
     sw.next_buf = worker_next_buf;
-    rc = parse_file(path, writer_record, &sw, &nrec, NULL, w->pool->pipe);
-    if (rc == SK_OK) writer_flush(&sw);
+    rc = it->ranged ? parse_range(it, writer_record, &sw, &nrec) : parse_file(it->path, writer_record, &sw, &nrec, NULL, w->pool->pipe);
+    if (rc == SK_OK || (rc == SK_E_SPLIT && !sw.rc)) writer_flush(&sw);
     *bases += sw.bases;
     if (rc != SK_OK) return rc;
     if (sw.rc) return sw.rc;
@@ -737,10 +822,10 @@ static void *pool_worker(void *arg)
         int64_t rc;
         pthread_mutex_lock(&p->queue_mu);
         i = p->next;
-        if (i >= p->npath || p->rc != SK_OK) { pthread_mutex_unlock(&p->queue_mu); break; }
+        if (i >= p->nitem || p->rc != SK_OK) { pthread_mutex_unlock(&p->queue_mu); break; }
         p->next++;
         pthread_mutex_unlock(&p->queue_mu);
-        rc = wrc != SK_OK ? wrc : worker_file(&w, p->path[i], &bases);
+        rc = wrc != SK_OK ? wrc : worker_item(&w, &p->item[i], &bases);
         pthread_mutex_lock(&p->queue_mu);
         p->bases += bases;
         if (rc < 0 && (p->rc == SK_OK || i < p->rc_index)) { p->rc = (int)rc; p->rc_index = i; }
@@ -750,18 +835,46 @@ static void *pool_worker(void *arg)
     return NULL;
 }
 
+/* the plan: items of the whole list (every rank computes the same), then who takes which */
+typedef struct { uint64_t est; uint32_t idx; } plan_key;
+static int plan_cmp(const void *a, const void *b)
+{
+    const plan_key *x = (const plan_key *)a, *y = (const plan_key *)b;
+    if (x->est != y->est) return x->est > y->est ? -1 : 1;
+    return x->idx < y->idx ? -1 : x->idx > y->idx;
+}
+
+/* items[0..n): all items in list order; owner[i] = the rank that scans item i */
+static void plan_owners(const scan_item *items, const uint64_t *est, uint32_t n, uint32_t world, uint32_t *owner)
+{
+    plan_key *k = (plan_key *)malloc(((size_t)n + 1) * sizeof *k);
+    uint64_t *load = (uint64_t *)calloc(world, sizeof *load);
+    uint32_t i, r;
+    (void)items;
+    for (i = 0; i < n; i++) { k[i].est = est[i]; k[i].idx = i; }
+    qsort(k, n, sizeof *k, plan_cmp);
+    for (i = 0; i < n; i++) {
+        uint32_t best = 0;
+        for (r = 1; r < world; r++) if (load[r] < load[best]) best = r;
+        owner[k[i].idx] = best;
+        load[best] += k[i].est ? k[i].est : 1;
+    }
+    free(k); free(load);
+}
+
 int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
                   FILE *err, uint32_t rank, uint32_t world, uint64_t *bases)
 {
     FILE *fp = fopen(list_path, "r");
     char *line = NULL, *nl;
     size_t cap = 0;
-    uint32_t idx = 0, pcap = 0, i;
+    uint32_t nline = 0, nall = 0, acap = 0, i;
     int nthreads = 1;
     const char *env = getenv("SK_THREADS");
     scan_pool pool;
-    scan_worker seq;
-    int seq_ready = 0, seq_rc = SK_OK;
+    scan_item *all = NULL;
+    uint64_t *est = NULL, total = 0;
+    uint32_t *owner = NULL;
     if (!fp) {
         if (err) fprintf(err, "could not read file %s in GEN_all_kmer_counts()\n", list_path);
         return SK_E_OPEN;
@@ -779,6 +892,7 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     /* the reference logs "<line>\t<time>" before it scans each file (src/genome_compare.c:167-170);
      * with a pool the time is the time of the list walk */
     while (getline(&line, &cap, fp) != -1) {
+        struct stat st;
         if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
         if (progress && rank == 0) {
             time_t now = time(NULL);
@@ -786,54 +900,110 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
         }
         if (skip && strcmp(skip, line) == 0) {
             if (err && rank == 0) fprintf(err, "skipping %s (identical match)\n", line);
-            idx++;
+            nline++;
             continue;
         }
-        if (idx++ % world != rank) continue;
-        if (nthreads == 1) {                                  /* strict sequence, as the reference */
-            uint64_t b = 0;
-            int64_t rc;
-            if (!seq_ready) { seq_rc = worker_init(&seq, &pool); seq_ready = 1; }
-            rc = seq_rc != SK_OK ? seq_rc : worker_file(&seq, line, &b);
-            pool.bases += b;
-            if (rc < 0) { pool.rc = (int)rc; pool.path = (char **)realloc(pool.path, sizeof(char *)); pool.path[0] = strdup(line); pool.npath = 1; pool.rc_index = 0; break; }
-            continue;
-        }
-        if (pool.npath == pcap) { pcap = pcap ? pcap * 2 : 64; pool.path = (char **)realloc(pool.path, pcap * sizeof(char *)); }
-        pool.path[pool.npath++] = strdup(line);
+        if (nall == acap) { acap = acap ? acap * 2 : 64; all = (scan_item *)realloc(all, acap * sizeof *all); }
+        memset(&all[nall], 0, sizeof all[nall]);
+        all[nall].path = strdup(line);
+        all[nall].line = nline++;
+        all[nall].size = stat(line, &st) == 0 && S_ISREG(st.st_mode) ? (uint64_t)st.st_size : 0;
+        nall++;
     }
     free(line);
     fclose(fp);
+
+    /* cut big plain-text files into pieces (never with one thread and one rank: that is the reference's strict sequence) */
+    {
+        const uint64_t lanes = (uint64_t)world * (uint64_t)(nthreads > 1 ? nthreads : 1);
+        uint64_t target;
+        uint32_t n0 = nall, out = 0;
+        scan_item *cut;
+        uint64_t *gz = (uint64_t *)calloc((size_t)nall + 1, sizeof *gz);
+        for (i = 0; i < nall; i++) {
+            unsigned char magic[2] = {0, 0};
+            FILE *f = all[i].size ? fopen(all[i].path, "rb") : NULL;
+            if (f) { if (fread(magic, 1, 2, f) != 2) magic[0] = 0; fclose(f); }
+            gz[i] = magic[0] == 0x1f && magic[1] == 0x8b;
+            total += gz[i] ? all[i].size * 4 : all[i].size;           /* (a .gz FASTQ inflates about fourfold) */
+        }
+        target = total / (4 * lanes);
+        if (target < (32u << 20)) target = 32u << 20;
+        if ((env = getenv("SK_SPLIT_BYTES")) != NULL && atoll(env) > 0) target = (uint64_t)atoll(env);     /* (tests) */
+        cut = (scan_item *)malloc(((size_t)nall + 1) * 260 * sizeof *cut);
+        est = (uint64_t *)malloc(((size_t)nall + 1) * 260 * sizeof *est);
+        for (i = 0; i < n0; i++) {
+            uint32_t np = 1, k;
+            if (lanes > 1 && !gz[i] && !getenv("SK_NO_SPLIT") && all[i].size >= 2 * target) {
+                np = (uint32_t)((all[i].size + target - 1) / target);
+                if (np > 256) np = 256;
+            }
+            for (k = 0; k < np; k++) {
+                cut[out] = all[i];
+                if (k) cut[out].path = strdup(all[i].path);
+                cut[out].ranged = np > 1;
+                cut[out].a = all[i].size / np * k;
+                cut[out].b = k + 1 == np ? all[i].size : all[i].size / np * (k + 1);
+                est[out] = np > 1 ? cut[out].b - cut[out].a : (gz[i] ? all[i].size * 4 : all[i].size);
+                out++;
+            }
+        }
+        free(all); free(gz);
+        all = cut; nall = out;
+    }
+    owner = (uint32_t *)malloc(((size_t)nall + 1) * sizeof *owner);
+    plan_owners(all, est, nall, world, owner);
+    pool.item = (scan_item *)malloc(((size_t)nall + 1) * sizeof *pool.item);
+    for (i = 0; i < nall; i++) {
+        if (owner[i] == rank) pool.item[pool.nitem++] = all[i];
+        else free(all[i].path);
+    }
+    free(all); free(est); free(owner);
+
     {   /* with fewer files than half the cores, a file's inflate and its record parsing take a core each; with
          * fewer still, the threads left over inflate inside the files (a speculative segment costs about twice a
          * serial one, so it takes three threads per file to be worth it).  SK_GZ_THREADS sets the number per file. */
         const long ncpu = sk_cpu_budget();
         const char *gzt = getenv("SK_GZ_THREADS");
-        pool.pipe = nthreads > 1 && (long)pool.npath * 2 <= ncpu;
-        if (pool.pipe && pool.npath && nthreads / (int)pool.npath >= 3) pool.pipe = nthreads / (int)pool.npath;
+        pool.pipe = nthreads > 1 && (long)pool.nitem * 2 <= ncpu;
+        if (pool.pipe && pool.nitem && nthreads / (int)pool.nitem >= 3) pool.pipe = nthreads / (int)pool.nitem;
         if (gzt && nthreads > 1) pool.pipe = atoi(gzt) < 1 ? 1 : atoi(gzt);
         if (pool.pipe > 16) pool.pipe = 16;
     }
-    if (nthreads > 1 && pool.npath) {
+    if (nthreads == 1) {                                      /* strict sequence, as the reference */
+        scan_worker seq;
+        int seq_rc = SK_OK;
+        if (pool.nitem) seq_rc = worker_init(&seq, &pool);
+        for (i = 0; i < pool.nitem; i++) {
+            uint64_t b = 0;
+            const int64_t rc = seq_rc != SK_OK ? seq_rc : worker_item(&seq, &pool.item[i], &b);
+            pool.bases += b;
+            if (rc < 0) { pool.rc = (int)rc; pool.rc_index = i; break; }
+        }
+        if (pool.nitem) worker_done(&seq);
+    } else if (pool.nitem) {
         pthread_t *th;
-        if ((uint32_t)nthreads > pool.npath) nthreads = (int)pool.npath;
+        if ((uint32_t)nthreads > pool.nitem) nthreads = (int)pool.nitem;
         th = (pthread_t *)malloc((size_t)nthreads * sizeof *th);
         for (i = 0; i < (uint32_t)nthreads; i++) pthread_create(&th[i], NULL, pool_worker, &pool);
         for (i = 0; i < (uint32_t)nthreads; i++) pthread_join(th[i], NULL);
         free(th);
     }
     if (pool.rc == SK_E_OPEN) {
-        if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", pool.path[pool.rc_index]);
+        if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", pool.item[pool.rc_index].path);
+    } else if (pool.rc == SK_E_SPLIT) {
+        if (err) fprintf(err, "kmer_scrub_count: %s could not be cut at record boundaries (bytes %llu-%llu): nothing is reported; "
+                              "run again with SK_NO_SPLIT=1\n", pool.item[pool.rc_index].path,
+                         (unsigned long long)pool.item[pool.rc_index].a, (unsigned long long)pool.item[pool.rc_index].b);
     } else if (pool.rc != SK_OK) {
-        if (err) fprintf(err, "kmer_scrub_count: device error while scanning %s: %s (%s)\n", pool.path[pool.rc_index],
+        if (err) fprintf(err, "kmer_scrub_count: device error while scanning %s: %s (%s)\n", pool.item[pool.rc_index].path,
                          sk_strerror(pool.rc), sk_last_error(ctx));
     }
-    if (seq_ready) worker_done(&seq);
-    if (bases) *bases += pool.bases;
-    for (i = 0; i < pool.npath; i++) free(pool.path[i]);
-    free(pool.path);
+    for (i = 0; i < pool.nitem; i++) free(pool.item[i].path);
+    free(pool.item);
     pthread_mutex_destroy(&pool.submit_mu);
     pthread_mutex_destroy(&pool.queue_mu);
+    if (bases) *bases += pool.bases;
     return pool.rc;
 }
 
@@ -991,31 +1161,38 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     t1 = now_s();
     crc = sk_ctxjob_join(&cj, &ctx);
     t2 = now_s();
-    if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", R); goto done; }
-    if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s\n", sk_strerror(rc)); goto done; }
-    if (ks.short_records && rank == 0)
-        fprintf(err, "kmer_scrub_count: skipped %llu reference record(s) shorter than %d bases "
-                     "(the original program crashes on these)\n", (unsigned long long)ks.short_records, SK_K - 1);
-
-    if (crc != SK_OK) { fprintf(err, "kmer_scrub_count: cannot use HIP device %d: %s\n", device, sk_strerror(crc)); goto done; }
-    if (use_comm) {
-        char path[256];
-        if ((env = getenv("SK_RCCL_ID_FILE")) != NULL) snprintf(path, sizeof path, "%s", env);
-        else if ((env = getenv("MASTER_PORT")) != NULL) snprintf(path, sizeof path, "/tmp/sk_rccl_id.%s", env);
-        else snprintf(path, sizeof path, "/tmp/sk_rccl_id.%d", (int)getuid());
-        if (rank == 0) remove(path);
-        {   /* RCCL prints its version banner on stdout, which here is the TSV: park fd 1 on stderr meanwhile */
-            int saved;
-            fflush(stdout);
-            saved = dup(1);
-            dup2(2, 1);
-            rc = sk_comm_init(ctx, rank, world, path, 120);
-            fflush(stdout);
-            dup2(saved, 1);
-            close(saved);
+    {   /* set-up problems are reported here; with several ranks the others are told before anyone enters the collective */
+        int setup_failed = 0;
+        if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", R); setup_failed = 1; }
+        else if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s\n", sk_strerror(rc)); setup_failed = 1; }
+        else if (ks.short_records && rank == 0)
+            fprintf(err, "kmer_scrub_count: skipped %llu reference record(s) shorter than %d bases "
+                         "(the original program crashes on these)\n", (unsigned long long)ks.short_records, SK_K - 1);
+        if (crc != SK_OK) {
+            if (!setup_failed) fprintf(err, "kmer_scrub_count: cannot use HIP device %d: %s\n", device, sk_strerror(crc));
+            setup_failed = 1; ctx = NULL;
         }
-        if (rank == 0) remove(path);
-        if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: RCCL rendezvous failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+        if (use_comm) {
+            char path[256];
+            int timeout_s = 120;
+            if ((env = getenv("SK_RCCL_ID_FILE")) != NULL) snprintf(path, sizeof path, "%s", env);
+            else if ((env = getenv("MASTER_PORT")) != NULL) snprintf(path, sizeof path, "/tmp/sk_rccl_id.%s", env);
+            else snprintf(path, sizeof path, "/tmp/sk_rccl_id.%d", (int)getuid());
+            if ((env = getenv("SK_RENDEZVOUS_TIMEOUT")) != NULL && atoi(env) > 0) timeout_s = atoi(env);
+            {   /* RCCL prints its version banner on stdout, which here is the TSV: park fd 1 on stderr meanwhile */
+                int saved;
+                fflush(stdout);
+                saved = dup(1);
+                dup2(2, 1);
+                rc = sk_comm_init_ex(ctx, rank, world, path, timeout_s, setup_failed);
+                fflush(stdout);
+                dup2(saved, 1);
+                close(saved);
+            }
+            if (rc != SK_OK && !setup_failed)
+                fprintf(err, "kmer_scrub_count: RCCL rendezvous failed: %s (%s)\n", sk_strerror(rc), ctx ? sk_last_error(ctx) : "no context");
+            if (rc != SK_OK) goto done;
+        } else if (setup_failed) goto done;
     }
     rc = skh_keyset_load(ctx, &ks, 4);
     t3 = now_s();

@@ -378,32 +378,38 @@ static void tally_one(void *arg, uint32_t s)
     sd_prog *p = &j->p[s];
     sd_chunk *c = j->c;
     uint64_t nh = 0, h = 0;
-    uint32_t *tally, n = 0, r, k;
+    uint32_t n = 0, r, k;
     int rc;
     p->job_rc = SK_OK;
     c->hits[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
     c->inf[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
     c->hbeg[s] = (uint32_t *)calloc((size_t)c->nrec + 2, sizeof(uint32_t));
     if (c->np == 0) return;
+    /* only the pieces that hit this strain at all come back (compacted on the device): with many strains against one
+     * metagenome nearly every (read, strain) pair is a blank */
     if (p->tallycap < c->np) {
         p->tallycap = c->np + c->np / 4 + 1024;
-        p->tallybuf = (uint32_t *)realloc(p->tallybuf, (size_t)p->tallycap * 8);
+        p->tallybuf = (uint32_t *)realloc(p->tallybuf, (size_t)p->tallycap * sizeof(sk_tally_rec));
     }
-    tally = p->tallybuf;
-    if ((rc = sk_tally_collect(p->ctx, tally, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
+    sk_tally_rec *sparse = (sk_tally_rec *)p->tallybuf;
+    uint64_t nsp = 0, e;
+    if ((rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
     if (nh > p->hitcap) {                                 /* the log overflowed: once more with room */
         p->hitcap = nh + nh / 4;
         p->hitbuf = (sk_hit *)realloc(p->hitbuf, (size_t)p->hitcap * sizeof(sk_hit));
         if ((rc = sk_tally_launch(p->ctx, j->batch, SD_TYPE, SD_INFORMATIVE, p->hitcap)) != SK_OK ||
-            (rc = sk_tally_collect(p->ctx, tally, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
+            (rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
+    }
+    for (e = 0; e < nsp; e++) {                           /* (a record cut into pieces: the pieces' windows add up) */
+        const uint32_t rec = c->prec[sparse[e].rec];
+        c->hits[s][rec] += sparse[e].all;
+        c->inf[s][rec] += sparse[e].inf;
     }
     qsort(p->hitbuf, (size_t)nh, sizeof(sk_hit), hit_cmp);
     c->rows[s] = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
     for (k = 0, r = 0; k < c->np; k++) {
         const uint32_t rec = c->prec[k], end = k + 1 < c->np ? c->pstart[k + 1] : 0xFFFFFFFFu;
         for (; r <= rec; r++) c->hbeg[s][r] = n;          /* records without a piece own an empty range */
-        c->hits[s][rec] = tally[2 * k];
-        c->inf[s][rec] = tally[2 * k + 1];
         while (h < nh && p->hitbuf[h].pos < end) c->rows[s][n++] = p->hitbuf[h++].row;
     }
     for (; r <= c->nrec; r++) c->hbeg[s][r] = n;

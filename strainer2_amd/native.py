@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "sk_table_load_wide", "sk_table_load_text", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
     "sk_ticket_wait", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
-    "sk_counts_allreduce", "sk_comm_init", "sk_comm_destroy", "sk_comm_sum_u32", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
+    "sk_counts_allreduce", "sk_comm_init", "sk_comm_init_ex", "sk_rendezvous_exchange", "sk_comm_destroy", "sk_comm_sum_u32", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
     "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
     "sk_distinct_count", "sk_first_seen_count", "skh_coverage_depth_main",
-    "sk_batch_create", "sk_batch_destroy", "sk_batch_fill", "sk_tally_launch", "sk_tally_collect",
+    "sk_batch_create", "sk_batch_destroy", "sk_batch_fill", "sk_tally_launch", "sk_tally_collect", "sk_tally_collect_sparse",
 ]
 
 
@@ -96,6 +96,7 @@ lib.sk_table_rows.restype = C.c_uint32
 lib.sk_table_cols.argtypes = [C.c_void_p]
 lib.sk_table_cols.restype = C.c_uint32
 lib.sk_counts_allreduce.argtypes = [C.c_void_p, C.c_void_p]
+lib.sk_rendezvous_exchange.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_double]
 lib.sk_scan_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
 lib.sk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
 lib.sk_dev_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64]
@@ -139,6 +140,7 @@ lib.sk_batch_destroy.restype = None
 lib.sk_batch_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
 lib.sk_tally_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
 lib.sk_tally_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+lib.sk_tally_collect_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]
 
 _libc = C.CDLL(None)
 _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]

@@ -121,6 +121,18 @@ int sk_tally_collect(sk_ctx *c, uint32_t *tally, sk_hit *hits, uint64_t *nhits)
     *nhits = nh;
     return SK_OK;
 }
+int sk_tally_collect_sparse(sk_ctx *c, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *hits, uint64_t *nhits)
+{
+    const uint32_t nrec = c->inflight->nrec;
+    uint32_t *dense = calloc((size_t)nrec * 2 + 2, 4), r;
+    uint64_t k = 0;
+    const int rc = sk_tally_collect(c, dense, hits, nhits);
+    for (r = 0; r < nrec; r++)
+        if (dense[2 * r]) { if (k < cap) { out[k].rec = r; out[k].all = dense[2 * r]; out[k].inf = dense[2 * r + 1]; } k++; }
+    *n = k;
+    free(dense);
+    return rc;
+}
 int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec, uint32_t type_col,
                    uint32_t inf_value, uint32_t *tally, sk_hit *hits, uint64_t cap, uint64_t *nhits)
 {
@@ -169,6 +181,7 @@ int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64
 int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return SK_OK; }
 int sk_sync(sk_ctx *c) { (void)c; return SK_OK; }
 int sk_comm_init(sk_ctx *c, int r, int w, const char *f, int t) { (void)c; (void)r; (void)w; (void)f; (void)t; return die("sk_comm_init"); }
+int sk_comm_init_ex(sk_ctx *c, int r, int w, const char *f, int t, int s) { (void)c; (void)r; (void)w; (void)f; (void)t; (void)s; return die("sk_comm_init_ex"); }
 int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s) { (void)c; (void)v; (void)s; return die("sk_comm_sum_u32"); }
 int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return die("sk_counts_zero"); }
 int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return die("sk_counts_allreduce"); }
@@ -180,7 +193,9 @@ int sk_first_seen_count(sk_ctx *ctx, const uint32_t *id, const uint32_t *sample,
     return die("sk_first_seen_count");
 }
 
+#ifndef DOUBLE_NO_MAIN
 #ifndef DOUBLE_MAIN
 #define DOUBLE_MAIN skh_strain_detect_main
 #endif
 int main(int argc, char **argv) { return DOUBLE_MAIN(argc, argv, stdout, stderr); }
+#endif

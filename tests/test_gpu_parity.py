@@ -464,3 +464,51 @@ def test_strain_with_more_keys_than_2_pow_24():
     # every window of read 0 (forward strand copy of the strain at starts[0]) is counted at least once
     keys = ks.keys()
     assert len(keys) == ks.nrows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_sharded_list_adds_up_on_the_device(world, tmp_path, monkeypatch):
+    """SURVEY 8(e) from the product's side: every rank scans ITS share of a skewed list (skh_scan_list's own dealing
+    by size and cutting of the big file), the ranks' raw counter blocks -- as they lie on the device, locality order,
+    exactly what the RCCL all-reduce sums -- are added mod 2^32, and the result is the unsharded block and the oracle's
+    counts.  (Several contexts on one device stand in for the ranks.)"""
+    rng = random.Random(4242 + world)
+    strain = _synth.rand_dna(rng, 80_000)
+    sstream = strain + b"\n"
+    sizes = [9000, 300, 1200, 40, 700]                                  # reads per file: one file dominates
+    names = []
+    for i, n in enumerate(sizes):
+        data = _synth.fuzz_stream(rng, strain, n, p_junk=0.002, min_len=20, max_len=300)
+        recs = [r for r in data.split(b"\n") if r]
+        p = tmp_path / f"f{i}.fa"
+        p.write_bytes(b"".join(b">r%d\n%s\n" % (j, r) for j, r in enumerate(recs)))
+        names.append(str(p))
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(n + "\n" for n in names))
+    monkeypatch.setenv("SK_SPLIT_BYTES", "200000")                      # so that the big file IS cut into pieces
+    monkeypatch.setenv("SK_THREADS", "3")
+    ks = sk.Keyset.from_stream(sstream)
+
+    def block(rank, nranks):
+        with sk.KmerContext(0) as c:
+            c.load_keyset(ks, 4)
+            c.zero_counts(0)                                            # (column 0 holds the build counts: not part of the sum)
+            c.scan_list(str(lst), 2, rank=rank, world=nranks)
+            c.sync()
+            raw = c.dev_download(c.counts_device_ptr(), 4 * 4 * ks.nrows).view(np.uint32).copy()
+            return raw, c.counts(2)
+
+    whole, whole_rows = block(0, 1)
+    total = np.zeros_like(whole)
+    for r in range(world):
+        total += block(r, world)[0]                                     # (uint32: wraps like the all-reduce)
+    assert np.array_equal(total, whole)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    for n in names:
+        for rec in open(n, "rb").read().split(b"\n"):
+            if rec and not rec.startswith(b">"):
+                t.scan_stream(rec + b"\n", 2)
+    _, ocounts = t.rows()
+    assert np.array_equal(whole_rows, ocounts[:, 2]) and whole_rows.sum() > 100_000

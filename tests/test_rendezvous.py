@@ -1,0 +1,88 @@
+"""The file rendezvous that precedes the RCCL collective (strainer2_amd/csrc/sk_rendezvous.h), several processes on the
+CPU: freshness (files left by a crashed launch are ignored), agreement on a failed set-up before anyone would block,
+and bounded waits.  New relative to the reference, which is single-process."""
+import ctypes as C
+import multiprocessing as mp
+import os
+import struct
+import time
+
+import pytest
+
+import strainer2_amd.native as native
+
+MAGIC = 0x534B5244565A3031
+
+
+def _rank(rank, world, base, status, timeout, delay, q):
+    if delay:
+        time.sleep(delay)
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        for i in range(128):
+            buf[i] = (i * 7 + 1) & 0xFF
+    rc = native.lib.sk_rendezvous_exchange(rank, world, base.encode(), status, buf, timeout)
+    q.put((rank, rc, bytes(buf)))
+
+
+def _run(world, base, status=None, timeout=10.0, absent=(), delays=None):
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    ps = []
+    for r in range(world):
+        if r in absent:
+            continue
+        p = ctx.Process(target=_rank, args=(r, world, base, (status or {}).get(r, 0), timeout, (delays or {}).get(r, 0), q))
+        p.start()
+        ps.append(p)
+    out = {}
+    for _ in ps:
+        r, rc, payload = q.get(timeout=timeout + 20)
+        out[r] = (rc, payload)
+    for p in ps:
+        p.join(timeout=10)
+    return out
+
+
+WANT = bytes((i * 7 + 1) & 0xFF for i in range(128))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_everyone_gets_rank0s_payload(tmp_path, world):
+    out = _run(world, str(tmp_path / "id"))
+    assert all(rc == 0 for rc, _ in out.values()), out
+    assert all(payload == WANT for _, payload in out.values())
+
+
+def test_leftovers_of_a_crashed_launch_are_ignored(tmp_path):
+    base = str(tmp_path / "id")
+    world = 4
+    # a board and hello files with the right magic and shape, but the tokens of another launch
+    board = struct.pack("<QII", MAGIC, world, 0) + struct.pack("<64Q", *([0x1111] * 64)) + bytes(128)
+    open(base, "wb").write(board)
+    for r in range(1, world):
+        open(f"{base}.hello.{r}", "wb").write(struct.pack("<QIIQII", MAGIC, r, world, 0x2222, 0, 0))
+    # rank 0 starts late: the others meet the stale board first and must not take it
+    out = _run(world, base, delays={0: 0.8})
+    assert all(rc == 0 for rc, _ in out.values()), out
+    assert all(payload == WANT for _, payload in out.values())
+
+
+@pytest.mark.parametrize("bad", [0, 2])
+def test_a_failed_set_up_makes_everyone_leave(tmp_path, bad):
+    out = _run(4, str(tmp_path / "id"), status={bad: 1})
+    assert all(rc == 1 for rc, _ in out.values()), out          # SKR_ABORT on every rank, nobody enters the collective
+
+
+def test_a_rank_that_never_shows_up_is_a_bounded_wait(tmp_path):
+    t0 = time.time()
+    out = _run(4, str(tmp_path / "id"), timeout=1.5, absent=(3,))
+    assert time.time() - t0 < 15
+    assert out[0][0] == 2                                        # rank 0 timed out ...
+    assert all(rc in (1, 2) for rc, _ in out.values()), out      # ... and told the ones that did arrive to leave (or they timed out too)
+
+
+def test_without_rank0_the_others_time_out(tmp_path):
+    out = _run(3, str(tmp_path / "id"), timeout=1.0, absent=(0,))
+    assert all(rc == 2 for rc, _ in out.values()), out
+    assert not [f for f in os.listdir(tmp_path) if "hello" in f]   # their hello files are gone

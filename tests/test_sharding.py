@@ -1,0 +1,111 @@
+"""How a -A/-B list is shared out: items dealt to ranks by size, big plain-text files cut into byte-range
+pieces at CHECKED record boundaries (strainer2_amd/csrc/sk_host.c).  The identity that makes both harmless --
+the ranks' count vectors add up to the unsharded one (src/genome_compare.c:220-223: counters only ever get +1) -- is
+run on the CPU with the plain-C device double, world 2/4/8, several decode threads, under ASan+UBSan."""
+import gzip
+import os
+import random
+import subprocess
+
+import pytest
+
+import _synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = [os.path.join(REPO, "tests", "native", f) for f in ("shard_check.c", "device_double.c")] + \
+      [os.path.join(REPO, "strainer2_amd", "csrc", f) for f in ("sk_host.c", "sk_host_sd.c", "sk_host_cov.c")]
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("shard") / "shard_check")
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-DDOUBLE_NO_MAIN"] + SRC +
+                   ["-lz", "-lpthread", "-o", out], check=True)
+    return out
+
+
+def _fastq(rng, strain, n, wrap_qual_at=False):
+    out = []
+    for i in range(n):
+        L = rng.choice([31, 60, 150, 150, 150, 250])
+        if rng.random() < 0.5:
+            a = rng.randrange(0, len(strain) - L)
+            s = strain[a:a + L]
+        else:
+            s = _synth.rand_dna(rng, L)
+        q = bytes(rng.choice(b"@+>IIIIFF#") for _ in range(L)) if wrap_qual_at else b"I" * L   # quality lines that begin with @, + or >
+        out.append(b"@r%d some comment\n%s\n+\n%s\n" % (i, s, q))
+    return b"".join(out)
+
+
+def _fasta(rng, strain, n, width):
+    out = []
+    for i in range(n):
+        L = rng.randrange(100, 30000)
+        a = rng.randrange(0, max(1, len(strain) - L))
+        s = strain[a:a + L] if rng.random() < 0.6 else _synth.rand_dna(rng, L)
+        out.append(b">c%d\n" % i + (b"\n".join(s[j:j + width] for j in range(0, len(s), width)) if width else s) + b"\n")
+    return b"".join(out)
+
+
+@pytest.fixture(scope="module")
+def world_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("shard_data")
+    rng = random.Random(2024)
+    strain = _synth.rand_dna(rng, 60000)
+    open(d / "strain.fa", "wb").write(b">s\n" + strain + b"\n")
+    files = {
+        "big.fq": _fastq(rng, strain, 6000),                       # by far the biggest: has to be cut or one rank does it all
+        "tricky.fq": _fastq(rng, strain, 2500, wrap_qual_at=True),  # quality lines beginning with @ / + / >
+        "wrapped.fa": _fasta(rng, strain, 60, 60),
+        "oneline.fa": _fasta(rng, strain, 40, 0),                   # records longer than a piece
+        "small1.fq": _fastq(rng, strain, 50),
+        "small2.fa": _fasta(rng, strain, 3, 70),
+        "crlf.fq": _fastq(rng, strain, 300).replace(b"\n", b"\r\n"),
+    }
+    for name, data in files.items():
+        open(d / name, "wb").write(data)
+    with gzip.open(d / "zipped.fq.gz", "wb") as f:
+        f.write(_fastq(rng, strain, 800))
+    names = list(files) + ["zipped.fq.gz", "small1.fq"]             # (a duplicate line: scanned twice, as the reference does)
+    open(d / "list.txt", "w").write("".join(str(d / n) + "\n" for n in names))
+    return d
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("split", ["20000", "150000", None])
+def test_sharded_sums_equal_the_unsharded_scan(exe, world_files, world, split):
+    env = dict(os.environ, SK_THREADS="3", ASAN_OPTIONS="detect_leaks=0")
+    if split:
+        env["SK_SPLIT_BYTES"] = split          # piece size: far below the 32 MiB floor, so that these small files ARE cut
+    else:
+        env["SK_NO_SPLIT"] = "1"               # dealing by size only
+    p = subprocess.run([exe, str(world_files / "strain.fa"), str(world_files / "list.txt"), str(world)], env=env,
+                       capture_output=True, timeout=600)
+    assert p.returncode == 0, (p.stdout, p.stderr[-2000:])
+    tag, total, bases = p.stdout.split()
+    assert tag == b"OK" and int(total) > 100000 and int(bases) > 1000000
+
+
+def test_a_file_that_cannot_be_cut_safely_fails_the_run(exe, tmp_path):
+    """wrapped FASTQ whose quality lines imitate a header two lines before a '+' line: the guess lands inside a record,
+    the check after the piece before it notices (parser not between two records) and the scan FAILS (SK_E_SPLIT = -9)
+    instead of counting a different set of records; with SK_NO_SPLIT=1 the same list goes through"""
+    rng = random.Random(5)
+    strain = _synth.rand_dna(rng, 20000)
+    open(tmp_path / "strain.fa", "wb").write(b">s\n" + strain + b"\n")
+    recs = []
+    for i in range(400):
+        a = rng.randrange(0, len(strain) - 150)
+        s = strain[a:a + 150]
+        q = b"@" + b"I" * 49 + b"\n" + b"I" * 50 + b"\n" + b"+" + b"I" * 49          # three quality lines: "@..", "..", "+.."
+        recs.append(b"@r%d\n%s\n%s\n%s\n+\n%s\n" % (i, s[:50], s[50:100], s[100:], q))
+    open(tmp_path / "wrapped.fq", "wb").write(b"".join(recs))
+    open(tmp_path / "list.txt", "w").write(str(tmp_path / "wrapped.fq") + "\n")
+    env = dict(os.environ, SK_THREADS="3", ASAN_OPTIONS="detect_leaks=0", SK_SPLIT_BYTES="5000")
+    p = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "2"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 1 and b"failed: -9" in p.stdout and b"could not be cut at record boundaries" in p.stderr
+    env.pop("SK_SPLIT_BYTES")
+    env["SK_NO_SPLIT"] = "1"
+    p = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "2"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith(b"OK")

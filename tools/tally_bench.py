@@ -19,7 +19,7 @@ contigs = synth.make_strain()
 ks = sk.Keyset.from_stream(synth.strain_stream(contigs), default_val=1, incr=0)
 reads, nbases = synth.make_reads(contigs, READS)
 rec = 151
-per = (48 << 20) // rec
+per = (int(os.environ.get("BATCH_MIB", "48")) << 20) // rec          # records per batch (the program hands over 32 MiB chunks)
 with sk.KmerContext(0) as ctx:
     ctx.load_keyset(ks, 6)
     t = np.ones(ks.nrows, dtype=np.uint32)
