@@ -270,6 +270,12 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err);
  * stdout go to `out`, stderr texts to `err`; the -o file is gzip (members compressed in parallel; the
  * decompressed bytes are the reference's).  Returns the exit status. */
 int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err);
+/* The same on a strain that is ALREADY resident (the table of step 1 serves step 3): ctx holds its table,
+ * loaded with at least 6 columns, *ks its key set -- both are taken over and released by the call --; informative_path is
+ * what -a would name.  argv = the rest of a strain_detect command line (-B/-b/-c/-t/-g/-o, --coverage-depth ...), argv[0]
+ * ignored; -r and -a are implied.  `kmer_scrub_count ... --scrub m --detect <those arguments>` runs the reference's
+ * steps 1 to 3 (4 with --coverage-depth) in one process this way. */
+int skh_strain_detect_resident(sk_ctx *ctx, skh_keyset *ks, const char *informative_path, int argc, char **argv, FILE *out, FILE *err);
 
 /* Record reader exposed for tests: decode `path` into the record stream, calling `sink` with
  * successive chunks (records separated by '\n'; a long record may be cut with a k-1 overlap).

@@ -1112,13 +1112,28 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     double scrub_fraction = -1.0;                    /* >= 0: print the scrub filter's result instead of the table */
     int scrub_independent = 0, j;
+    const char *scrub_out = NULL;                    /* --scrub-out FILE: the filter's result goes there instead of stdout */
+    int detect_argc = 0;                             /* --detect ...: strain_detect's arguments, run on the resident table */
+    char **detect_argv = NULL;
 
     /* Extension (not in the reference): "--scrub <min_fraction>" [--independent] runs step 2 of the
      * workflow (scripts/kmer_scrub_filter.py -s <table> -m <min_fraction> [-i]) on the counters while
      * they are still on the device and prints ITS output; the 38-bytes-per-k-mer table is never written.
      * The words are taken out of argv before getopt, which only knows the reference's letters. */
+    /* "--detect <strain_detect arguments>" (extension; needs --scrub): after steps 1 and 2 the same process goes on into
+     * step 3 on the SAME resident table (key set, row order, device table, filters and strain text built once; SURVEY
+     * 8(f3)): -r is this run's, -a is the list --scrub just produced; everything behind --detect is strain_detect's
+     * command line (-B/-b/-c/-t/-g/-o, --coverage-depth ...).  "--scrub-out FILE" keeps the informative list. */
+    for (c = 1; c < argc; c++)
+        if (!strcmp(argv[c], "--detect")) {
+            detect_argv = argv + c;                  /* argv[0] of the second command line: ignored there */
+            detect_argc = argc - c;
+            argc = c;
+            break;
+        }
     for (c = 1, j = 1; c < argc; c++) {
         if (!strcmp(argv[c], "--independent")) { scrub_independent = 1; continue; }
+        if (!strcmp(argv[c], "--scrub-out") && c + 1 < argc) { scrub_out = argv[++c]; continue; }
         if (!strncmp(argv[c], "--scrub", 7) && (argv[c][7] == 0 || argv[c][7] == '=')) {
             const char *v = argv[c][7] ? argv[c] + 8 : (c + 1 < argc ? argv[++c] : "");
             char *e;
@@ -1146,6 +1161,10 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
         }
     }
     if (!R || !A || !B) { usage(err); return 1; }
+    if (detect_argv && (scrub_fraction < 0.0 || world > 1)) {
+        fprintf(err, "kmer_scrub_count: --detect needs --scrub <min_fraction> and a single process\n");
+        return 1;
+    }
     if (world < 1 || rank < 0 || rank >= world) { fprintf(err, "kmer_scrub_count: bad rank %d of %d\n", rank, world); return 1; }
     if (P && rank == 0) {
         progress = fopen(P, "w");
@@ -1194,7 +1213,7 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
             if (rc != SK_OK) goto done;
         } else if (setup_failed) goto done;
     }
-    rc = skh_keyset_load(ctx, &ks, 4);
+    rc = skh_keyset_load(ctx, &ks, detect_argv ? 6 : 4);        /* (strain_detect's table has six columns) */
     t3 = now_s();
     if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); failed = 1; }
     if (rc == SK_OK && world > 1) rc = sk_counts_zero(ctx, 0);      /* column 0 must not be summed world times: keep it on rank 0 */
@@ -1213,8 +1232,35 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     } else if (failed) goto done;
     t4 = now_s();
     if (rank == 0 && scrub_fraction >= 0.0) {
-        status = skh_scrub_filter_resident(ctx, &ks, C != NULL, scrub_fraction, scrub_independent, out, err);
+        FILE *so = out;
+        char tmp_path[64] = "";
+        const char *list_path = scrub_out;
+        if (detect_argv && !scrub_out) {              /* step 3 reads the list from a file: a temporary one, copied to stdout */
+            int fd;
+            snprintf(tmp_path, sizeof tmp_path, "/tmp/sk_scrubbed.XXXXXX");
+            fd = mkstemp(tmp_path);
+            if (fd < 0) { fprintf(err, "kmer_scrub_count: cannot create a temporary file for the informative k-mers\n"); goto done; }
+            close(fd);
+            list_path = tmp_path;
+        }
+        if (list_path && !(so = fopen(list_path, "w"))) { fprintf(err, "kmer_scrub_count: cannot write %s\n", list_path); goto done; }
+        status = skh_scrub_filter_resident(ctx, &ks, C != NULL, scrub_fraction, scrub_independent, so, err);
+        if (so != out) fclose(so);
+        if (tmp_path[0] && status == 0) {             /* no --scrub-out: the list still goes to stdout, as --scrub alone does */
+            FILE *f = fopen(tmp_path, "r");
+            char blk[65536];
+            size_t got;
+            while (f && (got = fread(blk, 1, sizeof blk, f)) > 0) fwrite(blk, 1, got, out);
+            if (f) fclose(f);
+            fflush(out);
+        }
         t5 = now_s();
+        if (status == 0 && detect_argv) {
+            sk_ctx *c2 = ctx;
+            ctx = NULL;                               /* ctx and ks now belong to strain_detect, which releases them */
+            status = skh_strain_detect_resident(c2, &ks, list_path, detect_argc, detect_argv, out, err);
+        }
+        if (tmp_path[0]) unlink(tmp_path);
         goto done;
     }
     if (rank == 0) {

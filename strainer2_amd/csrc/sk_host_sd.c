@@ -853,9 +853,23 @@ static void *sd_keyset_pool_thread(void *arg)
     }
 }
 
+/* the informative rows, the -g filter, the output file: the part of a strain's opening that follows the table load */
+static int sd_strain_flags(sd_prog *p, const char *a, const char *g, const char *o)
+{
+    unsigned n_inform = 0, i;
+    p->type = (uint32_t *)malloc((size_t)(p->ks.nrows ? p->ks.nrows : 1) * sizeof(uint32_t));
+    for (i = 0; i < p->ks.nrows; i++) p->type[i] = SD_PLAIN;
+    if (sd_flag_informative(p, a, &n_inform)) return 1;
+    if (g && sd_background_filter(p, g, 0.5, n_inform)) return 1;
+    for (i = 0; i < p->ks.nrows; i++) if (p->type[i] == SD_INFORMATIVE) p->genome_inf++;
+    p->zo = skzo_open(sd_zpool, o);
+    if (!p->zo) { fprintf(p->err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
+    p->o_path = strdup(o);
+    return 0;
+}
+
 static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a, const char *g, const char *o, int device)
 {   /* p->ctx may already hold a context opened in the background (single-strain start-up) */
-    unsigned n_inform = 0, i;
     int rc = ks_rc;
     FILE *err = p->err;
     if (rc == SK_E_OPEN) { fprintf(err, "could not read file %s GEN_hash_sequences_set_count_vec()\n", r); return 1; }
@@ -867,15 +881,30 @@ static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a,
     if (rc != SK_OK) { fprintf(err, "strain_detect: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); return 1; }
     rc = skh_keyset_load(p->ctx, &p->ks, SD_NCOLS);
     if (rc != SK_OK) { fprintf(err, "strain_detect: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
-    p->type = (uint32_t *)malloc((size_t)(p->ks.nrows ? p->ks.nrows : 1) * sizeof(uint32_t));
-    for (i = 0; i < p->ks.nrows; i++) p->type[i] = SD_PLAIN;
-    if (sd_flag_informative(p, a, &n_inform)) return 1;
-    if (g && sd_background_filter(p, g, 0.5, n_inform)) return 1;
-    for (i = 0; i < p->ks.nrows; i++) if (p->type[i] == SD_INFORMATIVE) p->genome_inf++;
-    p->zo = skzo_open(sd_zpool, o);
-    if (!p->zo) { fprintf(err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
-    p->o_path = strdup(o);
-    return 0;
+    return sd_strain_flags(p, a, g, o);
+}
+
+/* The strain of a kmer_scrub_count run that goes on into strain_detect in the same process (key set, row
+ * order, device table, filters and text are built ONCE for steps 1 and 3; src/strain_detect.c:137-146 rebuilds what
+ * src/kmer_scrub_count.c:87-89 built).  Takes over ctx and *ks (the caller's copy is cleared); the table must have been
+ * loaded with at least SD_NCOLS columns.  Every column goes back to what a fresh strain_detect start has. */
+static int sd_strain_adopt(sd_prog *p, sk_ctx *ctx, skh_keyset *ks, const char *a, const char *g, const char *o, FILE *out, FILE *err)
+{
+    uint32_t col;
+    int rc = SK_OK;
+    memset(p, 0, sizeof *p);
+    p->out = out; p->err = err; p->ctx = ctx; p->ks = *ks;
+    memset(ks, 0, sizeof *ks);
+    if (sk_table_cols(ctx) < SD_NCOLS || sk_table_rows(ctx) != p->ks.nrows) { fprintf(err, "strain_detect: the resident table does not fit (columns/rows)\n"); return 1; }
+    for (col = 0; col < SD_NCOLS && rc == SK_OK; col++) rc = sk_counts_zero(ctx, col);
+    if (rc == SK_OK && p->ks.nrows) {
+        uint32_t *plain = (uint32_t *)malloc((size_t)p->ks.nrows * sizeof(uint32_t)), i;
+        for (i = 0; i < p->ks.nrows; i++) plain[i] = SD_PLAIN;
+        rc = sk_counts_set(ctx, SD_TYPE, plain);               /* what skh_keyset_load(.., default SD_PLAIN, incr 0) leaves there */
+        free(plain);
+    }
+    if (rc != SK_OK) { fprintf(err, "strain_detect: device error: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); return 1; }
+    return sd_strain_flags(p, a, g, o);
 }
 
 /* --coverage-depth: where the table of strain p goes, and the accumulator that collects it */
@@ -969,7 +998,20 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
     return bad;
 }
 
-int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
+static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *adopt_ctx, skh_keyset *adopt_ks, const char *adopt_a);
+
+int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err) { return sd_main_impl(argc, argv, out, err, NULL, NULL, NULL); }
+
+/* strain_detect on a strain that is already resident: ctx holds its table (>= 6 columns), *ks its key set -- both are
+ * taken over and released here -- and informative_path names the informative k-mer list (what -a would name).  argv: the
+ * rest of a strain_detect command line (-B/-b/-c/-t/-g/-o, --coverage-depth ...), argv[0] ignored; -r and -a are implied. */
+int skh_strain_detect_resident(sk_ctx *ctx, skh_keyset *ks, const char *informative_path, int argc, char **argv, FILE *out, FILE *err)
+{
+    if (!ctx || !ks || !informative_path) return 1;
+    return sd_main_impl(argc, argv, out, err, ctx, ks, informative_path);
+}
+
+static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *adopt_ctx, skh_keyset *adopt_ks, const char *adopt_a)
 {
     const char *a = NULL, *r = NULL, *b = NULL, *b2 = NULL, *B = NULL, *tt = NULL, *g = NULL, *o = NULL, *S = NULL, *env;
     int c, j, mode = SD_SE, status = 1, device = 0, n_S = 0, want_cov = 0;
@@ -1017,6 +1059,7 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
      * line of the file is  <reference genome> TAB <informative k-mer file> TAB <outfile> [TAB <-g list>];
      * every outfile gets exactly what a separate run with that line's -r/-a/-o[/-g] would write.  All
      * tables stay resident on the device; each metagenome is decoded and uploaded once. */
+    if (adopt_ctx) { a = adopt_a; r = "(resident)"; S = NULL; }
     if (S && !a && !o && !r) {
         if (!b && !B) { usage(err); return 1; }
     } else {
@@ -1116,7 +1159,7 @@ int skh_strain_detect_main(int argc, char **argv, FILE *out, FILE *err)
     } else {
         p = (sd_prog *)malloc(sizeof *p);
         ns = 1;
-        if (sd_strain_open(&p[0], r, a, g, o, device, out, err)) goto done;
+        if (adopt_ctx ? sd_strain_adopt(&p[0], adopt_ctx, adopt_ks, a, g, o, out, err) : sd_strain_open(&p[0], r, a, g, o, device, out, err)) goto done;
     }
     t_setup = now_s() - t_begin;
     for (s = 0; want_cov && s < ns; s++)

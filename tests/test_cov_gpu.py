@@ -107,3 +107,32 @@ def test_fused_coverage_equals_separate_step(golden, tmp_path, name, extra):
     q = subprocess.run([sk.cli_path("coverage_depth"), "-k", hits] + m, capture_output=True)
     assert q.returncode == 0 and q.stdout.count(b"\n") >= 2
     assert open(cov, "rb").read() == q.stdout
+
+
+def test_bundled_workflow_in_one_process(golden, tmp_path):
+    """test/example.sh steps 1 to 4 in ONE process -- `kmer_scrub_count ... --scrub 0.01 --detect ...` keeps
+    the strain's key set, row order and device table from step 1 for step 3 (src/strain_detect.c:137-146 rebuilds what
+    src/kmer_scrub_count.c:87-89 built).  The informative list, the hit list and the coverage table must be the ones the
+    reference's own programs and scripts produced."""
+    import gzip
+    import hashlib
+    b = os.path.join(golden, "bundled")
+    f1 = json.load(open(os.path.join(b, "step1_facts.json")))
+    f3 = json.load(open(os.path.join(b, "step3_facts.json")))
+    nm = "Bacteroides_ovatus_1001283st1_B8_1001283B150210_160208.kmer_hits.gz"
+    rest = list(f3["argv"])
+    for flag in ("-r", "-a"):                                   # implied: this run's strain, the list --scrub produces
+        i = rest.index(flag)
+        del rest[i:i + 2]
+    rest[rest.index("-o") + 1] = str(tmp_path / nm)
+    scrubbed = tmp_path / "scrubbed_kmers"
+    p = subprocess.run([sk.cli_path()] + f1["argv"] + ["--scrub", "0.01", "--scrub-out", str(scrubbed), "--detect"] + rest + ["--coverage-depth"],
+                       cwd=b, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert hashlib.md5(open(scrubbed, "rb").read()).hexdigest() == "fe981fa571be70e602875ac3463ecdac"      # step 2
+    assert hashlib.md5(gzip.open(tmp_path / nm, "rb").read()).hexdigest() == f3["hits_md5"]         # step 3
+    want = open(os.path.join(COV_CASES, "bundled_step4", "expected.stdout"), "rb").read()
+    assert open(tmp_path / nm.replace(".kmer_hits.gz", ".coverage_depth"), "rb").read() == want            # step 4
+    # without --scrub-out the informative list goes to stdout, as with --scrub alone
+    q = subprocess.run([sk.cli_path()] + f1["argv"] + ["--scrub", "0.01", "--detect"] + rest, cwd=b, capture_output=True)
+    assert q.returncode == 0 and hashlib.md5(q.stdout).hexdigest() == "fe981fa571be70e602875ac3463ecdac"
