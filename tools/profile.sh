@@ -9,8 +9,8 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu --no-host-rate $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
+ARGS="--steps 5 --warmup 1 --no-cpu --no-host-rate --file-reads 0 $@"   # (only the resident launches: per-launch averages must be of one size)
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 grep '^{' $OUT/trace.log > $OUT/bench_line.json
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
@@ -19,6 +19,6 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
            "TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 bench.py $ARGS > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i ($PMC) failed"; tail -3 $OUT/pmc$i.log; }
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 bench.py $ARGS > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i ($PMC) failed"; tail -3 $OUT/pmc$i.log; }
 done
 python3 tools/profile_summary.py $OUT

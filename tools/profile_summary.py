@@ -37,7 +37,7 @@ with open(os.path.join(out, "summary.txt"), "w") as f:
     for k, v in sorted(summary["kernels"].items(), key=lambda kv: -kv[1]["pct"]):
         f.write(f"{k:28s} calls={v['calls']:4d} avg={v['avg_ns'] / 1e6:10.4f} ms  {v['pct']:6.2f}%\n")
     for k, cs in summary["counters"].items():
-        if "sk_scan_main" not in k and "sk_scan_grid" not in k:
+        if "sk_scan_grid" not in k:
             continue
         f.write(f"\n[{k}] per-launch averages\n")
         for c, v in sorted(cs.items()):
@@ -45,7 +45,8 @@ with open(os.path.join(out, "summary.txt"), "w") as f:
         fs = cs.get("FETCH_SIZE")
         ws = cs.get("WRITE_SIZE")
         if fs is not None:
-            f.write(f"  -> FETCH_SIZE KiB x1024 = {fs * 1024 / 1e9:.3f} GB raw; x2 (gfx950 streaming correction) = {fs * 2048 / 1e9:.3f} GB\n")
+            f.write(f"  -> FETCH_SIZE KiB x1024 = {fs * 1024 / 1e9:.3f} GB raw (gfx950 tallies the 128-B requests of the streaming read at 64 B: "
+                    f"tools/save_profile.py adds half of the record stream's bytes, for the streaming share only)\n")
         if ws is not None:
             f.write(f"  -> WRITE_SIZE = {ws * 1024 / 1e9:.3f} GB\n")
 print(open(os.path.join(out, "summary.txt")).read())
