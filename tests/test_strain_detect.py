@@ -267,3 +267,23 @@ def test_sd_strain_list_with_background_column(golden, tmp_path):
     assert p.stdout == out + out and p.stderr == err + err
     for f in ("a.gz", "b.gz"):
         assert gzip.open(tmp_path / f, "rb").read() == hits
+
+
+@pytest.mark.gpu
+def test_sd_32_strains_against_32_oracle_runs(tmp_path):
+    """cfg 5 in miniature (one GPU's share of 256 strains is 32): 32 small strains resident at once, ONE pass over the
+    metagenomes (each chunk uploaded once, 32 launches, sparse tallies back), every strain's hit list byte-identical
+    (decompressed) to a separate run of the CPU oracle program on that strain (src/strain_detect.c:387-663)."""
+    n = _make_multi_inputs(tmp_path, nstrains=32, strain_len=20_000, nreads=60_000)
+    exe = sk.cli_path("strain_detect")
+    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt")], capture_output=True)
+    assert multi.returncode == 0, multi.stderr.decode()[-500:]
+    total = 0
+    for s in range(n):
+        ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / f"s{s}.fa"), "-a", str(tmp_path / f"s{s}.inf.gz"), "-B", str(tmp_path / "B.txt"),
+                                         "-o", str(tmp_path / f"oracle{s}.gz")], str(tmp_path))
+        assert ora.returncode == 0
+        want = gzip.open(tmp_path / f"oracle{s}.gz", "rb").read()
+        assert gzip.open(tmp_path / f"multi{s}.gz", "rb").read() == want, s
+        total += want.count(b"\n")
+    assert total > 32 * 50

@@ -24,30 +24,36 @@ SEPARATE = int(os.environ.get("SEPARATE", str(NSTRAINS)))       # how many of th
 work = os.environ.get("WORK", "/tmp/sk_sdm")
 os.makedirs(work, exist_ok=True)
 rng = np.random.default_rng(11)
-acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 t0 = time.time()
 strains = []
 with open(os.path.join(work, "strains.txt"), "w") as lst:
     for s in range(NSTRAINS):
-        g = acgt[rng.integers(0, 4, STRAIN_BP)]
+        g = synth._rand_bases(rng, STRAIN_BP)
         strains.append(g)
         with open(os.path.join(work, f"s{s}.fa"), "wb") as f:
             f.write(b">s%d\n" % s + g.tobytes() + b"\n")
         ks = sk.Keyset.from_stream(g.tobytes() + b"\n")
-        keys = ks.keys()
-        pick = rng.choice(len(keys), size=len(keys) // 100, replace=False)
+        pick = np.sort(rng.choice(ks.nrows, size=ks.nrows // 100, replace=False))
         with open(os.path.join(work, f"s{s}.inf"), "wb") as f:
-            f.write(b"\n".join(keys[i] for i in sorted(pick)) + b"\n")
+            f.write(b"\n".join(ks.key(int(i)) for i in pick) + b"\n")
         ks.close()
         lst.write(f"{work}/s{s}.fa\t{work}/s{s}.inf\t{work}/multi{s}.gz\n")
-reads = acgt[rng.integers(0, 4, (READS, 150))]
-from_strain = np.flatnonzero(rng.random(READS) < 0.02)
-for i in from_strain:
-    g = strains[int(rng.integers(0, NSTRAINS))]
-    a = int(rng.integers(0, STRAIN_BP - 150))
-    reads[i] = g[a:a + 150]
+# the metagenome, written a block of reads at a time (10 Gbase = 66.7 M reads = 10.3 GB of FASTA)
+BLOCK = 2_000_000
+head = np.frombuffer(b">r\n", dtype=np.uint8)
 with open(os.path.join(work, "reads.fa"), "wb") as f:
-    f.write(b"".join(b">r%d\n%s\n" % (j, reads[j].tobytes()) for j in range(READS)))
+    for a0 in range(0, READS, BLOCK):
+        m = min(BLOCK, READS - a0)
+        blk = synth._rand_bases(rng, m * 150).reshape(m, 150)
+        for i in np.flatnonzero(rng.random(m) < 0.02):
+            g = strains[int(rng.integers(0, NSTRAINS))]
+            p0 = int(rng.integers(0, STRAIN_BP - 150))
+            blk[i] = g[p0:p0 + 150]
+        fa = np.empty((m, 3 + 151), dtype=np.uint8)
+        fa[:, :3] = head
+        fa[:, 3:153] = blk
+        fa[:, 153] = 10
+        fa.tofile(f)
 print(f"inputs ready in {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
 
 exe = os.path.join(REPO, "strainer2_amd", "bin", "strain_detect")
