@@ -512,3 +512,26 @@ def test_rank_sharded_list_adds_up_on_the_device(world, tmp_path, monkeypatch):
                 t.scan_stream(rec + b"\n", 2)
     _, ocounts = t.rows()
     assert np.array_equal(whole_rows, ocounts[:, 2]) and whole_rows.sum() > 100_000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["1", "5", "16"])
+def test_program_on_the_cfg3_shaped_job_equals_the_reference(golden, tmp_path, threads, monkeypatch):
+    """BASELINE configs[2] in shape through bin/kmer_scrub_count: a real 1000-line -A list, a multi-file -B list (plain and
+    .gz FASTQ), a -C list that holds the -r path (skip rule), -p.  stdout md5, stderr and the progress file (without its time
+    stamps) must be what the UNMODIFIED reference program produced for the same inputs (tests/golden/cfg3_shape_facts.json;
+    src/kmer_scrub_count.c:29-156, src/genome_compare.c:115-236) -- with one decode thread (the reference's strict sequence),
+    a few, and sixteen."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_cfg3_shape", os.path.join(golden, "make_cfg3_shape.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    facts = json.load(open(os.path.join(golden, "cfg3_shape_facts.json")))
+    argv = mk.write_inputs(str(tmp_path))
+    monkeypatch.setenv("SK_THREADS", threads)
+    p = subprocess.run([sk.cli_path()] + argv, cwd=str(tmp_path), capture_output=True)
+    assert p.returncode == facts["returncode"], p.stderr.decode()[-500:]
+    assert p.stderr.decode() == facts["stderr"]
+    got = mk.facts_of(p.stdout, p.stderr, str(tmp_path))
+    for k in ("md5_stdout", "lines", "column_sums", "md5_progress_without_times"):
+        assert got[k] == facts[k], k

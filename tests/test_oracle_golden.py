@@ -95,3 +95,25 @@ def test_oracle_equals_live_reference_on_fuzz(seed, tmp_path):
     assert ref.returncode == ora.returncode == 0
     assert ref.stdout == ora.stdout
     assert ref.stderr == ora.stderr
+
+
+def test_oracle_on_the_cfg3_shaped_job(golden, tmp_path):
+    """BASELINE configs[2] in shape -- a 1000-line -A list, a multi-file -B list (plain and .gz FASTQ), a -C list that holds
+    the -r path, -p -- against what the UNMODIFIED reference printed for the same inputs (tests/golden/cfg3_shape_facts.json,
+    made by tests/golden/make_cfg3_shape.py; the inputs are rebuilt here from the same seed)."""
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_cfg3_shape", os.path.join(golden, "make_cfg3_shape.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    facts = json.load(open(os.path.join(golden, "cfg3_shape_facts.json")))
+    argv = mk.write_inputs(str(tmp_path))
+    assert argv == facts["argv"]
+    p = _oracle.run_oracle_cli(argv, str(tmp_path))
+    assert p.returncode == facts["returncode"] and p.stderr.decode() == facts["stderr"]
+    got = mk.facts_of(p.stdout, p.stderr, str(tmp_path))
+    assert {k: got[k] for k in ("md5_stdout", "lines", "column_sums", "md5_progress_without_times")} == \
+           {k: facts[k] for k in ("md5_stdout", "lines", "column_sums", "md5_progress_without_times")}
+    if _oracle.have_reference():                     # where the reference binary exists: live, too
+        q = _oracle.run_reference_cli(argv, str(tmp_path))
+        assert hashlib.md5(q.stdout).hexdigest() == facts["md5_stdout"]
