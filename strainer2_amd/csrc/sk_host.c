@@ -722,37 +722,6 @@ static void worker_done(scan_worker *w)
     pthread_mutex_unlock(&w->pool->submit_mu);
 }
 
-/* First offset >= x of a plain FASTA/FASTQ text at which a record may start: a '>' or '@' at the start of a line --
- * for '@' with a '+' line two lines on, which sets it apart from a quality line that happens to begin with '@'
- * (src/kseq.h:171-211 has no such check, it reads from the top; a guess that is wrong is caught by parse_range). */
-static uint64_t guess_record_start(const unsigned char *t, uint64_t size, uint64_t x)
-{
-    uint64_t i = x;
-    if (x == 0) return 0;
-    while (i < size) {
-        const unsigned char *nl = (const unsigned char *)memchr(t + i - 1, '\n', (size_t)(size - (i - 1)));
-        uint64_t s;
-        if (!nl) return size;
-        s = (uint64_t)(nl - t) + 1;
-        if (s >= size) return size;
-        if (t[s] == '>') {
-            /* not if the line before begins with '+': then this is a FASTQ quality line that happens to begin with '>'
-             * (no line of a FASTA file begins with '+') */
-            uint64_t q = s >= 2 ? s - 2 : 0;
-            while (q > 0 && t[q] != '\n') q--;
-            if (!(s >= 2 && t[q == 0 && t[0] != '\n' ? 0 : q + 1] == '+')) return s;
-        }
-        if (t[s] == '@') {
-            const unsigned char *l1 = (const unsigned char *)memchr(t + s, '\n', (size_t)(size - s));
-            const unsigned char *l2 = l1 && (uint64_t)(l1 - t) + 1 < size ? (const unsigned char *)memchr(l1 + 1, '\n', (size_t)(size - ((uint64_t)(l1 - t) + 1))) : NULL;
-            if (!l2 || (uint64_t)(l2 - t) + 1 >= size) return s;          /* too close to the end to tell: the check decides */
-            if (l2[1] == '+') return s;
-        }
-        i = s + 1;
-    }
-    return size;
-}
-
 /* One piece [a, b) of a plain-text file: the records that START in it.  The piece's own start s(a) and end s(b) come from
  * guess_record_start; its bytes are parsed as a file of their own, and afterwards the parser must stand between two records
  * (P_SEEK after a FASTQ record, P_LINE_START after a FASTA line) with a header character next -- then s(b) is a true record
@@ -774,12 +743,12 @@ static int parse_range(const scan_item *it, rec_fn fn, void *user, int64_t *nrec
     close(fd);
     if (t == MAP_FAILED) return SK_E_OPEN;
     madvise((void *)t, (size_t)it->size, MADV_SEQUENTIAL);
-    sa = guess_record_start(t, it->size, it->a);
-    sb = it->b >= it->size ? it->size : guess_record_start(t, it->size, it->b);
+    sa = parser_guess_start(t, it->size, it->a, 1);
+    sb = it->b >= it->size ? it->size : parser_guess_start(t, it->size, it->b, 1);
     parser_init(&ps, fn, user);
     for (i = sa; i < sb && ps.state != P_STOP; i += BLK) parser_feed(&ps, t + i, (size_t)(sb - i < BLK ? sb - i : BLK));
     if (ps.state != P_STOP && sb < it->size && sb > sa)
-        ok = (ps.state == P_SEEK || ps.state == P_LINE_START) && (t[sb] == '>' || t[sb] == '@');
+        ok = parser_between_records(&ps) && (t[sb] == 0x3e || t[sb] == 0x40);
     if (ps.state != P_STOP) parser_eof(&ps);
     if (nrecords) *nrecords = ps.nrecords;
     {

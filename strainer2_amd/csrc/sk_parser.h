@@ -201,4 +201,45 @@ static void parser_eof(parser *ps)
 }
 
 
+/* ---- cutting a text into pieces that are parsed on their own (several threads, several ranks) -------------------- */
+/* First offset >= x of a plain FASTA/FASTQ text at which a record may start: a '>' or '@' at the start of a line --
+ * for '@' with a '+' line two lines on, which sets it apart from a quality line that happens to begin with '@'
+ * (src/kseq.h:171-211 has no such check, it reads from the top; a guess that is wrong is caught by parse_range). */
+static __attribute__((unused)) uint64_t parser_guess_start(const unsigned char *t, uint64_t size, uint64_t x, int size_is_eof)
+{
+    uint64_t i = x;
+    if (x == 0) return 0;
+    while (i < size) {
+        const unsigned char *nl = (const unsigned char *)memchr(t + i - 1, '\n', (size_t)(size - (i - 1)));
+        uint64_t s;
+        if (!nl) return size;
+        s = (uint64_t)(nl - t) + 1;
+        if (s >= size) return size;
+        if (t[s] == '>') {
+            /* not if the line before begins with '+': then this is a FASTQ quality line that happens to begin with '>'
+             * (no line of a FASTA file begins with '+') */
+            uint64_t q = s >= 2 ? s - 2 : 0;
+            while (q > 0 && t[q] != '\n') q--;
+            if (!(s >= 2 && t[q == 0 && t[0] != '\n' ? 0 : q + 1] == '+')) return s;
+        }
+        if (t[s] == '@') {
+            const unsigned char *l1 = (const unsigned char *)memchr(t + s, '\n', (size_t)(size - s));
+            const unsigned char *l2 = l1 && (uint64_t)(l1 - t) + 1 < size ? (const unsigned char *)memchr(l1 + 1, '\n', (size_t)(size - ((uint64_t)(l1 - t) + 1))) : NULL;
+            if (!l2 || (uint64_t)(l2 - t) + 1 >= size) {                   /* too close to the end of the text at hand to tell */
+                if (size_is_eof) return s;                                  /* (the end of the file: the check decides) */
+                return size;                                                /* (more text will come: no guess yet) */
+            }
+            if (l2[1] == '+') return s;
+        }
+        i = s + 1;
+    }
+    return size;
+}
+
+
+/* After the bytes of a piece have been fed: does the parser stand BETWEEN two records (after a complete FASTQ record, or at
+ * the start of a line after a FASTA header/sequence line), so that a header character next begins a new record?  If the
+ * piece began at a true record boundary and this holds at its end, the end is a true boundary as well. */
+static __attribute__((unused)) int parser_between_records(const parser *ps) { return ps->state == P_SEEK || ps->state == P_LINE_START; }
+
 #endif

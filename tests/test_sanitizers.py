@@ -3,6 +3,7 @@ layer (parser, keyset build, order replay, stream writer) over every fixture fil
 import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -277,3 +278,69 @@ def test_kmer_scrub_count_members_inflated_by_several_threads(ks_host_exe, tmp_p
     for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
         assert bad not in p.stderr, p.stderr.decode()[-3000:]
     assert (p.returncode, p.stdout, p.stderr) == (want.returncode, want.stdout, want.stderr)
+
+
+def _sd_inputs(tmp_path, seed):
+    """a strain with an informative list and three read files whose records test the cutting: FASTQ with quality lines that
+    begin with @ + >, wrapped FASTA, short reads (the carried-over tallies of the reference), an odd interleaved file"""
+    import gzip
+    import random
+    import _synth
+    rng = random.Random(seed)
+    strain = _synth.rand_dna(rng, 30_000)
+    (tmp_path / "s.fa").write_bytes(b">s\n" + strain + b"\n")
+
+    def canon(k):
+        r = _synth.revcomp(k)
+        return k if k >= r else r
+    kms = sorted({canon(strain[i:i + 31]) for i in range(0, len(strain) - 31, 13)})
+    with gzip.open(tmp_path / "s.inf.gz", "wb") as f:
+        f.write(b"\n".join(kms) + b"\n")
+
+    def read(r):
+        L = r.choice([20, 31, 75, 150, 150, 151, 300])
+        if r.random() < 0.4:
+            a = r.randrange(0, len(strain) - L)
+            s = strain[a:a + L]
+            return _synth.revcomp(s) if r.random() < 0.5 else s
+        return _synth.rand_dna(r, L)
+
+    def fastq(n, r):
+        out = []
+        for i in range(n):
+            s = read(r)
+            out.append(b"@q%d x\n%s\n+\n%s\n" % (i, s, bytes(r.choice(b"@+>IF#") for _ in s)))
+        return b"".join(out)
+
+    def fasta(n, r, width):
+        return b"".join(b">f%d\n" % i + (b"\n".join(s[j:j + width] for j in range(0, len(s), width)) if width else s) + b"\n"
+                        for i, s in ((i, read(r)) for i in range(n)))
+    with gzip.open(tmp_path / "se.fq.gz", "wb", compresslevel=1) as f:
+        f.write(fastq(2500, random.Random(seed + 1)))
+    (tmp_path / "pe_1.fq").write_bytes(fastq(1200, random.Random(seed + 2)))
+    (tmp_path / "pe_2.fa").write_bytes(fasta(1200, random.Random(seed + 3), 60))
+    (tmp_path / "il.fa").write_bytes(fasta(1501, random.Random(seed + 4), 0))
+    (tmp_path / "B.txt").write_text(f"SE\t{tmp_path}/se.fq.gz\nPE\t{tmp_path}/pe_1.fq\t{tmp_path}/pe_2.fa\nPEI\t{tmp_path}/il.fa\n")
+
+
+@pytest.mark.parametrize("chunk", ["700", "5000", "60000"])
+def test_strain_detect_parser_threads_give_the_serial_result(sd_host_exe, tmp_path, chunk):
+    """several parser threads on one metagenome file (segments cut at guessed record starts, each CHECKED to end between two
+    records, chunks queued in file order; sk_host_sd.c) against the one-thread decode of the same program and against the
+    CPU oracle program -- under ASan+UBSan and TSan, with segments of a few hundred bytes to tens of kilobytes"""
+    import gzip
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import _oracle
+    _sd_inputs(tmp_path, 77)
+    base = ["-r", str(tmp_path / "s.fa"), "-a", str(tmp_path / "s.inf.gz"), "-B", str(tmp_path / "B.txt")]
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_SD_CHUNK_BYTES=chunk, SK_PARSE_THREADS="3")
+    par = subprocess.run([sd_host_exe] + base + ["-o", str(tmp_path / "par.gz")], env=env, capture_output=True)
+    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+        assert bad not in par.stderr, par.stderr.decode()[-3000:]
+    assert par.returncode == 0, par.stderr.decode()[-500:]
+    ser = subprocess.run([sd_host_exe] + base + ["-o", str(tmp_path / "ser.gz")], env=dict(env, SK_NO_SPLIT="1"), capture_output=True)
+    assert ser.returncode == 0 and ser.stdout == par.stdout
+    a, b = gzip.open(tmp_path / "par.gz", "rb").read(), gzip.open(tmp_path / "ser.gz", "rb").read()
+    assert a == b and a.count(b"\n") > 500
+    ora = _oracle.run_sd_oracle_cli(base + ["-o", str(tmp_path / "ora.gz")], str(tmp_path))
+    assert ora.returncode == 0 and gzip.open(tmp_path / "ora.gz", "rb").read() == a
