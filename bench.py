@@ -361,37 +361,52 @@ def main():
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
         root = os.path.join(base or tempfile.gettempdir(), "sk_bench_files_%s" % os.environ.get("MASTER_PORT", str(os.getuid())))
         rec = args.read_len + 1
+        n_small = min(args.file_reads, args.reads // 8)
+
+        def everyone_ok(ok, why):
+            """a side measurement must never hang the headline run: every step that can fail locally (disk full, a file
+            missing) is followed by an agreement, and the leg is dropped on EVERY rank if it failed on one"""
+            if world > 1:
+                t_ok = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                ok = bool(t_ok.item())
+            return ok, (None if ok else {"skipped": why})
+
+        def write_fastq(path, rows):
+            n = rows.shape[0]
+            fq = np.empty((n, 3 + rec + 2 + rec), dtype=np.uint8)
+            fq[:, :3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+            fq[:, 3:3 + rec] = rows
+            fq[:, 3 + rec:5 + rec] = np.frombuffer(b"+\n", dtype=np.uint8)
+            fq[:, 5 + rec:5 + rec + args.read_len] = ord("I")
+            fq[:, 5 + rec + args.read_len] = ord("\n")
+            fq.tofile(path)
+
+        ok, why = True, ""
         try:
             os.makedirs(root, exist_ok=True)
-            def write_fastq(path, rows):
-                n = rows.shape[0]
-                q = np.full((n, rec), ord("I"), dtype=np.uint8)
-                q[:, args.read_len] = ord("\n")
-                fq = np.empty((n, 3 + rec + 2 + rec), dtype=np.uint8)
-                fq[:, :3] = np.frombuffer(b"@r\n", dtype=np.uint8)
-                fq[:, 3:3 + rec] = rows
-                fq[:, 3 + rec:5 + rec] = np.frombuffer(b"+\n", dtype=np.uint8)
-                fq[:, 5 + rec:] = q
-                fq.tofile(path)
-            n_small = min(args.file_reads, args.reads // 8)
             for k in range(2):
                 write_fastq(os.path.join(root, f"r{rank}_{k}.fq"), reads[k * n_small * rec:(k + 1) * n_small * rec].reshape(n_small, rec))
             if rank == 0:
                 write_fastq(os.path.join(root, "big.fq"), reads[:4 * n_small * rec].reshape(4 * n_small, rec))
-            if world > 1:
-                dist.barrier()
-            lst = os.path.join(root, "list.txt")
-            if rank == 0:
-                with open(lst, "w") as f:
+                with open(os.path.join(root, "list.txt"), "w") as f:
                     f.write(os.path.join(root, "big.fq") + "\n")
                     for r in range(world):
                         for k in range(2):
                             f.write(os.path.join(root, f"r{r}_{k}.fq") + "\n")
+        except Exception as e:                               # noqa: BLE001
+            ok, why = False, f"could not write the files: {e}"
+        ok, file_fed = everyone_ok(ok, "a rank could not write its FASTQ files under " + root + (": " + why if why else ""))
+        if ok:
             barrier()
             ctx.zero_counts(1)
             t1 = time.perf_counter()
-            fb = ctx.scan_list(lst, 1, rank=rank, world=world)
-            ctx.sync()
+            fb = 0
+            try:
+                fb = ctx.scan_list(os.path.join(root, "list.txt"), 1, rank=rank, world=world)
+                ctx.sync()
+            except Exception as e:                           # noqa: BLE001
+                ok, why = False, f"scan_list failed: {e}"
             if world > 1:
                 allreduce_counts(ctx, 1)
             barrier()
@@ -403,15 +418,16 @@ def main():
                 dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
                 dist.all_reduce(tmax2, op=dist.ReduceOp.MAX)
                 fb_total, dt_max = float(tsum[0].item()), float(tmax2[1].item())
-            file_fed = {"bases_per_s": fb_total / dt_max, "bases": int(fb_total), "seconds": dt_max,
-                        "what": "plain FASTQ under %s: 2 files x %d reads per rank + one file of %d reads, ONE list scanned by "
-                                "all ranks through skh_scan_list (items dealt by size, the big file cut at checked record "
-                                "boundaries), counts all-reduced; decode threads per rank = SK_THREADS or the CPU budget / ranks"
-                                % (root, n_small, 4 * n_small)}
-        finally:
-            barrier()
-            if rank == 0:
-                shutil.rmtree(root, ignore_errors=True)
+            ok, file_fed = everyone_ok(ok, "a rank's list scan failed" + (": " + why if why else ""))
+            if ok:
+                file_fed = {"bases_per_s": fb_total / dt_max, "bases": int(fb_total), "seconds": dt_max,
+                            "what": "plain FASTQ under %s: 2 files x %d reads per rank + one file of %d reads, ONE list scanned by "
+                                    "all ranks through skh_scan_list (items dealt by size, the big file cut at checked record "
+                                    "boundaries), counts all-reduced; decode threads per rank = SK_THREADS or the CPU budget / ranks"
+                                    % (root, n_small, 4 * n_small)}
+        barrier()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
 
     if rank == 0:
         total_bases = nbases * args.steps * world

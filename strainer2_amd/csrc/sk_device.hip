@@ -116,20 +116,37 @@ struct sk_sink {
     unsigned long long  hits_cap;
 };
 
+// TALLY: the record that holds batch offset pos = the last one whose start is <= pos.  The per-tile index narrows it to the
+// records that start in pos's 32 KiB tile (or run into it); among those the starts are close to evenly spaced (reads of
+// similar length), so an interpolated guess checked against its two neighbours usually settles it in two round trips
+// instead of the eight of a binary search -- which finishes the job when the guess is off.
+__device__ __forceinline__ uint32_t sk_record_of(const sk_sink &k, uint32_t pos)
+{
+    const uint32_t t = pos >> 15;
+    uint32_t lo = k.tile_first[t], hi = k.tile_first[t + 1u];
+    lo = lo ? lo - 1u : 0u;
+    if (hi <= lo) hi = lo + 1u;
+    if (hi - lo > 3u) {
+        const uint32_t s_lo = k.rec_start[lo], s_hi = k.rec_start[hi - 1u];
+        if (pos >= s_hi) return hi - 1u;
+        uint32_t g = lo + (uint32_t)((float)(pos - s_lo) * (float)(hi - 1u - lo) / (float)(s_hi - s_lo));
+        g = g > hi - 2u ? hi - 2u : g;
+        const uint32_t a = k.rec_start[g], b = k.rec_start[g + 1u];
+        if (a <= pos) { if (pos < b) return g; lo = g + 1u; } else hi = g;            // (lo stays a record with start <= pos)
+    }
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (k.rec_start[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 template <bool TALLY, bool NOATOMIC = false>
 __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32_t pos)
 {
     if (NOATOMIC) { if (row == 0x7FFFFFFFu) k.counts[0] = pos; return; }      // timing experiment only
     if (!TALLY) { atomicAdd(&k.counts[row], 1u); return; }
-    // last record whose start <= pos: it starts in this tile, or is the one that runs into it
-    const uint32_t t = pos >> 15;
-    uint32_t lo = k.tile_first[t], hi = k.tile_first[t + 1u];
-    lo = lo ? lo - 1u : 0u;
-    if (hi <= lo) hi = lo + 1u;
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (k.rec_start[mid] <= pos) lo = mid; else hi = mid;
-    }
+    const uint32_t lo = sk_record_of(k, pos);
     atomicAdd(&k.tally[2u * lo], 1u);
     if (k.type[row] == k.inf_value) {
         atomicAdd(&k.tally[2u * lo + 1u], 1u);
@@ -147,15 +164,7 @@ __device__ __forceinline__ void sk_tally_wave(const sk_sink &k, uint32_t hit, ui
     uint32_t rec = 0xFFFFFF00u | lane;                    // distinct per lane when there is no hit
     bool is_inf = false;
     if (is_hit) {
-        const uint32_t t = pos >> 15;
-        uint32_t lo = k.tile_first[t], hi = k.tile_first[t + 1u];
-        lo = lo ? lo - 1u : 0u;
-        if (hi <= lo) hi = lo + 1u;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (k.rec_start[mid] <= pos) lo = mid; else hi = mid;
-        }
-        rec = lo;
+        rec = sk_record_of(k, pos);
         is_inf = k.type[hit] == k.inf_value;
     }
     const uint32_t prev = (uint32_t)__shfl_up((int)rec, 1);
@@ -759,15 +768,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 const uint32_t nh = (uint32_t)__popc(hits);
                 uint32_t rcd = 0xFFFFFF00u | lane, ih = 0u;                // record (distinct per lane without a hit)
                 if (nh) {
-                    const uint32_t p0 = (uint32_t)tile0 + ch * 16u, t = p0 >> 15;
-                    uint32_t lo = sink.tile_first[t], hi = sink.tile_first[t + 1u];
-                    lo = lo ? lo - 1u : 0u;
-                    if (hi <= lo) hi = lo + 1u;
-                    while (hi - lo > 1u) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (sink.rec_start[mid] <= p0) lo = mid; else hi = mid;
-                    }
-                    rcd = lo;
+                    rcd = sk_record_of(sink, (uint32_t)tile0 + ch * 16u);
                     const uint32_t w = r0 >> 5, sh = r0 & 31u;
                     const uint64_t two = ((uint64_t)sink.infbits[w + 1u] << 32) | sink.infbits[w];
                     const uint32_t byrank = (uint32_t)(two >> sh) & 0xFFFFu;            // bit k: row r0 + k is informative

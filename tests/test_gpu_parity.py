@@ -535,3 +535,41 @@ def test_program_on_the_cfg3_shaped_job_equals_the_reference(golden, tmp_path, t
     got = mk.facts_of(p.stdout, p.stderr, str(tmp_path))
     for k in ("md5_stdout", "lines", "column_sums", "md5_progress_without_times"):
         assert got[k] == facts[k], k
+
+
+@pytest.mark.gpu
+def test_counters_wrap_and_print_as_signed_through_the_gpu_scan(tmp_path):
+    """src/kmer_scrub_count.c:146-151 prints the unsigned counters with %d and they wrap mod 2^32: counters preset just
+    below 2^31 and just below 2^32 are scanned over on the device (run-length updates folded in by a prefix sum, plus the
+    one-by-one path) and printed by skh_print_counts; expected = (preset + oracle's increments) mod 2^32 as int32."""
+    rng = random.Random(99)
+    strain = _synth.rand_dna(rng, 40_000)
+    sstream = strain + b"\n"
+    ks = sk.Keyset.from_stream(sstream)
+    data = _synth.fuzz_stream(rng, strain, 4000, p_junk=0.002, min_len=25, max_len=260)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    t.scan_stream(data, 2)
+    okeys, ocounts = t.rows()
+    inc = ocounts[:, 2].astype(np.uint32)
+    assert (inc > 2).sum() > 1000
+    preset = np.zeros(ks.nrows, dtype=np.uint32)
+    preset[0::3] = 0xFFFFFFFF                       # wraps to inc - 1
+    preset[1::3] = 0x7FFFFFFE                       # crosses into the negative %d range
+    preset[2::3] = 7
+    with sk.KmerContext(0) as c:
+        c.load_keyset(ks, 4)
+        c.set_counts(2, preset)
+        c.scan_stream(data, 2)
+        got = c.counts(2)
+        out = tmp_path / "table.tsv"
+        c.print_counts(ks, str(out))
+        ref_col, pan_col = c.counts(0), c.counts(1)
+    want = (preset.astype(np.uint64) + inc.astype(np.uint64)).astype(np.uint32)       # mod 2^32
+    assert np.array_equal(got, want)
+    lines = open(out, "rb").read().split(b"\n")
+    assert lines[0] == b"#kmer\treference_count\tpangenome_count\tmetagenome_count\tdrug_count"
+    signed = want.view(np.int32)
+    assert (signed < 0).sum() > 1000
+    for r in range(0, ks.nrows, 97):
+        assert lines[1 + r] == b"%s\t%d\t%d\t%d" % (okeys[r], int(ref_col[r]), int(pan_col[r]), int(signed[r])), r
