@@ -505,10 +505,14 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     uint32_t g[SK_SPAN_CH];
     uint2    b1[SK_SPAN_CH];
     uint32_t okm = 0;                                             // chunks without a non-ACGT byte
+    // the thread's record in three 16-byte reads: with the 12-dword lane stride these are conflict-free, the same
+    // words read one by one are four-way bank conflicts (12 x 8 lanes = 96 = 0 mod 32 banks)
+    const sk_u4 rq0 = *(const sk_u4 *)my, rq1 = *(const sk_u4 *)(my + 4), rq2 = *(const sk_u4 *)(my + 8);
+    const uint32_t rw[12] = {rq0.x, rq0.y, rq0.z, rq0.w, rq1.x, rq1.y, rq1.z, rq1.w, rq2.x, rq2.y, rq2.z, rq2.w};
 #pragma unroll
     for (int i = 0; i < SK_SPAN_CH; i++) {
-        const uint32_t cw = my[i];
-        const uint32_t ipair = my[8 + (i >> 1)];
+        const uint32_t cw = rw[i];
+        const uint32_t ipair = rw[8 + (i >> 1)];
         const uint32_t inv = (i & 1) ? ipair >> 16 : ipair & 0xFFFFu;
         const uint32_t rc = sk_revcomp32(cw);
         g[i] = sk_gmix(cw < rc ? cw : rc);
