@@ -560,14 +560,19 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
         // level 1 next to a level-2 pass is as rare as level 2's own false positives.  Pruning less is always
         // exact: stage 2 verifies every window.
-        uint32_t m2 = 0;
-#pragma unroll
-        for (int i = 0; i < SK_SPAN_CH; i++)
-            if ((m >> i) & 1u) {
-                if (i > 0 && ((m2 >> (i - 1)) & 1u)) { m2 |= 1u << i; continue; }
-                const uint2 b2 = table.grid2[sk_grid2_block(g[i], table.grid2_shift)];   // (nontemporal loads here: 7 % slower)
-                m2 |= (uint32_t)sk_grid_test(b2, sk_grid2_bits(g[i])) << i;
-            }
+        // (a loop over the set bits, not over the eight chunks: a thread rarely has more than one survivor of level 1,
+        // and the unrolled form cost every wave all eight bodies)
+        uint32_t m2 = 0, left = m;
+        while (left) {
+            const uint32_t i = (uint32_t)__builtin_ctz(left);
+            left &= left - 1u;
+            if (i > 0u && ((m2 >> (i - 1u)) & 1u)) { m2 |= 1u << i; continue; }
+            const uint32_t cw = my[i];
+            const uint32_t rc = sk_revcomp32(cw);
+            const uint32_t gi = sk_gmix(cw < rc ? cw : rc);
+            const uint2 b2 = table.grid2[sk_grid2_block(gi, table.grid2_shift)];   // (nontemporal loads here: 7 % slower)
+            m2 |= (uint32_t)sk_grid_test(b2, sk_grid2_bits(gi)) << i;
+        }
         m = m2;
     }
 
