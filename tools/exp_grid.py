@@ -39,6 +39,8 @@ VARIANTS = {
     "pipe7_h2":     (0.02, {"ablate": 7}, False),
     "pipe8_h2":     (0.02, {"ablate": 8}, False),
     "pipe9_h2":     (0.02, {"ablate": 9}, False),
+    "abl8_h2":      (0.02, {"ablate": 8}, False),
+    "abl9_h2":      (0.02, {"ablate": 9}, False),
     "single_h0":    (0.0,  {"pipeline": 1}, False),
     "single_h2":    (0.02, {"pipeline": 1}, False),
     "single_h30":   (0.3,  {"pipeline": 1}, False),
