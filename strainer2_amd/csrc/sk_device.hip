@@ -576,7 +576,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         m = m2;
     }
 
-    if (ABLATE == 9) { if (m == 0x77u && tid == 1000u) flags[3] = 1u; return; }                            // timing: phases 1 and 2 alone
+    if (ABLATE == 9) { if (m == 0x77u && tid == 100u) flags[3] = 1u; return; }                            // timing: phases 1 and 2 alone
 
     // ================= stage 2: the windows of the surviving chunks ==============================
     // Seed and verify, a CHUNK per lane (16 windows at a time, 64 chunks = up to 1024 windows per round).
@@ -647,8 +647,8 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 
     // the wave's surviving chunks (index in the tile), compacted in stream order
     uint16_t *const cq = cq_all[tid >> 6];
-    uint32_t nq;
-    {
+    uint32_t nq = 0;
+    if (__ballot(m != 0u) != 0ull) {                              // (wave-uniform; most waves of an unrelated metagenome have none)
         uint32_t incl = (uint32_t)__popc(m);
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
