@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
     "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
-    "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_decode_file",
+    "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_strain_detect_resident", "skh_decode_file",
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
     "sk_distinct_count", "sk_first_seen_count", "skh_coverage_depth_main",
