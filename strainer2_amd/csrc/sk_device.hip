@@ -899,11 +899,11 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 // false positives are not the L2 filter's
 __device__ __forceinline__ uint32_t sk_grid3_hash(uint32_t g) { return (g ^ (g >> 13)) * 0x5BD1E995u; }
 
-__global__ void sk_grid3_insert(const uint64_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ w3)
+__global__ void sk_grid3_insert(const sk_u4 *__restrict__ slots, uint64_t nslots, uint32_t *__restrict__ w3)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = in[i];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (from the resident table: built on first use only)
+    if (i >= nslots) return;
+    const uint64_t k = sk_slot_key(slots[i]);
     if (k == SK_EMPTY64) return;
     for (int off = 0; off < 16; off++) {
         const uint32_t f = (uint32_t)(k >> (2 * (15 - off)));
@@ -1527,11 +1527,6 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
             SK_HIP(c, hipMemsetAsync(c->d_grid2, 0, b2, c->stream));
             hipLaunchKernelGGL(sk_grid_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, d_in, nrows,
                                (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
-            // the partitioned pipeline's filter slices: SK_BIN_P bitmaps of 2^20 bits (16 MiB)
-            const size_t b3 = (size_t)SK_BIN_P * SK_BIN_WORDS * 4;
-            SK_HIP(c, hipMalloc((void **)&c->d_grid3, b3));
-            SK_HIP(c, hipMemsetAsync(c->d_grid3, 0, b3, c->stream));
-            hipLaunchKernelGGL(sk_grid3_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, d_in, nrows, c->d_grid3);
         }
         uint32_t flags[2] = {0, 0};
         SK_HIP(c, hipMemcpyAsync(flags, c->d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
@@ -1689,8 +1684,17 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     // 2 % strain reads; profiles/r02_lds_pipeline.txt) -- its one full pass over the stream plus the
     // bin write already costs half of the single kernel's time, and the re-read of the candidates' neighbourhoods pays
     // the fabric's random-line rate.  The default is the single kernel for every batch size.
-    const bool piped = c->d_grid3 && (!c->ablate || c->ablate >= 7) && c->pipeline == 2;
+    const bool piped = (!c->ablate || c->ablate >= 7) && c->pipeline == 2;        // (ablations 7-9 exist for both forms)
     const uint8_t *d_cand = NULL;
+    if (piped && !c->d_grid3) {
+        // the partitioned pipeline's filter slices, built from the resident table the first time they are wanted:
+        // SK_BIN_P bitmaps of 2^20 bits (16 MiB)
+        const size_t b3 = (size_t)SK_BIN_P * SK_BIN_WORDS * 4;
+        const uint64_t nslots = (uint64_t)1 << c->slots_log2;
+        SK_HIP(c, hipMalloc((void **)&c->d_grid3, b3));
+        SK_HIP(c, hipMemsetAsync(c->d_grid3, 0, b3, c->stream));
+        hipLaunchKernelGGL(sk_grid3_insert, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, c->stream, (const sk_u4 *)c->d_keys, nslots, c->d_grid3);
+    }
     if (piped) {
         const uint64_t ntiles_bin = (nbytes + SK_BIN_TILE - 1) / SK_BIN_TILE;
         int rc;
