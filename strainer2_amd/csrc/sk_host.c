@@ -11,7 +11,7 @@
  *   - file-list walk, progress log, skip rule, error texts (src/genome_compare.c:115-177);
  *   - TSV printing (src/kmer_scrub_count.c:134-156) and the program's argv contract (:29-131).
  *
- * No window is ever looked up on the CPU here: lookups happen in sk_scan_main / sk_scan_wide.
+ * No window is ever looked up on the CPU here: lookups happen in sk_scan_grid / sk_scan_wide.
  */
 #define _GNU_SOURCE
 #include <ctype.h>

@@ -2,7 +2,7 @@
  *
  * What runs where:
  *   device  every k-mer lookup: the per-read tallies (all hits / informative hits) and the log of
- *           informative hits come from sk_tally_batch (sk_scan_main in TALLY mode); the informative
+ *           informative hits come from sk_tally_batch (sk_scan_grid in TALLY mode); the informative
  *           k-mer list (-a) is itself looked up as a batch of 31-byte records; the -g background
  *           counts use the ordinary counting scan.
  *   host    file grammar, the reference's sequential read-pair bookkeeping (src/strain_detect.c:443-626,
