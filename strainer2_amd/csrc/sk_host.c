@@ -899,13 +899,20 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
         target = total / (4 * lanes);
         if (target < (32u << 20)) target = 32u << 20;
         if ((env = getenv("SK_SPLIT_BYTES")) != NULL && atoll(env) > 0) target = (uint64_t)atoll(env);     /* (tests) */
-        cut = (scan_item *)malloc(((size_t)nall + 1) * 260 * sizeof *cut);
-        est = (uint64_t *)malloc(((size_t)nall + 1) * 260 * sizeof *est);
+        {   /* how many items there will be */
+            size_t total_items = 0;
+            for (i = 0; i < n0; i++) {
+                uint64_t np = 1;
+                if (lanes > 1 && !gz[i] && !getenv("SK_NO_SPLIT") && all[i].size >= 2 * target) np = (all[i].size + target - 1) / target;
+                total_items += np > 256 ? 256 : (size_t)np;
+            }
+            cut = (scan_item *)malloc((total_items + 1) * sizeof *cut);
+            est = (uint64_t *)malloc((total_items + 1) * sizeof *est);
+        }
         for (i = 0; i < n0; i++) {
             uint32_t np = 1, k;
             if (lanes > 1 && !gz[i] && !getenv("SK_NO_SPLIT") && all[i].size >= 2 * target) {
-                np = (uint32_t)((all[i].size + target - 1) / target);
-                if (np > 256) np = 256;
+                np = (uint32_t)((all[i].size + target - 1) / target > 256 ? 256 : (all[i].size + target - 1) / target);
             }
             for (k = 0; k < np; k++) {
                 cut[out] = all[i];

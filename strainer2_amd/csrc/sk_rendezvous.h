@@ -84,9 +84,7 @@ static int skr_exchange(int rank, int world, const char *base, int my_status, un
     if (world == 1) return my_status ? SKR_ABORT : SKR_OK;
     if (rank == 0) {
         skr_board bd;
-        unsigned have = 1;                           /* bit r: hello of rank r seen (world <= 64) */
-        uint64_t seen = 1;
-        (void)have;
+        uint64_t seen = 1;                           /* bit r: hello of rank r seen (world <= 64) */
         memset(&bd, 0, sizeof bd);
         unlink(base);
         for (r = 1; r < world; r++) { snprintf(path, sizeof path, "%s.hello.%d", base, r); unlink(path); }
