@@ -114,7 +114,35 @@ struct sk_sink {
     uint2          *hits;          // TALLY: (window-end offset in batch, caller's row)
     unsigned long long *nhits;
     unsigned long long  hits_cap;
+    // TALLY: the workgroup's share of the hit log is gathered in LDS (lds_hits[SK_AGG], filled up to *lds_n) and goes out
+    // with ONE atomic on nhits at the end of the tile: a returning atomic on a single word per wave and batch was the
+    // tail of every launch (same-address atomics serialise in the L2)
+    uint2              *lds_hits;
+    uint32_t           *lds_n;        // [0] places reserved so far, [1] end of the valid share (SK_AGG until a reservation did not fit)
 };
+
+// reserve `n` consecutive places of the hit log for the calling wave (wave-uniform n > 0; every lane gets the answer):
+// in the workgroup's LDS share if they fit (*in_lds = true, index into lds_hits), else in the global log
+__device__ __forceinline__ unsigned long long sk_log_reserve(const sk_sink &k, uint32_t n, uint32_t lane, bool *in_lds)
+{
+    uint32_t lb = 0;
+    if (lane == 0u) lb = atomicAdd(k.lds_n, n);
+    lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lb);
+    if (lb + n <= SK_AGG) { *in_lds = true; return lb; }
+    // did not fit, and nothing reserved after it will (the counter only grows): the LDS share ends where this
+    // reservation began -- remember the lowest such place -- and this wave's entries go to the global log
+    if (lane == 0u) atomicMin(k.lds_n + 1, lb);
+    unsigned long long base = 0;
+    if (lane == 0u) base = atomicAdd(k.nhits, (unsigned long long)n);
+    *in_lds = false;
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+}
+__device__ __forceinline__ void sk_log_put(const sk_sink &k, bool in_lds, unsigned long long at, uint2 e)
+{
+    if (in_lds) k.lds_hits[at] = e;
+    else if (at < k.hits_cap) k.hits[at] = e;
+}
 
 // TALLY: the record that holds batch offset pos = the last one whose start is <= pos.  The per-tile index narrows it to the
 // records that start in pos's 32 KiB tile (or run into it); among those the starts are close to evenly spaced (reads of
@@ -178,16 +206,10 @@ __device__ __forceinline__ void sk_tally_wave(const sk_sink &k, uint32_t hit, ui
         const uint32_t ni = (uint32_t)__popcll(im & seg);
         if (ni) atomicAdd(&k.tally[2u * rec + 1u], ni);
     }
-    if (im) {
-        unsigned long long base = 0;
-        const uint32_t leader = (uint32_t)__builtin_ctzll(im);
-        if (lane == leader) base = atomicAdd(k.nhits, (unsigned long long)__popcll(im));
-        base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), (int)leader) << 32) |
-               (uint32_t)__shfl((int)(uint32_t)base, (int)leader);
-        if (is_inf) {
-            const unsigned long long i = base + (unsigned long long)__popcll(im & ((1ull << lane) - 1ull));
-            if (i < k.hits_cap) k.hits[i] = make_uint2(pos, k.inv ? k.inv[hit] : hit);
-        }
+    if (im) {                                                      // (wave-uniform)
+        bool in_lds;
+        const unsigned long long base = sk_log_reserve(k, (uint32_t)__popcll(im), lane, &in_lds);
+        if (is_inf) sk_log_put(k, in_lds, base + (unsigned long long)__popcll(im & ((1ull << lane) - 1ull)), make_uint2(pos, k.inv ? k.inv[hit] : hit));
     }
 }
 
@@ -384,8 +406,14 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+    __shared__ uint32_t hl_n[2];                                  // TALLY: the hit log's LDS share (agg is free in that mode)
     if (!TALLY)
         for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) agg[i] = make_uint2(0xFFFFFFFFu, 0u);   // (visible after phase 1's barrier)
+    else {
+        if (tid == 0u) { hl_n[0] = 0u; hl_n[1] = SK_AGG; }
+        sink.lds_hits = agg;
+        sink.lds_n = hl_n;
+    }
 
     // ================= phase 1: bytes -> packed codes + invalid masks ==========================
     // All of a thread's 16-byte loads are issued before the first is decoded (nine HBM latencies in
@@ -812,17 +840,14 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                     if (sum_i) atomicAdd(&sink.tally[2u * rcd + 1u], sum_i);
                 }
                 if (tot_i) {                                                             // (wave-uniform)
-                    unsigned long long base = 0;
-                    if (lane == 0u) base = atomicAdd(sink.nhits, (unsigned long long)tot_i);
-                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                    bool in_lds;
+                    unsigned long long at = sk_log_reserve(sink, tot_i, lane, &in_lds) + off_i;
                     uint32_t h = ih;
-                    unsigned long long at = base + off_i;
                     while (h) {
                         const uint32_t a = (uint32_t)__builtin_ctz(h);
                         h &= h - 1u;
                         const uint32_t row = r0 + (uint32_t)__popc(bits16 & ((1u << a) - 1u));
-                        if (at < sink.hits_cap) sink.hits[at] = make_uint2((uint32_t)tile0 + ch * 16u + 15u + (dir ? 15u - a : a), sink.inv ? sink.inv[row] : row);
+                        sk_log_put(sink, in_lds, at, make_uint2((uint32_t)tile0 + ch * 16u + 15u + (dir ? 15u - a : a), sink.inv ? sink.inv[row] : row));
                         at++;
                     }
                 }
@@ -871,6 +896,16 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) {
             const uint2 e = agg[i];
             if (e.y != 0u && ABLATE != 3) atomicAdd(&sink.diff[e.x], e.y);
+        }
+    } else {                                                      // the tile's share of the hit log: one atomic, one copy
+        __syncthreads();
+        const uint32_t nl = hl_n[0] < hl_n[1] ? hl_n[0] : hl_n[1];
+        if (nl) {
+            __shared__ unsigned long long gbase;
+            if (tid == 0u) gbase = atomicAdd(sink.nhits, (unsigned long long)nl);
+            __syncthreads();
+            for (uint32_t i = tid; i < nl; i += SK_THREADS)
+                if (gbase + i < sink.hits_cap) sink.hits[gbase + i] = agg[i];
         }
     }
 }
