@@ -68,6 +68,9 @@
                                             // (profiles/r02_phase2_experiments.txt): it halves the kernel's L2 misses and changes nothing
                                             // (+2 %): the kernel is bound by the L2's REQUEST rate, and the question costs two requests
 #endif
+#ifndef SK_CHUNK_REJECT
+#define SK_CHUNK_REJECT 1                   // stage 2: three filter questions per differing base before its ~31 windows go one by one
+#endif
 #ifndef SK_ANCHOR_CH
 #define SK_ANCHOR_CH    8u                  // stage 2: one table probe per this many consecutive surviving chunks (and the first); 2: -10 %, 4: -1 %
 #endif
@@ -796,7 +799,47 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 const uint32_t asc = dir ? __builtin_bitreverse32(ver16) >> 16 : ver16;
                 hits = asc & bits16;
                 const uint32_t dups = asc & ~bits16;                           // a k-mer of the strain, but its row is elsewhere
-                fb = (live & ~ver16) | (dir ? __builtin_bitreverse32(dups) >> 16 : dups);
+                uint32_t un = live & ~ver16;                                   // live windows the diagonal does not explain
+                if (un && SK_CHUNK_REJECT) {
+                    // Mostly a base that differs from the strain (a read error, a diverged genome): ~31 windows in a row hold
+                    // it.  Before they go to the one-by-one path (two filter questions each), three questions for all of
+                    // them: the 16-mers that start 15 and 8 bases before the differing base and at it.  Every window that
+                    // holds the base holds one of the three, and a window that holds a 16-mer the strain does not have is
+                    // no k-mer of the strain (the filter has no false negatives) -- wherever in the strain it might lie.
+                    const uint64_t inval48 = (uint64_t)inv_prev | ((uint64_t)inv_next << 32);
+                    uint64_t mmw = (((uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32)) & ~inval48) & 0x0000FFFFFFFFFFFFull;
+                    uint32_t rej = 0;
+                    for (int round = 0; round < 2 && mmw; round++) {          // (the first two differing bases; more: the one-by-one path)
+                        const uint32_t x = (uint32_t)__builtin_ctzll(mmw);
+                        mmw &= mmw - 1ull;
+                        uint32_t p3[3], g3[3];
+                        uint2 q3[3];
+                        bool ok3[3];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const int back = k == 0 ? 15 : k == 1 ? 8 : 0;
+                            const uint32_t p = (int)x - back < 0 ? 0u : x - (uint32_t)back > 32u ? 32u : x - (uint32_t)back;   // 16-mer [p, p+16) of the 48 bases
+                            p3[k] = p;
+                            ok3[k] = ((inval48 >> p) & 0xFFFFull) == 0ull && p >= 1u;            // all ACGT, and inside at least one window
+                            const uint32_t q = p >> 4, o2 = 2u * (p & 15u);
+                            const uint32_t hiw = q == 0u ? w0 : q == 1u ? w1 : w2, low = q == 0u ? w1 : q == 1u ? w2 : 0u;
+                            const uint32_t v16 = (uint32_t)(((((uint64_t)hiw << 32) | low) << o2) >> 32);
+                            const uint32_t r16 = sk_revcomp32(v16);
+                            g3[k] = sk_gmix(v16 < r16 ? v16 : r16);
+                            q3[k] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                            if (ok3[k]) q3[k] = table.grid1[sk_grid1_block(g3[k], table.grid1_blocks)];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+                            if (ok3[k] && !sk_grid_test(q3[k], sk_grid1_bits(g3[k]))) {
+                                // windows j = p-16 .. p-1 (window j spans bases 1+j .. 31+j) hold the 16-mer [p, p+16)
+                                const uint32_t lo = p3[k] > 16u ? p3[k] - 16u : 0u, hi = p3[k] - 1u > 15u ? 15u : p3[k] - 1u;
+                                rej |= ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+                            }
+                    }
+                    un &= ~rej;
+                }
+                fb = un | (dir ? __builtin_bitreverse32(dups) >> 16 : dups);
             }
             if (TALLY) {
                 // A chunk's windows all lie in the record that holds the chunk, and their rows are consecutive ranks:

@@ -17,7 +17,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-# name -> (hit_frac, options, uncached stream)
+# name -> (hit_frac, options, uncached stream[, substitution rate of the strain reads (default 0.005)])
 VARIANTS = {
     "base_h0":      (0.0,  {}, False),
     "base_h2":      (0.02, {}, False),
@@ -45,6 +45,8 @@ VARIANTS = {
     "single_h2":    (0.02, {"pipeline": 1}, False),
     "single_h30":   (0.3,  {"pipeline": 1}, False),
     "single_h100":  (1.0,  {"pipeline": 1}, False),
+    "div1_h100":    (1.0,  {}, False, 0.01),
+    "div3_h100":    (1.0,  {}, False, 0.03),
     "base_h30":     (0.3,  {}, False),
     "base_h100":    (1.0,  {}, False),
 }
@@ -66,10 +68,11 @@ def main():
     reads_by_frac = {}
     out = []
     for name in names:
-        frac, opts, unc = VARIANTS[name]
-        if frac not in reads_by_frac:
-            reads_by_frac[frac] = synth.make_reads(contigs, args.reads, 150, hit_frac=frac, seed=synth.SEED + 1)
-        reads, nbases = reads_by_frac[frac]
+        frac, opts, unc = VARIANTS[name][:3]
+        sub = VARIANTS[name][3] if len(VARIANTS[name]) > 3 else 0.005
+        if (frac, sub) not in reads_by_frac:
+            reads_by_frac[(frac, sub)] = synth.make_reads(contigs, args.reads, 150, hit_frac=frac, sub_rate=sub, seed=synth.SEED + 1)
+        reads, nbases = reads_by_frac[(frac, sub)]
         ctx = sk.KmerContext(0)
         for k, v in opts.items():
             ctx.set_option(k, v)
