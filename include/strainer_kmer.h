@@ -45,6 +45,9 @@ extern "C" {
 #define SK_K                 31            /* seed length: src/kmer_scrub_count.c:39, src/strain_detect.c:78 */
 #define SK_REF_TABLE_SLOTS   8000000u      /* DEFAULT_GENOME_HASH_SIZE: src/genome_compare.h:20 */
 #define SK_KEY_NONE          UINT64_MAX    /* "no packed key for this row" (row is a wide key) */
+#define SK_ROWS_IN_STRAIN_ORDER UINT32_MAX /* skh_keyset_from_*: initial_slots value meaning "do not replay the reference's hash table: rows in
+                                            * first-occurrence order along the strain" -- for callers whose output does not show the row order
+                                            * (strain_detect: src/strain_detect.c prints k-mer text per hit, never walks the table) */
 #define SK_LOCALITY_FWD      0x80000000u   /* locality[] flag: the key is the strain text itself at its first occurrence */
 
 /* error codes (0 = success) */

@@ -507,7 +507,11 @@ static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
 {
     uint32_t r, *rows;
     builder_drain(b);
-    rows = replay_slot_order(b, initial_slots, &ks->final_slots);
+    if (initial_slots == SK_ROWS_IN_STRAIN_ORDER) {      /* rows as they first occur along the strain: no replay of the reference's table */
+        rows = (uint32_t *)malloc(((size_t)b->n + 1) * sizeof(uint32_t));
+        for (r = 0; r < b->n; r++) rows[r] = r;
+        ks->final_slots = 0;
+    } else rows = replay_slot_order(b, initial_slots, &ks->final_slots);
     uint32_t *wide_newrow = (uint32_t *)calloc(b->wn ? b->wn : 1, sizeof(uint32_t));
     ks->nrows = b->n;
     ks->nwide = b->wn;
