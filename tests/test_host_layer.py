@@ -221,3 +221,28 @@ def test_cpu_budget_follows_quota_and_local_ranks(tmp_path):
     shared = int(subprocess.run([exe], env=dict(env, LOCAL_WORLD_SIZE="4"), capture_output=True, check=True).stdout)
     assert shared == max(1, alone // 4)
     assert int(subprocess.run([exe], env=dict(env, OMPI_COMM_WORLD_LOCAL_SIZE="1000"), capture_output=True, check=True).stdout) == 1
+
+
+def test_bench_reports_measured_traffic_only_for_the_kernel_it_was_measured_on(repo, tmp_path, monkeypatch):
+    """bench.py takes roofline.traffic from profiles/traffic.json only if that file carries the sha256 of the current
+    sk_device.hip (tools/save_profile.py stamps it) and belongs to the workload; otherwise null with the reason"""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    args = types.SimpleNamespace(reads=10_000_000, read_len=150, strain_bp=5_000_000, hit_frac=0.02)
+    tj = json.load(open(os.path.join(repo, "profiles", "traffic.json")))
+    got, why = b.measured_traffic(args, "sk_scan_grid")
+    if tj.get("sk_device_hip_sha256") == b.device_source_sha():
+        assert got == tj["hbm_bytes_per_launch"] and got > 1.5e9
+    else:
+        assert got is None and "stale" in why
+    args.reads = 123
+    assert b.measured_traffic(args, "sk_scan_grid")[0] is None
+    # the committed facts of the reference's run: present for the timed workload, for all eight ranks
+    args.reads = 10_000_000
+    f = b.load_cfg2_facts(args)
+    assert f is not None and len(f["ranks"]) == 8 and f["ranks"][0]["sum"] == 21279803
+    args.hit_frac = 0.1
+    assert b.load_cfg2_facts(args) is None
