@@ -1653,7 +1653,7 @@ extern "C" int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nba
     if (!c || !text2 || !first_pos) return SK_E_ARG;
     if (!c->d_keys || !c->nrows) return sk_fail(c, SK_E_STATE, "sk_table_load_ex first");
     if (c->h_perm.empty()) return sk_fail(c, SK_E_STATE, "the text stage needs the locality order of sk_table_load_ex");
-    if (nbases < SK_K || nbases > 0xFFFFFF00u) return sk_fail(c, SK_E_ARG, "text of %u bases", nbases);
+    if (nbases < SK_K || nbases > 0x7FFFFF00u) return sk_fail(c, SK_E_ARG, "text of %u bases (a table slot holds 31 bits of position)", nbases);
     const uint32_t nrows = c->nrows;
     // by counter index; the contract: rows with a position first, positions ascending
     std::vector<uint32_t> pos_by_idx(nrows, 0xFFFFFFFFu);

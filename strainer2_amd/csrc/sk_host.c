@@ -379,7 +379,7 @@ static int builder_record(void *user, char *seq, size_t len)
         soft = sk_is_hard_break(c) ? 0 : soft + 1;
         if (run >= SK_K) {
             const uint64_t tp = tbase + i - (SK_K - 1);
-            builder_add_packed(b, fwd > rc ? fwd : rc, fwd > rc, tp < NO_POS - 64u ? (uint32_t)tp : NO_POS);
+            builder_add_packed(b, fwd > rc ? fwd : rc, fwd > rc, tp < 0x7FFFFF00u ? (uint32_t)tp : NO_POS);
         } else if (soft >= SK_K) {
             char u[SK_K], o[SK_K + 1];
             const char *w = seq + i - (SK_K - 1);
@@ -531,7 +531,7 @@ static int keyset_finish(skh_keyset *ks, builder *b, uint32_t initial_slots)
         for (e = 0; e < b->n; e++) if (b->firstpos[e] != NO_POS) newloc[e] = m++;
         for (e = 0; e < b->n; e++) if (b->firstpos[e] == NO_POS) newloc[e] = m++;
     }
-    ks->text_bases = b->text_n < NO_POS - 64u ? (uint32_t)b->text_n : 0u;      /* 0: too long, no text stage */
+    ks->text_bases = b->text_n < 0x7FFFFF00u ? (uint32_t)b->text_n : 0u;       /* 0: too long (a table slot has 31 bits for a position): no text stage */
     ks->text2 = NULL;
     if (ks->text_bases) {
         const size_t words = (size_t)ks->text_bases / 16 + 4;
