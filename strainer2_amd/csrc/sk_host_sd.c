@@ -15,7 +15,10 @@
  */
 #define _GNU_SOURCE
 #include <errno.h>
+#include <fcntl.h>
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -387,8 +390,32 @@ static void *sd_decode_thread(void *arg)
             const unsigned char *data;
             size_t n;
             while (ps.state != P_STOP && !st->cancel && (n = skzp_next(&zp, &data)) > 0) parser_feed(&ps, data, n);
-        } else
-            while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
+        } else {
+            /* plain text: parsed straight out of the mapped file (zlib's pass-through mode copies every byte once more:
+             * 4.9 GB/s of FASTA against what the parser itself does); anything that cannot be mapped, or SK_ZLIB=1: gzread */
+            const unsigned char *map = NULL;
+            size_t mlen = 0;
+            if (!getenv("SK_ZLIB")) {
+                const int fd = open(st->path, O_RDONLY);
+                struct stat sb;
+                if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+                    void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                    if (m != MAP_FAILED) { map = (const unsigned char *)m; mlen = (size_t)sb.st_size; madvise(m, mlen, MADV_SEQUENTIAL); }
+                }
+                if (fd >= 0) close(fd);
+                if (map && mlen >= 2 && map[0] == 0x1f && map[1] == 0x8b) { munmap((void *)map, mlen); map = NULL; }   /* (gzip after all: zlib) */
+            }
+            if (map) {
+                size_t at = 0;
+                while (ps.state != P_STOP && !st->cancel && at < mlen) {
+                    const size_t n = mlen - at < (4u << 20) ? mlen - at : (4u << 20);
+                    parser_feed(&ps, map + at, n);
+                    at += n;
+                }
+                munmap((void *)map, mlen);
+            } else
+                while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
+        }
         parser_eof(&ps);
         c = b.cur ? b.cur : (sd_chunk *)calloc(1, sizeof *c);
         b.cur = NULL;
