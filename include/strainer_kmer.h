@@ -201,7 +201,9 @@ int sk_scan_timing(sk_ctx *ctx, double *total_ms, uint64_t *launches, int reset)
 
 /* Tunables (before sk_table_load).  name: "table_load_pct" (max load factor in percent), "grid_kib" (size of
  * the level-1 filter in KiB, -1 = automatic), "text_stage" (0 = stage 2 probes every window on its own even
- * when the strain's text is resident; for A/B runs and tests), "odd_list_cap" (tests), "ablate" (timing
+ * when the strain's text is resident; for A/B runs and tests), "pipeline" (2 = the partitioned pipeline sk_bin ->
+ * sk_lds_probe -> candidates-only scan, an experiment that measured slower than the default single kernel: DESIGN.md
+ * section 4), "odd_list_cap" (tests), "dev_alloc_uncached" (experiment: no effect), "ablate" (timing
  * experiments only: kernel variants that skip memory stages and give WRONG counts).
  * Unknown name -> SK_E_ARG. */
 int sk_set_option(sk_ctx *ctx, const char *name, long value);
