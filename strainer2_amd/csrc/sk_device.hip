@@ -251,13 +251,16 @@ __device__ __forceinline__ uint32_t sk_nz_msb(uint32_t x) { return ((x & 0x7F7F7
 // 7..6.  inv4: bit i set iff byte i is not A/C/G/T (any case).
 __device__ __forceinline__ void sk_decode4(uint32_t w, uint32_t &codes8, uint32_t &inv4)
 {
-    const uint32_t u  = w & 0xDFDFDFDFu;                                   // upper-cased letters
-    const uint32_t x  = (w >> 1) & 0x03030303u;                            // A0 C1 T2 G3
-    const uint32_t cd = x ^ ((x >> 1) & 0x01010101u);                      // A0 C1 G2 T3
+    // The low three bits of a letter tell A (1), C (3), T (4), G (7) apart in either case: two byte permutes with them as
+    // selector give the 2-bit code and the upper-case letter the byte would have to be; the byte is valid iff it IS that
+    // letter (every other selector value expects 0xFF, which no upper-cased byte equals).  Codes of invalid bytes are 0:
+    // no window that is looked at holds one.
+    const uint32_t u   = w & 0xDFDFDFDFu;                                  // upper-cased letters
+    const uint32_t sel = w & 0x07070707u;
+    const uint32_t cd  = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, sel);   // A0 C1 G2 T3
     codes8 = (cd * 0x40100401u) >> 24;                                     // gather 4 x 2 bits
-    const uint32_t lut = 0x47544341u;                                      // 'A','C','T','G' by x
-    const uint32_t d  = __builtin_amdgcn_perm(lut, lut, x) ^ u;            // 0 <=> the byte is that letter
-    inv4 = ((((sk_nz_msb(d) >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+    const uint32_t d   = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, sel) ^ u;   // 0 <=> the byte is that letter
+    inv4 = ((sk_nz_msb(d) & 0x80808080u) * 0x00204081u) >> 28;             // bit i <=> byte i is non-zero (the four top bits gathered)
 }
 
 // Among the (few) non-ACGT bytes of a 16-byte chunk, is there one that is neither N/n nor '\n'?
