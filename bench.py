@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of reads drawn from the strain (cfg 2: 0.02)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive host-buffer passes (keeps profiles clean)")
-    ap.add_argument("--file-reads", type=int, default=400_000, help="reads per FASTQ file of the file-fed, rank-sharded side measurement (0 = skip it)")
+    ap.add_argument("--file-reads", type=int, default=1_000_000, help="reads per FASTQ file of the file-fed, rank-sharded side measurement (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--grid-kib", type=int, default=None, help="size of the grid kernel's level-1 filter in KiB (default: automatic)")
     ap.add_argument("--text-stage", type=int, default=None, help="0 = stage 2 without the strain's text (A/B)")
