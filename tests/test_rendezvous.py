@@ -86,3 +86,29 @@ def test_without_rank0_the_others_time_out(tmp_path):
     out = _run(3, str(tmp_path / "id"), timeout=1.0, absent=(0,))
     assert all(rc == 2 for rc, _ in out.values()), out
     assert not [f for f in os.listdir(tmp_path) if "hello" in f]   # their hello files are gone
+
+
+def test_program_ranks_leave_together_when_a_set_up_fails(tmp_path):
+    """bin/kmer_scrub_count started as two ranks: here at least one rank's set-up fails (no usable device in the build
+    container, or -- on a one-GPU box -- no second device for rank 1; rank 1's strain is unreadable as well).  Through
+    sk_comm_init_ex every rank learns it BEFORE anyone would enter ncclCommInitRank, prints its own reason and exits
+    non-zero within the rendezvous -- no hang, no leftover files that would confuse the next launch."""
+    import subprocess
+    import strainer2_amd as sk
+    (tmp_path / "s.fa").write_bytes(b">s\n" + b"ACGTTGCA" * 40 + b"\n")
+    (tmp_path / "A.txt").write_text("")
+    (tmp_path / "B.txt").write_text("")
+    idf = str(tmp_path / "rccl_id")
+    ps = []
+    t0 = time.time()
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), SK_RCCL_ID_FILE=idf, SK_RENDEZVOUS_TIMEOUT="20")
+        strain = str(tmp_path / ("s.fa" if r == 0 else "missing.fa"))
+        ps.append(subprocess.Popen([sk.cli_path(), "-r", strain, "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")],
+                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=60) for p in ps]
+    assert time.time() - t0 < 30
+    assert all(p.returncode != 0 for p in ps), [(p.returncode, o[1][-300:]) for p, o in zip(ps, outs)]
+    assert outs[0][0] == b"" and outs[1][0] == b""                       # nobody printed a table
+    assert b"could not read file" in outs[1][1]                           # rank 1 says why
+    assert not [f for f in os.listdir(tmp_path) if "hello" in f]
