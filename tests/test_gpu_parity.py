@@ -573,3 +573,37 @@ def test_counters_wrap_and_print_as_signed_through_the_gpu_scan(tmp_path):
     assert (signed < 0).sum() > 1000
     for r in range(0, ks.nrows, 97):
         assert lines[1 + r] == b"%s\t%d\t%d\t%d" % (okeys[r], int(ref_col[r]), int(pan_col[r]), int(signed[r])), r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub_rate", [0.01, 0.03, 0.10])
+def test_diverged_copies_of_the_strain_vs_oracle(sub_rate):
+    """every read a copy of a strain segment with 1 / 3 / 10 % substitutions, both strands, long and short: the regime of
+    near-copy genomes in an -A list.  Stage 2 explains what it can by the diagonal, rejects the windows around a
+    differing base by three filter questions per base, and sends the rest one by one -- the counts must be the oracle's."""
+    rng = random.Random(int(sub_rate * 1000))
+    strain = _synth.rand_dna(rng, 150_000)
+    sstream = strain[:70_000] + b"\n" + strain[70_000:] + b"\n"
+    recs = []
+    for i in range(2500):
+        L = rng.choice([40, 100, 150, 150, 400, 3000])
+        a = rng.randrange(0, len(strain) - L)
+        r = bytearray(strain[a:a + L])
+        for j in range(L):
+            if rng.random() < sub_rate:
+                r[j] = rng.choice(b"ACGT")
+        recs.append(_synth.revcomp(bytes(r)) if rng.random() < 0.5 else bytes(r))
+    data = b"\n".join(recs) + b"\n"
+    ks = sk.Keyset.from_stream(sstream)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream) == 0
+    t.scan_stream(data, 2)
+    _, ocounts = t.rows()
+    for text_stage in (1, 0):
+        with sk.KmerContext(0) as c:
+            c.set_option("text_stage", text_stage)
+            c.load_keyset(ks, 4)
+            c.scan_stream(data, 2)
+            got = c.counts(2)
+        assert np.array_equal(got, ocounts[:, 2]), text_stage
+    assert ocounts[:, 2].sum() > 20_000
