@@ -9,6 +9,7 @@ missing, importing :mod:`strainer2_amd.native` raises.
 from .native import (  # noqa: F401
     SKError,
     KmerContext,
+    KmerUnion,
     Keyset,
     lib,
     library_path,
@@ -17,5 +18,5 @@ from .native import (  # noqa: F401
     run_cli_inprocess,
 )
 
-__all__ = ["SKError", "KmerContext", "Keyset", "lib", "library_path", "cli_path", "decode_file",
+__all__ = ["SKError", "KmerContext", "KmerUnion", "Keyset", "lib", "library_path", "cli_path", "decode_file",
            "run_cli_inprocess"]

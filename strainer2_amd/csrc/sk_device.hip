@@ -122,7 +122,34 @@ struct sk_sink {
     // tail of every launch (same-address atomics serialise in the L2)
     uint2              *lds_hits;
     uint32_t           *lds_n;        // [0] places reserved so far, [1] end of the valid share (SK_AGG until a reservation did not fit)
+    // TALLY against a union table (sk_union: the key sets of `ns` strains in one table).  umask[row] = {bit s: strain s holds
+    // the row's key, bit s: and it is informative there}; the tallies are then per (record, strain): tally[2 * (record * ns + s)],
+    // and a log entry is (position | s << 26, row) -- one per strain in which the hit is informative.  ns != 0 says so, and the
+    // masks then stand where the type column would (`type`, see sk_umask): the kernel is short of scalar registers.
+    uint32_t            ns;
 };
+__device__ __forceinline__ const uint2 *sk_umask(const sk_sink &k) { return (const uint2 *)k.type; }
+
+// union table: a hit of `count` windows on a key held by the strains in `members`, in record `rec`
+__device__ __forceinline__ void sk_union_credit(const sk_sink &k, uint32_t rec, uint32_t members, uint32_t count)
+{
+    while (members) {
+        const uint32_t s = (uint32_t)__builtin_ctz(members);
+        members &= members - 1u;
+        atomicAdd(&k.tally[2u * (rec * k.ns + s)], count);
+    }
+}
+// ... and its informative side: one tally and one log entry per strain in `infm`
+__device__ __forceinline__ void sk_union_informative(const sk_sink &k, uint32_t rec, uint32_t infm, uint32_t pos, uint32_t row)
+{
+    while (infm) {
+        const uint32_t s = (uint32_t)__builtin_ctz(infm);
+        infm &= infm - 1u;
+        atomicAdd(&k.tally[2u * (rec * k.ns + s) + 1u], 1u);
+        const unsigned long long i = atomicAdd(k.nhits, 1ull);
+        if (i < k.hits_cap) k.hits[i] = make_uint2(pos | (s << 26), row);
+    }
+}
 
 // reserve `n` consecutive places of the hit log for the calling wave (wave-uniform n > 0; every lane gets the answer):
 // in the workgroup's LDS share if they fit (*in_lds = true, index into lds_hits), else in the global log
@@ -172,12 +199,18 @@ __device__ __forceinline__ uint32_t sk_record_of(const sk_sink &k, uint32_t pos)
     return lo;
 }
 
-template <bool TALLY, bool NOATOMIC = false>
+template <bool TALLY, bool NOATOMIC = false, bool UNION = false>
 __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32_t pos)
 {
     if (NOATOMIC) { if (row == 0x7FFFFFFFu) k.counts[0] = pos; return; }      // timing experiment only
     if (!TALLY) { atomicAdd(&k.counts[row], 1u); return; }
     const uint32_t lo = sk_record_of(k, pos);
+    if (UNION) {
+        const uint2 mk = sk_umask(k)[row];
+        sk_union_credit(k, lo, mk.x, 1u);
+        sk_union_informative(k, lo, mk.y, pos, row);
+        return;
+    }
     atomicAdd(&k.tally[2u * lo], 1u);
     if (k.type[row] == k.inf_value) {
         atomicAdd(&k.tally[2u * lo + 1u], 1u);
@@ -189,9 +222,11 @@ __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32
 // TALLY for a whole wave at once (every lane calls it; `hit` = counter index or 0xFFFFFFFF): lanes of
 // one read sit next to each other, so each run of lanes with the same record adds its hit counts
 // with ONE atomic per tally word, and the hit log takes one atomic per wave.
+template <bool UNION = false>
 __device__ __forceinline__ void sk_tally_wave(const sk_sink &k, uint32_t hit, uint32_t pos, uint32_t lane)
 {
     const bool is_hit = hit != 0xFFFFFFFFu;
+    if (UNION) { if (is_hit) sk_on_hit<true, false, true>(k, hit, pos); return; }       // (union table: per (record, strain), lane by lane)
     uint32_t rec = 0xFFFFFF00u | lane;                    // distinct per lane when there is no hit
     bool is_inf = false;
     if (is_hit) {
@@ -230,14 +265,14 @@ __device__ __forceinline__ uint32_t sk_find(uint64_t canon, const sk_table_view 
 }
 
 // stage 2 for one window: slot from the k-mer hash, linear probing, 62-bit compare
-template <bool TALLY, bool NOATOMIC = false>
+template <bool TALLY, bool NOATOMIC = false, bool UNION = false>
 __device__ __forceinline__ void sk_probe(uint64_t canon, const sk_table_view &t, const sk_sink &k, uint32_t pos)
 {
     uint32_t slot = sk_slot0(sk_khash(canon), t.mask);
     for (;;) {
         const sk_u4 e = t.slots[slot];
         const uint64_t key = sk_slot_key(e);
-        if (key == canon) { sk_on_hit<TALLY, NOATOMIC>(k, e.z, pos); return; }
+        if (key == canon) { sk_on_hit<TALLY, NOATOMIC, UNION>(k, e.z, pos); return; }
         if (key == SK_EMPTY64) return;
         slot = (slot + 1u) & t.mask;
     }
@@ -396,7 +431,7 @@ __device__ __forceinline__ sk_u4 sk_load_chunk(const uint8_t *__restrict__ strea
 // CAND: third pass of the partitioned pipeline (sk_bin -> sk_lds_probe -> this): `cand` holds one byte per chunk of the
 // batch, non-zero for the chunks the LDS-resident filter slices could not rule out; only those chunks (and the lines
 // around them) are read and looked at.
-template <bool TALLY, int ABLATE, bool CAND>
+template <bool TALLY, int ABLATE, bool CAND, bool UNION = false>
 __global__ __launch_bounds__(SK_THREADS)
 void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags, const uint8_t *__restrict__ cand)
@@ -673,7 +708,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             }
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
-            if (TALLY) sk_tally_wave(sink, hit[s2], (uint32_t)tile0 + e[s2], lane);
+            if (TALLY) sk_tally_wave<UNION>(sink, hit[s2], (uint32_t)tile0 + e[s2], lane);
             else if (hit[s2] != 0xFFFFFFFFu) count_row(hit[s2], (uint32_t)tile0 + e[s2]);
         }
         __builtin_amdgcn_wave_barrier();
@@ -844,7 +879,23 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 }
                 fb = un | (dir ? __builtin_bitreverse32(dups) >> 16 : dups);
             }
-            if (TALLY) {
+            if (TALLY && UNION) {
+                // union table: the windows' rows each name their strains; consecutive rows mostly name the same ones
+                if (hits) {
+                    const uint32_t rcd = sk_record_of(sink, (uint32_t)tile0 + ch * 16u);
+                    uint32_t h = hits, cur = 0u, cnt = 0u;
+                    while (h) {
+                        const uint32_t a = (uint32_t)__builtin_ctz(h);
+                        h &= h - 1u;
+                        const uint32_t row = r0 + (uint32_t)__popc(bits16 & ((1u << a) - 1u));
+                        const uint2 mk = sk_umask(sink)[row];
+                        if (mk.x != cur) { sk_union_credit(sink, rcd, cur, cnt); cur = mk.x; cnt = 0u; }
+                        cnt++;
+                        if (mk.y) sk_union_informative(sink, rcd, mk.y, (uint32_t)tile0 + ch * 16u + 15u + (dir ? 15u - a : a), row);
+                    }
+                    sk_union_credit(sink, rcd, cur, cnt);
+                }
+            } else if (TALLY) {
                 // A chunk's windows all lie in the record that holds the chunk, and their rows are consecutive ranks:
                 // the chunk adds popcount(hits) to its record's tally, and the informative ones among them come from 16
                 // bits of the "row is informative" bitmap.  Lanes of one read are neighbours: one atomic per run.
@@ -1105,7 +1156,7 @@ struct sk_wide_view {
     uint32_t        nwide;
 };
 
-template <bool TALLY>
+template <bool TALLY, bool UNION = false>
 __global__ __launch_bounds__(256)
 void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, sk_wide_view wide, sk_sink sink,
@@ -1158,7 +1209,7 @@ void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         if (opure) {                                   // e.g. a window with U whose revcomp wins
             uint64_t key = 0;
             for (int i = 0; i < SK_K; i++) key = (key << 2) | sk_code((uint8_t)o[i]);
-            sk_probe<TALLY>(key, table, sink, (uint32_t)p);
+            sk_probe<TALLY, false, UNION>(key, table, sink, (uint32_t)p);
         } else if (wide.nwide) {
             uint32_t slot = sk_hash_wide(o) & wide.wmask;
             for (;;) {
@@ -1167,7 +1218,7 @@ void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 const char *cand = wide.keys31 + (size_t)(e - 1u) * 32u;
                 bool same = true;
                 for (int i = 0; i < SK_K; i++) same &= (cand[i] == o[i]);
-                if (same) { sk_on_hit<TALLY>(sink, wide.rows[e - 1u], (uint32_t)p); break; }
+                if (same) { sk_on_hit<TALLY, false, UNION>(sink, wide.rows[e - 1u], (uint32_t)p); break; }
                 slot = (slot + 1u) & wide.wmask;
             }
         }
@@ -1798,7 +1849,9 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     }
 #define SK_LAUNCH_GRID(T, A, C) hipLaunchKernelGGL((sk_scan_grid<T, A, C>), grid, block, 0, c->stream, \
                                                    d_stream, nbytes, emit_begin, tv, sink, c->d_flags, d_cand)
-    if (piped && tally_sink) SK_LAUNCH_GRID(true, 0, true);
+    if (tally_sink && tally_sink->ns)
+        hipLaunchKernelGGL((sk_scan_grid<true, 0, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, c->d_flags, d_cand);
+    else if (piped && tally_sink) SK_LAUNCH_GRID(true, 0, true);
     else if (piped && c->ablate == 7) SK_LAUNCH_GRID(false, 7, true);
     else if (piped && c->ablate == 8) SK_LAUNCH_GRID(false, 8, true);
     else if (piped && c->ablate == 9) SK_LAUNCH_GRID(false, 9, true);
@@ -1819,7 +1872,10 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     }
     uint64_t wblocks = (nbytes - emit_begin + 255) / 256;
     if (wblocks > 16384) wblocks = 16384;
-    if (tally_sink)
+    if (tally_sink && tally_sink->ns)
+        hipLaunchKernelGGL((sk_scan_wide<true, true>), dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
+                           d_stream, nbytes, emit_begin, tv, wv, sink, c->d_flags);
+    else if (tally_sink)
         hipLaunchKernelGGL(sk_scan_wide<true>, dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
                            d_stream, nbytes, emit_begin, tv, wv, sink, c->d_flags);
     else
@@ -2023,6 +2079,284 @@ extern "C" int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes,
     if ((rc = sk_tally_launch(c, c->own_batch, type_col, informative_value, hits_cap)) != SK_OK) return rc;
     return sk_tally_collect(c, out_tally, out_hits, out_nhits);
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// One table for several resident strains (strain_detect -S, BASELINE configs[4]: 32 strains per GPU against one
+// metagenome).  Without it a batch of reads is scanned once per strain; with it once.  New relative to the reference,
+// which holds one strain per process (src/strain_detect.c:137-146).
+//
+// The union is built on the device from the members' resident tables: global row g = base[s] + the member's counter
+// index; the members' texts and rank maps are laid one behind the other (each padded to a multiple of 64 bases), so
+// that seed-and-verify works on the union as it does on one strain.  A key that several strains hold gets ONE slot (the
+// first member's: its row and text position), but every one of its global rows carries the same pair of masks
+// {members that hold the key, members in which it is informative}: whichever row a hit comes out at -- the slot's, or
+// the rank of a position in another member's text -- it names the same strains.  The hit log names, per informative
+// strain, that member's own row (sk_union_resolve looks the key up in the member's table).
+// ---------------------------------------------------------------------------------------------
+struct sk_union_member { const sk_u4 *slots; uint32_t mask; const uint32_t *inv; };
+
+__global__ void sk_union_insert(const sk_u4 *__restrict__ mslots, uint64_t nslots, uint32_t base, uint32_t tbase,
+                                sk_u4 *slots, uint32_t mask, uint64_t *__restrict__ ukeys)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += stride) {
+        const sk_u4 e = mslots[i];
+        const uint64_t k = sk_slot_key(e);
+        if (k == SK_EMPTY64) continue;
+        const uint32_t g = base + e.z;
+        ukeys[g] = k;
+        const uint32_t tp = e.w >> 1;
+        const uint32_t w = tp == 0x7FFFFFFFu ? e.w : (((tbase + tp) << 1) | (e.w & 1u));
+        uint32_t slot = sk_slot0(sk_khash(k), mask);
+        for (;;) {
+            const unsigned long long old = atomicCAS((unsigned long long *)&slots[slot], (unsigned long long)SK_EMPTY64, (unsigned long long)k);
+            if (old == SK_EMPTY64) { ((uint32_t *)&slots[slot])[2] = g; ((uint32_t *)&slots[slot])[3] = w; break; }
+            if (old == k) break;                           // an earlier member holds the key: its slot stands
+            slot = (slot + 1u) & mask;
+        }
+    }
+}
+
+// pass A: every row finds its key's slot row ("canon") and sets its member's bits there
+__global__ void sk_union_mask_a(const sk_u4 *__restrict__ mslots, uint64_t nslots, uint32_t base, uint32_t s,
+                                const uint32_t *__restrict__ type, uint32_t inf_value,
+                                const sk_u4 *__restrict__ slots, uint32_t mask, uint2 *umask, uint32_t *__restrict__ canon)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += stride) {
+        const sk_u4 e = mslots[i];
+        const uint64_t k = sk_slot_key(e);
+        if (k == SK_EMPTY64) continue;
+        uint32_t slot = sk_slot0(sk_khash(k), mask), w = 0xFFFFFFFFu;
+        for (;;) {
+            const sk_u4 u = slots[slot];
+            const uint64_t uk = sk_slot_key(u);
+            if (uk == k) { w = u.z; break; }
+            if (uk == SK_EMPTY64) break;                   // (cannot happen: every key was inserted)
+            slot = (slot + 1u) & mask;
+        }
+        const uint32_t g = base + e.z;
+        canon[g] = w == 0xFFFFFFFFu ? g : w;
+        if (w == 0xFFFFFFFFu) continue;
+        atomicOr(&umask[w].x, 1u << s);
+        if (type[e.z] == inf_value) atomicOr(&umask[w].y, 1u << s);
+    }
+}
+
+// pass B: the other rows of a key copy the pair
+__global__ void sk_union_mask_b(uint2 *umask, const uint32_t *__restrict__ canon, uint32_t n)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t w = canon[g];
+    if (w != g && w < n) umask[g] = umask[w];
+}
+
+// a member's rank map into the union's: counter indices move by the member's base
+__global__ void sk_union_rank_copy(sk_u4 *__restrict__ dst, const sk_u4 *__restrict__ src, uint32_t nsrc, uint32_t ndst, uint32_t base, uint32_t after)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= ndst) return;
+    if (b < nsrc) { sk_u4 r = src[b]; r.x += base; dst[b] = r; }
+    else dst[b] = (sk_u4){after, 0u, 0u, 0u};             // padding: no row starts here
+}
+
+// the log's rows: from the union's global row to the named member's own row of the same key
+__global__ void sk_union_resolve(uint2 *hits, const unsigned long long *__restrict__ nhits, unsigned long long cap,
+                                 const uint64_t *__restrict__ ukeys, const sk_union_member *__restrict__ mem)
+{
+    const unsigned long long n = *nhits < cap ? *nhits : cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint2 e = hits[i];
+        const sk_union_member m = mem[e.x >> 26];
+        const uint64_t k = ukeys[e.y];
+        uint32_t slot = sk_slot0(sk_khash(k), m.mask), row = 0xFFFFFFFFu;
+        for (;;) {
+            const sk_u4 u = m.slots[slot];
+            const uint64_t uk = sk_slot_key(u);
+            if (uk == k) { row = m.inv ? m.inv[u.z] : u.z; break; }
+            if (uk == SK_EMPTY64) break;
+            slot = (slot + 1u) & m.mask;
+        }
+        hits[i].y = row;
+    }
+}
+
+struct sk_union {
+    sk_ctx   *uc;                    // the union as a context of its own (table, text, filters, scratch, stream)
+    uint32_t  n;
+    uint64_t *d_ukeys;               // [rows] key of every global row
+    uint2    *d_umask;               // [rows]
+    sk_union_member *d_members;
+};
+
+extern "C" void sk_union_destroy(sk_union *u)
+{
+    if (!u) return;
+    if (u->uc) {
+        hipSetDevice(u->uc->device);
+        hipStreamSynchronize(u->uc->stream);
+        hipFree(u->d_ukeys); hipFree(u->d_umask); hipFree(u->d_members);
+        sk_ctx_destroy(u->uc);
+    }
+    delete u;
+}
+
+extern "C" int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type_col, uint32_t informative_value, sk_union **out)
+{
+    if (!members || !out || n < 1 || n > SK_UNION_MAX) return SK_E_ARG;
+    *out = NULL;
+    sk_ctx *first = members[0];
+    if (!first) return SK_E_ARG;
+    uint64_t rows = 0, tbases = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        sk_ctx *m = members[s];
+        if (!m) return SK_E_ARG;
+        if (m->device != first->device) return sk_fail(first, SK_E_ARG, "the members of a union live on one device");
+        if (!m->d_keys || !m->nrows) return sk_fail(first, SK_E_STATE, "member %u has no table", s);
+        if (type_col >= m->ncols) return sk_fail(first, SK_E_ARG, "column %u out of range", type_col);
+        if (m->nwide) return sk_fail(first, SK_E_STATE, "member %u has byte-string keys: no union", s);
+        if (!m->d_text2 || !m->d_rank || m->no_text) return sk_fail(first, SK_E_STATE, "member %u has no text stage: no union", s);
+        rows += m->nrows;
+        tbases += ((uint64_t)m->text_bases + 63u) / 64u * 64u + 64u;
+    }
+    if (rows > 0x7FFFFFF0ull || tbases > 0x7FFFFF00ull) return sk_fail(first, SK_E_STATE, "union too large (%llu rows, %llu bases)", (unsigned long long)rows, (unsigned long long)tbases);
+    SK_HIP(first, hipSetDevice(first->device));
+    sk_union *u = new (std::nothrow) sk_union();
+    if (!u) return SK_E_NOMEM;
+    u->uc = NULL; u->n = n; u->d_ukeys = NULL; u->d_umask = NULL; u->d_members = NULL;
+    int rc = sk_ctx_create(&u->uc, first->device);
+    if (rc != SK_OK) { delete u; return rc; }
+    sk_ctx *c = u->uc;
+#define SK_U(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { sk_fail(first, SK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); sk_union_destroy(u); return SK_E_HIP; } } while (0)
+    const uint32_t nrows = (uint32_t)rows;
+    uint32_t lg = 10;
+    while (((uint64_t)1 << lg) * (uint64_t)first->table_load_pct < rows * 100ull && lg < 31) lg++;
+    const uint64_t slots = (uint64_t)1 << lg;
+    c->slots_log2 = lg;
+    c->nrows = nrows; c->ncols = 1;
+    SK_U(hipMalloc((void **)&c->d_keys, slots * sizeof(sk_u4)));
+    SK_U(hipMalloc((void **)&u->d_ukeys, (size_t)nrows * 8));
+    SK_U(hipMalloc((void **)&u->d_umask, (size_t)nrows * 8));
+    uint32_t *d_canon = NULL;
+    SK_U(hipMalloc((void **)&d_canon, (size_t)nrows * 4));
+    hipLaunchKernelGGL(sk_fill64, dim3(2048), dim3(256), 0, c->stream, (uint64_t *)c->d_keys, 2 * slots, SK_EMPTY64);
+    hipLaunchKernelGGL(sk_fill64, dim3(2048), dim3(256), 0, c->stream, u->d_ukeys, (uint64_t)nrows, SK_EMPTY64);
+    SK_U(hipMemsetAsync(u->d_umask, 0, (size_t)nrows * 8, c->stream));
+    // text and rank map, member behind member
+    const uint32_t text_bases = (uint32_t)tbases;
+    const size_t words = (size_t)text_bases / 16 + 4, nblk = (size_t)text_bases / 64 + 2;
+    SK_U(hipMalloc((void **)&c->d_text2, words * 4));
+    SK_U(hipMalloc((void **)&c->d_rank, nblk * sizeof(sk_u4)));
+    SK_U(hipMemsetAsync(c->d_text2, 0, words * 4, c->stream));
+    std::vector<sk_union_member> hm(n);
+    uint32_t base = 0, tbase = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        sk_ctx *m = members[s];
+        int frc = sk_diff_flush(m);                         // (the type column is read below)
+        if (frc != SK_OK) { hipFree(d_canon); sk_union_destroy(u); return frc; }
+        SK_U(hipStreamSynchronize(m->stream));
+        const uint64_t mslots = (uint64_t)1 << m->slots_log2;
+        hipLaunchKernelGGL(sk_union_insert, dim3(4096), dim3(256), 0, c->stream, (const sk_u4 *)m->d_keys, mslots, base, tbase,
+                           c->d_keys, (uint32_t)(slots - 1), u->d_ukeys);
+        const uint32_t span = (uint32_t)(((uint64_t)m->text_bases + 63u) / 64u * 64u + 64u);
+        SK_U(hipMemcpyAsync(c->d_text2 + tbase / 16u, m->d_text2, (((size_t)m->text_bases + 15) / 16) * 4, hipMemcpyDeviceToDevice, c->stream));
+        const uint32_t nsrc = m->text_bases / 64u + 1u, ndst = span / 64u;
+        hipLaunchKernelGGL(sk_union_rank_copy, dim3((ndst + 255) / 256), dim3(256), 0, c->stream, c->d_rank + tbase / 64u, (const sk_u4 *)m->d_rank,
+                           nsrc < ndst ? nsrc : ndst, ndst, base, base + m->nrows);
+        hm[s].slots = m->d_keys; hm[s].mask = (uint32_t)(mslots - 1); hm[s].inv = m->d_inv;
+        base += m->nrows;
+        tbase += span;
+    }
+    hipLaunchKernelGGL(sk_union_rank_copy, dim3(1), dim3(256), 0, c->stream, c->d_rank + tbase / 64u, (const sk_u4 *)c->d_rank, 0u, (uint32_t)(nblk - tbase / 64u), 0u, nrows);
+    base = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        sk_ctx *m = members[s];
+        hipLaunchKernelGGL(sk_union_mask_a, dim3(4096), dim3(256), 0, c->stream, (const sk_u4 *)m->d_keys, (uint64_t)1 << m->slots_log2, base, s,
+                           (const uint32_t *)(m->d_counts + (size_t)type_col * m->nrows), informative_value,
+                           (const sk_u4 *)c->d_keys, (uint32_t)(slots - 1), u->d_umask, d_canon);
+        base += m->nrows;
+    }
+    hipLaunchKernelGGL(sk_union_mask_b, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, u->d_umask, (const uint32_t *)d_canon, nrows);
+    {   // the filters, sized for all the keys (level 1 no longer fits the L2: its misses go to the Infinity Cache)
+        uint64_t kib = first->grid_kib > 0 ? (uint64_t)first->grid_kib * n : ((uint64_t)nrows * 5ull / 8ull + 1023ull) / 1024ull;
+        if (kib > (1ull << 22)) kib = 1ull << 22;
+        if (kib < 4ull) kib = 4ull;
+        c->grid1_blocks = (uint32_t)(kib * 1024ull / sizeof(uint2));
+        uint32_t g2 = 12;
+        while (g2 < 37 && ((uint64_t)1 << g2) < (uint64_t)nrows * 32ull) g2++;
+        c->grid2_blocks_log2 = g2 - 6u;
+        const size_t b1 = (size_t)c->grid1_blocks * sizeof(uint2), b2 = ((size_t)1 << c->grid2_blocks_log2) * sizeof(uint2);
+        SK_U(hipMalloc((void **)&c->d_grid1, b1));
+        SK_U(hipMalloc((void **)&c->d_grid2, b2));
+        SK_U(hipMemsetAsync(c->d_grid1, 0, b1, c->stream));
+        SK_U(hipMemsetAsync(c->d_grid2, 0, b2, c->stream));
+        hipLaunchKernelGGL(sk_grid_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)u->d_ukeys, nrows,
+                           (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+    }
+    SK_U(hipMalloc((void **)&u->d_members, n * sizeof(sk_union_member)));
+    SK_U(hipMemcpyAsync(u->d_members, hm.data(), n * sizeof(sk_union_member), hipMemcpyHostToDevice, c->stream));
+    SK_U(hipStreamSynchronize(c->stream));
+    hipFree(d_canon);
+    SK_U(hipGetLastError());
+#undef SK_U
+    c->text_bases = text_bases;
+    *out = u;
+    return SK_OK;
+}
+
+// Start the tallies of batch `b` against every member at once; returns at once.  Results: sk_union_tally_collect.
+extern "C" int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hits_cap)
+{
+    if (!u || !b) return SK_E_ARG;
+    sk_ctx *c = u->uc;
+    if (b->owner->device != c->device) return sk_fail(c, SK_E_ARG, "batch lives on another device");
+    if (b->nrec == 0) return sk_fail(c, SK_E_STATE, "empty batch");
+    if (b->nbytes >= (1ull << 26)) return sk_fail(c, SK_E_ARG, "a union tallies batches below 64 MiB (the log packs the member beside the offset)");
+    const uint64_t vrec = (uint64_t)b->nrec * u->n;
+    if (vrec > 0x7FFFFFF0ull) return sk_fail(c, SK_E_ARG, "too many records x members");
+    SK_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)vrec * 8 + 16)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_compact, &c->t_compact_cap, (size_t)vrec * 12 + 16)) != SK_OK) return rc;
+    if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
+    if (!c->h_tally) { SK_HIP(c, hipHostMalloc((void **)&c->h_tally, 4096, hipHostMallocDefault)); c->h_tally_cap = 4096; }
+    unsigned long long *d_n = (unsigned long long *)((uint8_t *)c->t_tally + (size_t)vrec * 8);
+    SK_HIP(c, hipStreamWaitEvent(c->stream, b->ready, 0));
+    SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)vrec * 8 + 16, c->stream));
+    sk_sink sink;
+    memset(&sink, 0, sizeof sink);
+    sink.rec_start = (const uint32_t *)b->d_rec; sink.nrec = b->nrec; sink.tally = (uint32_t *)c->t_tally;
+    sink.tile_first = (const uint32_t *)b->d_rec + b->nrec;
+    sink.hits = (uint2 *)c->t_hits; sink.nhits = d_n; sink.hits_cap = hits_cap;
+    sink.type = (const uint32_t *)u->d_umask; sink.ns = u->n;
+    rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sk_tally_compact, dim3((uint32_t)((vrec + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)c->t_tally, (uint32_t)vrec,
+                       (uint32_t *)c->t_compact, d_n + 1);
+    hipLaunchKernelGGL(sk_union_resolve, dim3(256), dim3(256), 0, c->stream, (uint2 *)c->t_hits, (const unsigned long long *)d_n,
+                       (unsigned long long)hits_cap, (const uint64_t *)u->d_ukeys, (const sk_union_member *)u->d_members);
+    SK_HIP(c, hipMemcpyAsync(c->h_tally, d_n, 16, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(c, hipGetLastError());
+    c->t_inflight_nrec = (uint32_t)vrec;
+    c->t_inflight_cap = hits_cap;
+    return SK_OK;
+}
+
+// out[i] = {record * members + member, all hits, informative hits} for the pairs with at least one hit (unordered);
+// out_hits[j] = {member << 26 | window-end offset, the member's own row}.  *out_nhits may exceed the launch's hits_cap:
+// launch again with more room.
+extern "C" int sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *out_hits, uint64_t *out_nhits)
+{
+    if (!u) return SK_E_ARG;
+    return sk_tally_collect_sparse(u->uc, out, cap, n, out_hits, out_nhits);
+}
+
+extern "C" const char *sk_union_last_error(const sk_union *u) { return u ? u->uc->err : "no union"; }
+extern "C" uint32_t sk_union_members(const sk_union *u) { return u ? u->n : 0u; }
+extern "C" uint32_t sk_union_rows(const sk_union *u) { return u ? u->uc->nrows : 0u; }
 
 extern "C" int sk_scan_device(sk_ctx *c, const void *dev_stream, uint64_t nbytes, uint32_t col)
 {

@@ -52,6 +52,8 @@ ABI_SYMBOLS = [
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
     "sk_distinct_count", "sk_first_seen_count", "skh_coverage_depth_main",
     "sk_batch_create", "sk_batch_destroy", "sk_batch_fill", "sk_tally_launch", "sk_tally_collect", "sk_tally_collect_sparse",
+    "sk_union_create", "sk_union_destroy", "sk_union_tally_launch", "sk_union_tally_collect", "sk_union_last_error",
+    "sk_union_members", "sk_union_rows",
 ]
 
 
@@ -141,6 +143,17 @@ lib.sk_batch_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.
 lib.sk_tally_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
 lib.sk_tally_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
 lib.sk_tally_collect_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]
+lib.sk_union_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+lib.sk_union_destroy.argtypes = [C.c_void_p]
+lib.sk_union_destroy.restype = None
+lib.sk_union_tally_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+lib.sk_union_tally_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]
+lib.sk_union_last_error.argtypes = [C.c_void_p]
+lib.sk_union_last_error.restype = C.c_char_p
+lib.sk_union_members.argtypes = [C.c_void_p]
+lib.sk_union_members.restype = C.c_uint32
+lib.sk_union_rows.argtypes = [C.c_void_p]
+lib.sk_union_rows.restype = C.c_uint32
 
 _libc = C.CDLL(None)
 _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
@@ -367,6 +380,73 @@ class KmerContext:
                 lib.sk_dev_free(self._h, p)
             self._bufs = []
             lib.sk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class KmerUnion:
+    """One table for several resident strains (sk_union_*): a batch is tallied against all of them in one launch."""
+
+    def __init__(self, contexts, type_col=0, informative_value=2):
+        self._members = list(contexts)                    # (they must outlive the union)
+        arr = (C.c_void_p * len(self._members))(*[c._h for c in self._members])
+        self._h = C.c_void_p()
+        rc = lib.sk_union_create(arr, len(self._members), type_col, informative_value, C.byref(self._h))
+        if rc:
+            self._h = None
+            raise SKError(rc, lib.sk_last_error(self._members[0]._h).decode() if self._members else "no members")
+        self._batch = C.c_void_p()
+        rc = lib.sk_batch_create(self._members[0]._h, C.byref(self._batch))
+        if rc:
+            raise SKError(rc, "sk_batch_create")
+
+    @property
+    def rows(self):
+        return lib.sk_union_rows(self._h)
+
+    def tally_batch(self, stream: bytes, rec_start, hits_cap=None):
+        """returns (tally[nrec, members, 2], hits[n, 3] = (member, window-end offset, the member's row) sorted)"""
+        rec_start = np.ascontiguousarray(rec_start, dtype=np.uint32)
+        nrec, n = len(rec_start), len(self._members)
+        rc = lib.sk_batch_fill(self._batch, stream, len(stream), rec_start.ctypes.data, nrec)
+        if rc:
+            raise SKError(rc, lib.sk_last_error(self._members[0]._h).decode())
+        cap = hits_cap if hits_cap is not None else max(len(stream) * 2, 16)
+        while True:
+            rc = lib.sk_union_tally_launch(self._h, self._batch, cap)
+            if rc:
+                raise SKError(rc, lib.sk_union_last_error(self._h).decode())
+            recs = np.zeros((nrec * n + 1, 3), dtype=np.uint32)
+            hits = np.zeros((max(cap, 1), 2), dtype=np.uint32)
+            nr, nh = C.c_uint64(0), C.c_uint64(0)
+            rc = lib.sk_union_tally_collect(self._h, recs.ctypes.data, nrec * n, C.byref(nr), hits.ctypes.data, C.byref(nh))
+            if rc:
+                raise SKError(rc, lib.sk_union_last_error(self._h).decode())
+            if nh.value <= cap:
+                break
+            cap = nh.value + 16                           # the log overflowed: once more with room
+        tally = np.zeros((nrec * n, 2), dtype=np.uint32)
+        recs = recs[: nr.value]
+        tally[recs[:, 0]] = recs[:, 1:]
+        hits = hits[: nh.value]
+        out = np.stack([hits[:, 0] >> 26, hits[:, 0] & ((1 << 26) - 1), hits[:, 1]], axis=1) if len(hits) else np.zeros((0, 3), dtype=np.uint32)
+        order = np.lexsort((out[:, 2], out[:, 1], out[:, 0]))
+        return tally.reshape(nrec, n, 2), out[order]
+
+    def close(self):
+        if getattr(self, "_batch", None):
+            lib.sk_batch_destroy(self._batch)
+            self._batch = None
+        if getattr(self, "_h", None):
+            lib.sk_union_destroy(self._h)
             self._h = None
 
     def __del__(self):
