@@ -70,6 +70,7 @@ typedef struct {
     skc_acc    *cov; char *cov_path, *o_path;           /* --coverage-depth: step 4 of the workflow, fed at emission */
     sk_hit     *hitbuf; uint64_t hitcap;   /* landing area of the hit log */
     uint32_t   *tallybuf; uint32_t tallycap;
+    uint64_t    u_nsp, u_nh;               /* union table: this strain's share of a batch's results, dealt out by sd_tally_chunk */
     int         hc_out, job_rc;            /* results of this strain's part of a pool job */
 } sd_prog;
 
@@ -594,7 +595,7 @@ static int hit_cmp(const void *a, const void *b)
 /* tally one chunk against every strain: one upload, one launch per strain (they overlap on the device),
  * then -- strain by strain on the pool -- the per-record tallies and per-record lists of informative rows, in
  * window order */
-typedef struct { sd_prog *p; sk_batch *batch; sd_chunk *c; } sd_tally_job;
+typedef struct { sd_prog *p; sk_batch *batch; sd_chunk *c; int from_union; } sd_tally_job;
 
 static void tally_one(void *arg, uint32_t s)
 {
@@ -611,18 +612,21 @@ static void tally_one(void *arg, uint32_t s)
     if (c->np == 0) return;
     /* only the pieces that hit this strain at all come back (compacted on the device): with many strains against one
      * metagenome nearly every (read, strain) pair is a blank */
-    if (p->tallycap < c->np) {
+    if (!j->from_union && p->tallycap < c->np) {
         p->tallycap = c->np + c->np / 4 + 1024;
         p->tallybuf = (uint32_t *)realloc(p->tallybuf, (size_t)p->tallycap * sizeof(sk_tally_rec));
     }
     sk_tally_rec *sparse = (sk_tally_rec *)p->tallybuf;
     uint64_t nsp = 0, e;
+    if (j->from_union) { nsp = p->u_nsp; nh = p->u_nh; }  /* (dealt out by sd_tally_chunk: tallybuf and hitbuf hold this strain's share) */
+    else {
     if ((rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
     if (nh > p->hitcap) {                                 /* the log overflowed: once more with room */
         p->hitcap = nh + nh / 4;
         p->hitbuf = (sk_hit *)realloc(p->hitbuf, (size_t)p->hitcap * sizeof(sk_hit));
         if ((rc = sk_tally_launch(p->ctx, j->batch, SD_TYPE, SD_INFORMATIVE, p->hitcap)) != SK_OK ||
             (rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
+    }
     }
     for (e = 0; e < nsp; e++) {                           /* (a record cut into pieces: the pieces' windows add up) */
         const uint32_t rec = c->prec[sparse[e].rec];
@@ -639,12 +643,107 @@ static void tally_one(void *arg, uint32_t s)
     for (; r <= c->nrec; r++) c->hbeg[s][r] = n;
 }
 
+/* Many strains on one device: one union table per group of up to SK_UNION_MAX strains (sk_union_*), so that a batch is
+ * scanned once per group instead of once per strain (BASELINE configs[4]: 32 strains per GPU).  Built by sd_run when the
+ * strains are open and flagged; a strain the union cannot hold (byte-string keys, no text stage), SK_SD_NO_UNION=1, or a
+ * batch of 64 MiB or more (one huge record) leave the member-by-member way below, which gives the same results. */
+static struct { sk_union **u; uint32_t n; sk_tally_rec *recs; uint64_t recs_cap; sk_hit *hits; uint64_t *hcap; } sd_un;
+
+static void sd_unions_close(void)
+{
+    uint32_t g;
+    for (g = 0; g < sd_un.n; g++) sk_union_destroy(sd_un.u[g]);
+    free(sd_un.u); free(sd_un.recs); free(sd_un.hits); free(sd_un.hcap);
+    memset(&sd_un, 0, sizeof sd_un);
+}
+
+static void sd_unions_open(sd_prog *p, uint32_t ns)
+{
+    uint32_t g, ng = (ns + SK_UNION_MAX - 1) / SK_UNION_MAX;
+    const double t0 = now_s();
+    memset(&sd_un, 0, sizeof sd_un);
+    if (ns < 2 || getenv("SK_SD_NO_UNION")) return;
+    sd_un.u = (sk_union **)calloc(ng, sizeof *sd_un.u);
+    sd_un.hcap = (uint64_t *)calloc(ng, sizeof *sd_un.hcap);
+    for (g = 0; g < ng; g++) {
+        sk_ctx *m[SK_UNION_MAX];
+        const uint32_t a = g * SK_UNION_MAX, n = ns - a < SK_UNION_MAX ? ns - a : SK_UNION_MAX;
+        uint32_t k;
+        int rc;
+        for (k = 0; k < n; k++) m[k] = p[a + k].ctx;
+        rc = sk_union_create(m, n, SD_TYPE, SD_INFORMATIVE, &sd_un.u[g]);
+        if (rc != SK_OK) {
+            if (getenv("SK_SD_TIMING")) fprintf(p[0].err, "strain_detect: no union table (%s: %s): strain by strain\n", sk_strerror(rc), sk_last_error(m[0]));
+            sd_un.n = g;
+            sd_unions_close();
+            return;
+        }
+        sd_un.n = g + 1;
+        sd_un.hcap[g] = 1u << 18;
+    }
+    if (getenv("SK_SD_TIMING")) fprintf(p[0].err, "strain_detect timing: %u union table(s) for %u strains in %.2f s\n", ng, ns, now_s() - t0);
+}
+
+/* one batch against the unions; the results are dealt to the strains' tallybuf/hitbuf (u_nsp, u_nh entries) */
+static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
+{
+    uint32_t g, s;
+    int rc;
+    for (g = 0; g < sd_un.n; g++)
+        if ((rc = sk_union_tally_launch(sd_un.u[g], batch, sd_un.hcap[g])) != SK_OK) return rc;
+    for (s = 0; s < ns; s++) p[s].u_nsp = p[s].u_nh = 0;
+    for (g = 0; g < sd_un.n; g++) {
+        const uint32_t a = g * SK_UNION_MAX, n = sk_union_members(sd_un.u[g]);
+        const uint64_t worst = (uint64_t)c->np * n;
+        uint64_t nsp = 0, nh = 0, e;
+        uint64_t cnt[SK_UNION_MAX], hcnt[SK_UNION_MAX];
+        if (worst > sd_un.recs_cap) {                       /* (address space only: pages are touched as far as results come back) */
+            free(sd_un.recs);
+            sd_un.recs_cap = worst + worst / 4 + 1024;
+            sd_un.recs = (sk_tally_rec *)malloc((size_t)sd_un.recs_cap * sizeof *sd_un.recs);
+        }
+        for (;;) {
+            sd_un.hits = (sk_hit *)realloc(sd_un.hits, (size_t)sd_un.hcap[g] * sizeof(sk_hit));
+            if ((rc = sk_union_tally_collect(sd_un.u[g], sd_un.recs, sd_un.recs_cap, &nsp, sd_un.hits, &nh)) != SK_OK) return rc;
+            if (nh <= sd_un.hcap[g]) break;
+            sd_un.hcap[g] = nh + nh / 4;                    /* the log overflowed: once more with room */
+            if ((rc = sk_union_tally_launch(sd_un.u[g], batch, sd_un.hcap[g])) != SK_OK) return rc;
+        }
+        memset(cnt, 0, sizeof cnt); memset(hcnt, 0, sizeof hcnt);
+        for (e = 0; e < nsp; e++) cnt[sd_un.recs[e].rec % n]++;
+        for (e = 0; e < nh; e++) hcnt[sd_un.hits[e].pos >> 26]++;
+        for (s = 0; s < n; s++) {
+            sd_prog *q = &p[a + s];
+            if (q->tallycap < cnt[s] || !q->tallybuf) {
+                q->tallycap = (uint32_t)(cnt[s] + cnt[s] / 4 + 1024);
+                q->tallybuf = (uint32_t *)realloc(q->tallybuf, (size_t)q->tallycap * sizeof(sk_tally_rec));
+            }
+            if (q->hitcap < hcnt[s] || !q->hitbuf) {
+                q->hitcap = hcnt[s] + hcnt[s] / 4 + 1024;
+                q->hitbuf = (sk_hit *)realloc(q->hitbuf, (size_t)q->hitcap * sizeof(sk_hit));
+            }
+        }
+        for (e = 0; e < nsp; e++) {
+            sd_prog *q = &p[a + sd_un.recs[e].rec % n];
+            sk_tally_rec *out = (sk_tally_rec *)q->tallybuf + q->u_nsp++;
+            out->rec = sd_un.recs[e].rec / n; out->all = sd_un.recs[e].all; out->inf = sd_un.recs[e].inf;
+        }
+        for (e = 0; e < nh; e++) {
+            sd_prog *q = &p[a + (sd_un.hits[e].pos >> 26)];
+            sk_hit *out = q->hitbuf + q->u_nh++;
+            out->pos = sd_un.hits[e].pos & ((1u << 26) - 1u); out->row = sd_un.hits[e].row;
+        }
+    }
+    return SK_OK;
+}
+
 static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, sd_chunk *c)
 {
     sd_tally_job job;
     uint32_t s;
     int rc;
     double t0 = now_s(), t1;
+    const int use_union = sd_un.n && c->blen < (1u << 26);
     c->nstrains = ns;
     c->hits = (uint32_t **)calloc(ns, sizeof *c->hits);
     c->inf = (uint32_t **)calloc(ns, sizeof *c->inf);
@@ -653,13 +752,16 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *poo
     if (c->np) {
         if ((rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
         t1 = now_s(); t_fill += t1 - t0; t0 = t1;
+        if (use_union) {
+            if ((rc = sd_tally_unions(p, ns, batch, c)) != SK_OK) return rc;
+        } else
         for (s = 0; s < ns; s++) {
             if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
             if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
         }
         t1 = now_s(); t_launch += t1 - t0; t0 = t1;
     }
-    job.p = p; job.batch = batch; job.c = c;
+    job.p = p; job.batch = batch; job.c = c; job.from_union = use_union;
     pool_run(pool, ns, tally_one, &job);
     t_post += now_s() - t0;
     for (s = 0; s < ns; s++) if (p[s].job_rc != SK_OK) return p[s].job_rc;
@@ -1201,12 +1303,13 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
         return 1;
     }
     sd_pin_open(p[0].ctx, sd_chunk_bytes());
+    sd_unions_open(p, ns);
     pool_start(&pool, ns);
     if (B) {
         FILE *fp = fopen(B, "r");
         char *line = NULL, *nl, *tok, *f1, *f2;
         size_t cap = 0;
-        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); pool_stop(&pool); sk_batch_destroy(batch); return 1; }
+        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); pool_stop(&pool); sd_unions_close(); sk_batch_destroy(batch); return 1; }
         while (!bad && getline(&line, &cap, fp) != -1) {
             int m;
             if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
@@ -1226,6 +1329,7 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
         fclose(fp);
     } else bad = sd_quantify(p, ns, batch, &pool, b, b2, mode);
     pool_stop(&pool);
+    sd_unions_close();
     sk_batch_destroy(batch);
     return bad;
 }

@@ -133,6 +133,47 @@ int sk_tally_collect_sparse(sk_ctx *c, sk_tally_rec *out, uint64_t cap, uint64_t
     free(dense);
     return rc;
 }
+/* the union of several tables: here simply the members asked one after the other, results merged into the union's format */
+struct sk_union { sk_ctx *m[SK_UNION_MAX]; uint32_t n; const sk_batch *b; uint64_t cap; uint32_t type_col, inf_value; };
+int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type_col, uint32_t inf_value, sk_union **out)
+{
+    sk_union *u;
+    uint32_t i;
+    if (!members || !out || n < 1 || n > SK_UNION_MAX) return SK_E_ARG;
+    if (getenv("DOUBLE_NO_UNION")) return SK_E_STATE;                      /* (tests: the member-by-member way) */
+    u = calloc(1, sizeof *u);
+    for (i = 0; i < n; i++) u->m[i] = members[i];
+    u->n = n; u->type_col = type_col; u->inf_value = inf_value;
+    *out = u;
+    return SK_OK;
+}
+void sk_union_destroy(sk_union *u) { free(u); }
+uint32_t sk_union_members(const sk_union *u) { return u->n; }
+uint32_t sk_union_rows(const sk_union *u) { uint32_t i, r = 0; for (i = 0; i < u->n; i++) r += u->m[i]->n; return r; }
+const char *sk_union_last_error(const sk_union *u) { (void)u; return "stub"; }
+int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t cap)
+{
+    if (b->nbytes >= (1u << 26)) return SK_E_ARG;
+    u->b = b; u->cap = cap;
+    return SK_OK;
+}
+int sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *hits, uint64_t *nhits)
+{
+    const uint32_t nrec = u->b->nrec;
+    sk_tally_rec *one = malloc(((size_t)nrec + 1) * sizeof *one);
+    sk_hit *oh = malloc(((size_t)u->cap + 1) * sizeof *oh);
+    uint64_t k = 0, nh = 0, i, got, goth;
+    uint32_t s;
+    for (s = 0; s < u->n; s++) {
+        sk_tally_launch(u->m[s], u->b, u->type_col, u->inf_value, u->cap);
+        sk_tally_collect_sparse(u->m[s], one, nrec, &got, oh, &goth);
+        for (i = 0; i < got; i++) { if (k < cap) { out[k].rec = one[i].rec * u->n + s; out[k].all = one[i].all; out[k].inf = one[i].inf; } k++; }
+        for (i = 0; i < goth; i++) { if (nh < u->cap && i < u->cap) { hits[nh].pos = oh[i].pos | (s << 26); hits[nh].row = oh[i].row; } nh++; }
+    }
+    free(one); free(oh);
+    *n = k; *nhits = nh;
+    return SK_OK;
+}
 int sk_tally_batch(sk_ctx *c, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec, uint32_t type_col,
                    uint32_t inf_value, uint32_t *tally, sk_hit *hits, uint64_t cap, uint64_t *nhits)
 {

@@ -159,9 +159,12 @@ def test_strain_detect_tiny_chunks_under_sanitizers(sd_host_exe, name, chunk, tm
     assert gzip.open(tmp_path / "o.gz", "rb").read() == open(os.path.join(d, "expected.hits"), "rb").read()
 
 
+@pytest.mark.parametrize("union", [True, False])
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])
-def test_strain_detect_many_strains_host_logic_under_sanitizers(san, tmp_path):
-    """-S with four strains (the thread pool is in use): every output equals the single-strain golden"""
+def test_strain_detect_many_strains_host_logic_under_sanitizers(san, union, tmp_path):
+    """-S with four strains (the thread pool is in use): every output equals the single-strain golden; the results
+    of a batch dealt out from a union table (the double merges its members' answers into the union's format), and
+    fetched strain by strain"""
     import gzip
     exe = str(tmp_path / "sd_multi")
     subprocess.run(["gcc", "-O1", "-g", "-fsanitize=" + san, "-fno-omit-frame-pointer"] + SD_SOURCES + ["-lz", "-lpthread", "-o", exe], check=True)
@@ -169,8 +172,11 @@ def test_strain_detect_many_strains_host_logic_under_sanitizers(san, tmp_path):
     with open(tmp_path / "strains.txt", "w") as f:
         for s in range(4):
             f.write(f"strain.fa\tinf.txt.gz\t{tmp_path}/o{s}.gz\n")
-    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4")
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_SD_TIMING="1")
+    if not union:
+        env["DOUBLE_NO_UNION"] = "1"
     p = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", "B.txt", "--coverage-depth"], cwd=d, env=env, capture_output=True)
+    assert (b"1 union table(s) for 4 strains" in p.stderr) == union
     for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
         assert bad not in p.stderr, p.stderr.decode()[-3000:]
     assert p.returncode == 0

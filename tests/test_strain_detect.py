@@ -135,15 +135,28 @@ def _canon(k):
     return k if k >= r else r
 
 
-def _make_multi_inputs(tmp_path, nstrains=3, strain_len=60_000, nreads=320_000):
+def _make_multi_inputs(tmp_path, nstrains=3, strain_len=60_000, nreads=320_000, related=False):
     """nstrains synthetic strains with their informative lists, and a -B list with an SE (.gz), a PE pair and
-    an interleaved file whose decoded size spans more than one 32 MiB chunk; short reads mixed in."""
+    an interleaved file whose decoded size spans more than one 32 MiB chunk; short reads mixed in.  related: the
+    strains are diverged copies of three ancestors (0.5-3 % substitutions, every seventh an exact copy): most k-mers
+    are shared by several strains, and a k-mer informative in one strain is plain in another."""
     rng = random.Random(4242)
-    strains = [_synth.rand_dna(rng, strain_len) for _ in range(nstrains)]
+    if related:
+        anc = [_synth.rand_dna(rng, strain_len) for _ in range(3)]
+        strains = []
+        for s in range(nstrains):
+            g = bytearray(anc[s % 3])
+            rate = 0.0 if s % 7 == 6 else rng.choice([0.005, 0.01, 0.03])
+            for i in range(strain_len):
+                if rng.random() < rate:
+                    g[i] = rng.choice(b"ACGT")
+            strains.append(bytes(g) if s % 5 else _synth.revcomp(bytes(g)))
+    else:
+        strains = [_synth.rand_dna(rng, strain_len) for _ in range(nstrains)]
     lines = []
     for s, g in enumerate(strains):
         (tmp_path / f"s{s}.fa").write_bytes(b">s%d\n" % s + g + b"\n")
-        kms = sorted({_canon(g[i:i + 31]) for i in range(0, strain_len - 31, 17)})
+        kms = sorted({_canon(g[i:i + 31]) for i in range(s % 13 if related else 0, strain_len - 31, 17)})
         with gzip.open(tmp_path / f"s{s}.inf.gz", "wb") as f:
             f.write(b"#informative\n" + b"\n".join(kms) + b"\n")
         lines.append(f"{tmp_path}/s{s}.fa\t{tmp_path}/s{s}.inf.gz\t{tmp_path}/multi{s}.gz\n")
@@ -180,12 +193,18 @@ def _make_multi_inputs(tmp_path, nstrains=3, strain_len=60_000, nreads=320_000):
 
 
 @pytest.mark.gpu
-def test_sd_many_strains_in_one_pass_equal_separate_runs(tmp_path):
+@pytest.mark.parametrize("union", [True, False])
+def test_sd_many_strains_in_one_pass_equal_separate_runs(tmp_path, union):
     """-S <list>: every strain's output is byte-identical (decompressed) to a separate run with its -r/-a/-o,
-    and one of the separate runs is checked against the oracle."""
+    and one of the separate runs is checked against the oracle.  With the union table (one scan per batch for all
+    strains, the default) and strain by strain (SK_SD_NO_UNION=1)."""
     n = _make_multi_inputs(tmp_path)
     exe = sk.cli_path("strain_detect")
-    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt"), "--coverage-depth"], capture_output=True)
+    env = dict(os.environ, SK_SD_TIMING="1")
+    if not union:
+        env["SK_SD_NO_UNION"] = "1"
+    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt"), "--coverage-depth"], capture_output=True, env=env)
+    assert (b"union table(s) for 3 strains" in multi.stderr) == union, multi.stderr.decode()[-800:]
     assert multi.returncode == 0, multi.stderr.decode()[-500:]
     assert multi.stdout == b"unknown file type skipping line (#comment)\nunknown file type skipping line (XX)\n"
     for s in range(n):
@@ -287,3 +306,26 @@ def test_sd_32_strains_against_32_oracle_runs(tmp_path):
         assert gzip.open(tmp_path / f"multi{s}.gz", "rb").read() == want, s
         total += want.count(b"\n")
     assert total > 32 * 50
+
+
+@pytest.mark.gpu
+def test_sd_related_strains_in_two_unions_against_oracle_runs(tmp_path):
+    """40 strains that share most of their k-mers (diverged and exact copies of three ancestors, some on the other
+    strand), i.e. two union tables (32 + 8): a shared k-mer has one slot in a union but counts for every strain
+    that holds it, and is informative only where that strain's list says so.  Every strain's hit list byte-identical
+    to the CPU oracle program's run on that strain alone (src/strain_detect.c:387-663)."""
+    n = _make_multi_inputs(tmp_path, nstrains=40, strain_len=12_000, nreads=40_000, related=True)
+    exe = sk.cli_path("strain_detect")
+    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt")], capture_output=True,
+                           env=dict(os.environ, SK_SD_TIMING="1"))
+    assert multi.returncode == 0, multi.stderr.decode()[-500:]
+    assert b"2 union table(s) for 40 strains" in multi.stderr
+    total = 0
+    for s in range(n):
+        ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / f"s{s}.fa"), "-a", str(tmp_path / f"s{s}.inf.gz"), "-B", str(tmp_path / "B.txt"),
+                                         "-o", str(tmp_path / f"oracle{s}.gz")], str(tmp_path))
+        assert ora.returncode == 0
+        want = gzip.open(tmp_path / f"oracle{s}.gz", "rb").read()
+        assert gzip.open(tmp_path / f"multi{s}.gz", "rb").read() == want, s
+        total += want.count(b"\n")
+    assert total > 40 * 200
