@@ -167,7 +167,7 @@ static void stream_push(sd_stream *st, sd_chunk *c)
 }
 
 /* chunk builder of one parser: where finished chunks go depends on who parses */
-typedef struct sd_seg { unsigned char *buf; size_t n, cap; uint64_t seq; int is_last; } sd_seg;
+typedef struct sd_seg { unsigned char *buf; size_t n, cap; uint64_t seq; int is_last, borrowed; } sd_seg;   /* borrowed: buf points into the mapped file */
 typedef struct {
     sd_stream *st;
     sd_chunk  *cur;                          /* chunk under construction */
@@ -290,7 +290,7 @@ static void *sd_parse_worker(void *arg)
         }
         free(b.done);
         parser_free(&ps);
-        free(sg->buf);
+        if (!sg->borrowed) free(sg->buf);
         free(sg);
     }
 }
@@ -300,7 +300,7 @@ static void sd_seg_dispatch(sd_stream *st, sd_seg *sg)
 {
     pthread_mutex_lock(&st->pmu);
     while ((st->segn == (int)(sizeof st->segq / sizeof st->segq[0]) || st->segn > st->par) && !st->cancel) pthread_cond_wait(&st->pcv, &st->pmu);
-    if (st->cancel) { pthread_mutex_unlock(&st->pmu); free(sg->buf); free(sg); return; }
+    if (st->cancel) { pthread_mutex_unlock(&st->pmu); if (!sg->borrowed) free(sg->buf); free(sg); return; }
     st->segq[st->segn++] = sg;
     pthread_cond_broadcast(&st->pcv);
     pthread_mutex_unlock(&st->pmu);
@@ -315,20 +315,57 @@ static void *sd_decode_thread(void *arg)
     int got;
     skzp zp;
     const int own = !getenv("SK_ZLIB") && skzp_open_threads(&zp, st->path, st->gz_threads) == SKZ_OK;
-    if (st->par > 1 && own) {
+    /* plain text is parsed straight out of the mapped file (zlib's pass-through mode copies every byte once more: 4.9 GB/s of
+     * FASTA against what the parser itself does); anything that cannot be mapped, or SK_ZLIB=1: gzread */
+    const unsigned char *map = NULL;
+    size_t mlen = 0;
+    if (!own && !getenv("SK_ZLIB")) {
+        const int fd = open(st->path, O_RDONLY);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { map = (const unsigned char *)m; mlen = (size_t)sb.st_size; madvise(m, mlen, MADV_SEQUENTIAL); }
+        }
+        if (fd >= 0) close(fd);
+        if (map && mlen >= 2 && map[0] == 0x1f && map[1] == 0x8b) { munmap((void *)map, mlen); map = NULL; }   /* (gzip after all: zlib) */
+    }
+    if (st->par > 1 && (own || map)) {
         /* a .gz file inflated by several threads delivers text faster than one thread parses it (measured, 3 Gbase of FASTA,
-         * 16 inflate threads: waiting for the decode side 0.73 s with one parser, 0.47 s with four); a plain file does not
-         * (one parser keeps up with the read; cutting it was slower: 0.62 against 0.44 s) and is parsed here.
-         * Cut the text into segments for the parser threads: */
+         * 16 inflate threads: waiting for the decode side 0.73 s with one parser, 0.47 s with four), and so does a mapped
+         * plain file when many strains wait for it (32 strains x 10 Gbase of FASTA: the one parser thread, 3 GB/s, was what the
+         * whole pass waited for).  Cut the text into segments for the parser threads -- copied out of the inflate stream, or
+         * simply pointing into the map: */
         pthread_t wk[8];
         int nw = 0, i;
         uint64_t seq = 0;
         size_t scan_from;
         const size_t want = st->chunk_bytes;              /* about a chunk's worth of text per segment */
-        sd_seg *sg = (sd_seg *)calloc(1, sizeof *sg);
+        sd_seg *sg = NULL;
+        for (i = 0; i < st->par && i < 8; i++) if (pthread_create(&wk[nw], NULL, sd_parse_worker, st) == 0) nw++;
+        if (map) {
+            size_t at = 0;
+            while (at < mlen && nw) {
+                size_t cut = mlen;
+                int over;
+                pthread_mutex_lock(&st->pmu);
+                over = st->cancel_segments;
+                pthread_mutex_unlock(&st->pmu);
+                if (st->cancel || over) break;
+                if (mlen - at > want + TAIL) cut = at + (size_t)parser_guess_start(map + at, mlen - at, want, 1);
+                sg = (sd_seg *)calloc(1, sizeof *sg);
+                sg->buf = (unsigned char *)map + at;
+                sg->n = cut - at;
+                sg->borrowed = 1;
+                sg->seq = seq++;
+                sg->is_last = cut == mlen;
+                sd_seg_dispatch(st, sg);
+                at = cut;
+            }
+            sg = NULL;
+        } else {
+        sg = (sd_seg *)calloc(1, sizeof *sg);
         sg->cap = want + (want >> 2) + BLK;
         sg->buf = (unsigned char *)malloc(sg->cap);
-        for (i = 0; i < st->par && i < 8; i++) if (pthread_create(&wk[nw], NULL, sd_parse_worker, st) == 0) nw++;
         scan_from = want;
         for (;;) {
             const unsigned char *data = NULL;
@@ -367,6 +404,7 @@ static void *sd_decode_thread(void *arg)
         sg->seq = seq++;
         sg->is_last = 1;
         if (nw) sd_seg_dispatch(st, sg); else { free(sg->buf); free(sg); }
+        }
         pthread_mutex_lock(&st->pmu);
         st->seg_done = 1;
         pthread_cond_broadcast(&st->pcv);
@@ -392,20 +430,6 @@ static void *sd_decode_thread(void *arg)
             size_t n;
             while (ps.state != P_STOP && !st->cancel && (n = skzp_next(&zp, &data)) > 0) parser_feed(&ps, data, n);
         } else {
-            /* plain text: parsed straight out of the mapped file (zlib's pass-through mode copies every byte once more:
-             * 4.9 GB/s of FASTA against what the parser itself does); anything that cannot be mapped, or SK_ZLIB=1: gzread */
-            const unsigned char *map = NULL;
-            size_t mlen = 0;
-            if (!getenv("SK_ZLIB")) {
-                const int fd = open(st->path, O_RDONLY);
-                struct stat sb;
-                if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
-                    void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-                    if (m != MAP_FAILED) { map = (const unsigned char *)m; mlen = (size_t)sb.st_size; madvise(m, mlen, MADV_SEQUENTIAL); }
-                }
-                if (fd >= 0) close(fd);
-                if (map && mlen >= 2 && map[0] == 0x1f && map[1] == 0x8b) { munmap((void *)map, mlen); map = NULL; }   /* (gzip after all: zlib) */
-            }
             if (map) {
                 size_t at = 0;
                 while (ps.state != P_STOP && !st->cancel && at < mlen) {
@@ -413,7 +437,6 @@ static void *sd_decode_thread(void *arg)
                     parser_feed(&ps, map + at, n);
                     at += n;
                 }
-                munmap((void *)map, mlen);
             } else
                 while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
         }
@@ -427,6 +450,7 @@ static void *sd_decode_thread(void *arg)
         parser_free(&ps);
     }
     if (own) skzp_close(&zp);
+    if (map) munmap((void *)map, mlen);
     free(blk);
     return NULL;
 }

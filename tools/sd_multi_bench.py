@@ -60,6 +60,15 @@ exe = os.path.join(REPO, "strainer2_amd", "bin", "strain_detect")
 t = time.time()
 subprocess.run([exe, "-S", os.path.join(work, "strains.txt"), "-b", os.path.join(work, "reads.fa"), "-t", "SE"], check=True)
 t_multi = time.time() - t
+t_members = None
+if os.environ.get("ALSO_NO_UNION"):                  # the same pass strain by strain (one launch per strain and batch)
+    import hashlib
+    md5 = [hashlib.md5(gzip.open(f"{work}/multi{s}.gz").read()).hexdigest() for s in range(NSTRAINS)]
+    t = time.time()
+    subprocess.run([exe, "-S", os.path.join(work, "strains.txt"), "-b", os.path.join(work, "reads.fa"), "-t", "SE"], check=True,
+                   env=dict(os.environ, SK_SD_NO_UNION="1"))
+    t_members = time.time() - t
+    assert md5 == [hashlib.md5(gzip.open(f"{work}/multi{s}.gz").read()).hexdigest() for s in range(NSTRAINS)], "union and member-by-member outputs differ"
 t_sep = []
 same = True
 for s in range(SEPARATE):
@@ -73,6 +82,7 @@ bases = READS * 150
 print(json.dumps({
     "workload": f"{NSTRAINS} strains x {STRAIN_BP} bp, 1 % informative; {READS} x 150 bp SE reads ({bases / 1e9:.2f} Gbase), 2 % from the strains",
     "one_pass_all_strains_s": round(t_multi, 2),
+    "one_pass_strain_by_strain_s": round(t_members, 2) if t_members else None,
     "separate_runs_timed": SEPARATE,
     "separate_run_mean_s": round(float(np.mean(t_sep)), 2) if t_sep else None,
     "separate_runs_total_s_extrapolated": round(float(np.mean(t_sep)) * NSTRAINS, 2) if t_sep else None,
