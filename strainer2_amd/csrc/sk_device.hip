@@ -1399,9 +1399,13 @@ __global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint
 #define SK_STAGE_BYTES   (64ull << 20)
 #define SK_NSTAGE        2
 
+struct sk_pin { void *p; size_t n; bool used; };
+
 struct sk_ctx {
     int          device;
     hipStream_t  stream;
+    std::vector<sk_pin> pins;         // page-locked host buffers of sk_pinned_alloc, kept for re-use
+    pthread_mutex_t pin_mu;
     // table
     sk_u4       *d_keys;              // the slot array (name kept: "is a table loaded" checks)
     uint32_t     slots_log2;
@@ -1511,6 +1515,7 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     sk_ctx *c = new (std::nothrow) sk_ctx();
     if (!c) return SK_E_NOMEM;
     c->device = device;
+    pthread_mutex_init(&c->pin_mu, NULL);
     c->table_load_pct = 50;
     c->grid_kib = -1;
     c->diff_col = -1;
@@ -1572,6 +1577,8 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
     hipFree(c->t_tally); hipFree(c->t_hits); hipFree(c->t_compact);
     hipFree(c->p_bins); hipFree(c->p_binn); hipFree(c->p_cand);
     if (c->h_tally) hipHostFree(c->h_tally);
+    for (sk_pin &q : c->pins) { hipHostUnregister(q.p); free(q.p); }
+    pthread_mutex_destroy(&c->pin_mu);
     hipFree(c->d_flags);
     hipFree(c->d_oddlist);
     hipStreamDestroy(c->stream);
@@ -2407,21 +2414,40 @@ extern "C" int sk_scan_stream(sk_ctx *c, const uint8_t *stream, uint64_t nbytes,
 }
 
 // ---- zero-copy variant for callers that fill PINNED host buffers themselves ---------------------
+// Page-locked buffers are kept by the context and handed out again: locking pages is slow and serialised in the driver
+// (measured on the MI355X box, tools/probes/pin_probe.hip: hipHostMalloc 6.1 ms per 32 MiB plus 3.7 ms to free it, 32 buffers
+// from 16 threads 189 ms -- a list scan with 16 decode threads spent 0.3 s on its buffers, every call); registering ordinary
+// memory costs 2.7 ms per 32 MiB, and a buffer given back stays registered until the context goes.  May be called from
+// several threads at once.
 extern "C" int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t nbytes)
 {
     if (!c || !p) return SK_E_ARG;
-    SK_HIP(c, hipSetDevice(c->device));
-    SK_HIP(c, hipHostMalloc(p, nbytes ? nbytes : 16, hipHostMallocDefault));
+    const size_t want = (size_t)((nbytes ? nbytes : 16) + 4095u) & ~(size_t)4095u;
+    pthread_mutex_lock(&c->pin_mu);
+    for (sk_pin &q : c->pins)
+        if (!q.used && q.n == want) { q.used = true; *p = q.p; pthread_mutex_unlock(&c->pin_mu); return SK_OK; }
+    pthread_mutex_unlock(&c->pin_mu);
+    if (hipSetDevice(c->device) != hipSuccess) return SK_E_HIP;
+    void *m = NULL;
+    if (posix_memalign(&m, 4096, want) != 0) return SK_E_NOMEM;
+    if (hipHostRegister(m, want, hipHostRegisterDefault) != hipSuccess) { free(m); return SK_E_NOMEM; }
+    pthread_mutex_lock(&c->pin_mu);
+    c->pins.push_back((sk_pin){m, want, true});
+    pthread_mutex_unlock(&c->pin_mu);
+    *p = m;
     return SK_OK;
 }
 
 extern "C" int sk_pinned_free(sk_ctx *c, void *p)
 {
     if (!c) return SK_E_ARG;
-    SK_HIP(c, hipSetDevice(c->device));
-    SK_HIP(c, hipStreamSynchronize(c->stream));
-    SK_HIP(c, hipHostFree(p));
-    return SK_OK;
+    if (!p) return SK_OK;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return SK_E_HIP;   // (nothing reads it any more)
+    int rc = SK_E_ARG;
+    pthread_mutex_lock(&c->pin_mu);
+    for (sk_pin &q : c->pins) if (q.p == p && q.used) { q.used = false; rc = SK_OK; break; }
+    pthread_mutex_unlock(&c->pin_mu);
+    return rc;
 }
 
 // Like sk_scan_stream, but `pinned` (from sk_pinned_alloc, at most 64 MiB - 64 bytes) is DMA-read in

@@ -144,7 +144,7 @@ static int writer_flush(stream_writer *w)
 {
     if (w->len && !w->rc) {
         w->rc = w->sink(w->user, w->buf, w->len);
-        if (!w->rc && w->next_buf) w->buf = w->next_buf(w->user);
+        if (!w->rc && w->next_buf) w->buf = NULL;    /* the next buffer is asked for when a record needs it: not after the last flush */
     }
     w->len = 0;
     return w->rc;
@@ -156,9 +156,11 @@ static int writer_record(void *user, char *seq, size_t len)
     size_t off = 0;
     w->bases += len;
     if (len < SK_K) return 0;                        /* src/genome_compare.c:204: no window fits */
+    if (w->rc) return w->rc;
     while (off < len) {
         uint64_t room, take;
         if (w->cap - w->len < 2 * SK_K + 2 && writer_flush(w)) return w->rc;
+        if (!w->buf && (!w->next_buf || !(w->buf = w->next_buf(w->user)))) return w->rc = SK_E_NOMEM;
         room = w->cap - w->len - 1;
         take = len - off;
         if (take > room) take = room;
@@ -685,7 +687,14 @@ typedef struct {
     int        used[2], cur;
 } scan_worker;
 
-#define POOL_CHUNK (32u << 20)
+/* size of a worker's chunk buffer: SK_CHUNK_BYTES (4096 .. 63 MiB; tests use small ones: many flushes per file), default 32 MiB */
+static uint64_t pool_chunk_bytes(void)
+{
+    const char *e = getenv("SK_CHUNK_BYTES");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 4096 && v <= (63ll << 20) ? (uint64_t)v : 32ull << 20;
+}
+#define POOL_CHUNK pool_chunk_bytes()
 
 static int worker_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
 {
@@ -698,24 +707,27 @@ static int worker_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
     return rc;
 }
 
+/* the buffers come from the context's store of page-locked memory (kept from call to call) when they are first
+ * needed: a worker that finds the queue empty takes none, an item that fits one buffer never takes the second */
+static uint8_t *worker_buf(scan_worker *w, int i)
+{
+    if (!w->pinned[i] && sk_pinned_alloc(w->pool->ctx, (void **)&w->pinned[i], POOL_CHUNK) != SK_OK) w->pinned[i] = NULL;
+    return w->pinned[i];
+}
+
 static uint8_t *worker_next_buf(void *user)
 {
     scan_worker *w = (scan_worker *)user;
     w->cur ^= 1;
     if (w->used[w->cur]) sk_ticket_wait(w->pool->ctx, w->ticket[w->cur]);
-    return w->pinned[w->cur];
+    return worker_buf(w, w->cur);
 }
 
 static int worker_init(scan_worker *w, scan_pool *p)
 {
-    int rc;
     memset(w, 0, sizeof *w);
     w->pool = p;
-    pthread_mutex_lock(&p->submit_mu);
-    rc = sk_pinned_alloc(p->ctx, (void **)&w->pinned[0], POOL_CHUNK);
-    if (rc == SK_OK) rc = sk_pinned_alloc(p->ctx, (void **)&w->pinned[1], POOL_CHUNK);
-    pthread_mutex_unlock(&p->submit_mu);
-    return rc;
+    return SK_OK;
 }
 
 static void worker_done(scan_worker *w)
@@ -771,7 +783,7 @@ static int64_t worker_item(scan_worker *w, const scan_item *it, uint64_t *bases)
     int64_t nrec = 0;
     int rc;
     memset(&sw, 0, sizeof sw);
-    sw.buf = w->pinned[w->cur];
+    sw.buf = NULL;                                   /* (taken through next_buf by the first record: the other buffer may still be read) */
     sw.cap = POOL_CHUNK;
     sw.sink = worker_sink;
     sw.user = w;

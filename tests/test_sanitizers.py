@@ -199,7 +199,7 @@ def test_kmer_scrub_count_host_logic_under_sanitizers(ks_host_exe, golden, name,
     table print) under ASan+UBSan and TSan with the CPU test double, against the reference's output"""
     d = os.path.join(golden, "cases", name)
     meta = json.load(open(os.path.join(d, "case.json")))
-    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4")
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_CHUNK_BYTES="4096")     # (many chunk flushes per file, both buffers in use)
     p = subprocess.run([ks_host_exe] + meta["argv"], cwd=d, env=env, capture_output=True)
     for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
         assert bad not in p.stderr, p.stderr.decode()[-3000:]
@@ -229,11 +229,12 @@ def test_kmer_scrub_count_thread_pool_under_sanitizers(ks_host_exe, tmp_path):
     if not os.path.exists(oracle):
         subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "kso_oracle"], check=True, stdout=subprocess.DEVNULL)
     want = subprocess.run([oracle] + argv, cwd=tmp_path, capture_output=True)
-    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4")
-    p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=env, capture_output=True)
-    for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
-        assert bad not in p.stderr, p.stderr.decode()[-3000:]
-    assert (p.returncode, p.stdout) == (want.returncode, want.stdout) and want.returncode == 0
+    for chunk in ("4096", "33554432"):                       # chunks of a few records (many flushes, both buffers in turn) and of a whole file
+        env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_CHUNK_BYTES=chunk)
+        p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=env, capture_output=True)
+        for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+            assert bad not in p.stderr, p.stderr.decode()[-3000:]
+        assert (p.returncode, p.stdout) == (want.returncode, want.stdout) and want.returncode == 0
 
 
 @pytest.mark.parametrize("name", ["batch", "cli_pe", "cli_pei"])
