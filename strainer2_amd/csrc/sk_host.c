@@ -765,6 +765,10 @@ static int parse_range(const scan_item *it, rec_fn fn, void *user, int64_t *nrec
     for (i = sa; i < sb && ps.state != P_STOP; i += BLK) parser_feed(&ps, t + i, (size_t)(sb - i < BLK ? sb - i : BLK));
     if (ps.state != P_STOP && sb < it->size && sb > sa)
         ok = parser_between_records(&ps) && (t[sb] == 0x3e || t[sb] == 0x40);
+    /* a FASTQ record whose quality does not match its sequence ends the FILE for the reference (src/kseq.h:205-209 returns -2,
+     * src/genome_compare.c:203 stops reading): the pieces behind this one must not count, and some may have been counted
+     * already -- so the run fails rather than report more than the reference would */
+    if (ps.state == P_STOP && !ps.sink_rc && ps.end_kind == SKP_END_TRUNC && sb < it->size) ok = 0;
     if (ps.state != P_STOP) parser_eof(&ps);
     if (nrecords) *nrecords = ps.nrecords;
     {

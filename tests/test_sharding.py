@@ -109,3 +109,29 @@ def test_a_file_that_cannot_be_cut_safely_fails_the_run(exe, tmp_path):
     env["SK_NO_SPLIT"] = "1"
     p = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "2"], env=env, capture_output=True, timeout=300)
     assert p.returncode == 0 and p.stdout.startswith(b"OK")
+
+
+def test_a_record_that_ends_the_file_for_the_reference_is_not_read_past(exe, tmp_path):
+    """a FASTQ record in the middle of a big file whose quality is longer than its sequence: the reference's reader returns -2
+    there and the rest of the file is never read (src/kseq.h:205-209, src/genome_compare.c:203).  Cut into pieces, the later
+    pieces would be counted all the same -- so the scan fails (SK_E_SPLIT) instead; uncut it stops where the reference
+    stops: the same counts as the file's part before that record."""
+    rng = random.Random(11)
+    strain = _synth.rand_dna(rng, 20000)
+    open(tmp_path / "strain.fa", "wb").write(b">s\n" + strain + b"\n")
+    head = _fastq(rng, strain, 300)
+    bad = b"@bad\n" + strain[100:250] + b"\n+\n" + b"I" * 170 + b"\n"
+    tail = _fastq(rng, strain, 300)
+    open(tmp_path / "whole.fq", "wb").write(head + bad + tail)
+    open(tmp_path / "head.fq", "wb").write(head)
+    open(tmp_path / "list.txt", "w").write(str(tmp_path / "whole.fq") + "\n")
+    open(tmp_path / "list_head.txt", "w").write(str(tmp_path / "head.fq") + "\n")
+    env = dict(os.environ, SK_THREADS="3", ASAN_OPTIONS="detect_leaks=0", SK_SPLIT_BYTES="8000")
+    p = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "2"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 1 and b"failed: -9" in p.stdout and b"could not be cut at record boundaries" in p.stderr
+    env.pop("SK_SPLIT_BYTES")
+    env["SK_NO_SPLIT"] = "1"
+    p = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "2"], env=env, capture_output=True, timeout=300)
+    q = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list_head.txt"), "2"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0 and q.returncode == 0
+    assert p.stdout.split()[:2] == q.stdout.split()[:2] and p.stdout.startswith(b"OK")
