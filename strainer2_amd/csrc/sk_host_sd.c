@@ -71,7 +71,7 @@ typedef struct {
     sk_hit     *hitbuf; uint64_t hitcap;   /* landing area of the hit log */
     uint32_t   *tallybuf; uint32_t tallycap;
     uint64_t    u_nsp, u_nh;               /* union table: this strain's share of a batch's results, dealt out by sd_tally_chunk */
-    int         hc_out, job_rc;            /* results of this strain's part of a pool job */
+    int         job_rc;                    /* result of this strain's part of a pool job */
 } sd_prog;
 
 /* ---------------------------------------------------------------------------------------------
@@ -84,10 +84,13 @@ typedef struct sd_chunk {
     uint32_t *pstart, *prec; uint32_t np, pcap;   /* those records: offset in buf, index in len[] */
     uint64_t *len; uint32_t nrec, rcap;      /* every record, length as the reference sees it */
     int       last, end_kind; size_t end_len;/* last chunk of the file: how the parser ended */
-    /* per strain, filled by sd_tally_chunk: tallies per record and the informative rows per record (CSR) */
-    uint32_t **hits, **inf, **hbeg, **rows;
+    /* per strain, filled by sd_tally_chunk: the records that hit the strain at all, ascending -- their tallies and their
+     * informative rows (CSR).  Nothing here is proportional to records x strains: against a metagenome nearly every
+     * (read, strain) pair is a blank */
+    struct sd_sp *sp;
     uint32_t  nstrains;
 } sd_chunk;
+typedef struct sd_sp { uint32_t n; uint32_t *rec, *all, *inf, *hbeg /* n + 1 */, *rows; } sd_sp;
 
 typedef struct {
     const char *path;
@@ -149,8 +152,8 @@ static void chunk_free(sd_chunk *c)
 {
     uint32_t s;
     if (!c) return;
-    for (s = 0; s < c->nstrains; s++) { free(c->hits[s]); free(c->inf[s]); free(c->hbeg[s]); free(c->rows[s]); }
-    free(c->hits); free(c->inf); free(c->hbeg); free(c->rows);
+    for (s = 0; c->sp && s < c->nstrains; s++) { free(c->sp[s].rec); free(c->sp[s].rows); }   /* (rec, all, inf, hbeg: one block) */
+    free(c->sp);
     if (c->pinned) sd_pin_put(c->buf); else free(c->buf);
     free(c->pstart); free(c->prec); free(c->len);
     free(c);
@@ -341,7 +344,11 @@ static void *sd_decode_thread(void *arg)
         size_t scan_from;
         const size_t want = st->chunk_bytes;              /* about a chunk's worth of text per segment */
         sd_seg *sg = NULL;
-        for (i = 0; i < st->par && i < 8; i++) if (pthread_create(&wk[nw], NULL, sd_parse_worker, st) == 0) nw++;
+        {   /* a mapped file costs nothing to read: with a whole thread budget behind one file, eight parsers (an inflating
+             * file keeps its four: the inflate threads need the CPUs) */
+            const int npar = map && !getenv("SK_PARSE_THREADS") && st->gz_threads >= 16 ? 8 : st->par;
+            for (i = 0; i < npar && i < 8; i++) if (pthread_create(&wk[nw], NULL, sd_parse_worker, st) == 0) nw++;
+        }
         if (map) {
             size_t at = 0;
             while (at < mlen && nw) {
@@ -610,6 +617,12 @@ static void pool_run(sd_pool *pl, uint32_t ns, sd_job_fn fn, void *arg)
     pthread_mutex_unlock(&pl->mu);
 }
 
+static int tally_rec_cmp(const void *a, const void *b)
+{
+    const sk_tally_rec *x = (const sk_tally_rec *)a, *y = (const sk_tally_rec *)b;
+    return x->rec < y->rec ? -1 : x->rec > y->rec;
+}
+
 static int hit_cmp(const void *a, const void *b)
 {
     const sk_hit *x = (const sk_hit *)a, *y = (const sk_hit *)b;
@@ -627,12 +640,11 @@ static void tally_one(void *arg, uint32_t s)
     sd_prog *p = &j->p[s];
     sd_chunk *c = j->c;
     uint64_t nh = 0, h = 0;
-    uint32_t n = 0, r, k;
+    uint32_t n = 0, k;
+    sd_sp *sp = &c->sp[s];
     int rc;
     p->job_rc = SK_OK;
-    c->hits[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
-    c->inf[s] = (uint32_t *)calloc((size_t)c->nrec + 1, sizeof(uint32_t));
-    c->hbeg[s] = (uint32_t *)calloc((size_t)c->nrec + 2, sizeof(uint32_t));
+    memset(sp, 0, sizeof *sp);
     if (c->np == 0) return;
     /* only the pieces that hit this strain at all come back (compacted on the device): with many strains against one
      * metagenome nearly every (read, strain) pair is a blank */
@@ -652,19 +664,30 @@ static void tally_one(void *arg, uint32_t s)
             (rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
     }
     }
-    for (e = 0; e < nsp; e++) {                           /* (a record cut into pieces: the pieces' windows add up) */
-        const uint32_t rec = c->prec[sparse[e].rec];
-        c->hits[s][rec] += sparse[e].all;
-        c->inf[s][rec] += sparse[e].inf;
-    }
+    /* in the order of the pieces (they come back unordered): a sort when they are few, a sweep over a piece-indexed
+     * array when most pieces hit (one strain, reads from that strain) */
+    if (nsp * 8 > c->np) {
+        uint32_t *by = (uint32_t *)calloc((size_t)c->np, 2 * sizeof(uint32_t));
+        uint64_t w = 0;
+        for (e = 0; e < nsp; e++) { by[2 * (size_t)sparse[e].rec] = sparse[e].all; by[2 * (size_t)sparse[e].rec + 1] = sparse[e].inf; }
+        for (k = 0; k < c->np; k++) if (by[2 * (size_t)k]) { sparse[w].rec = k; sparse[w].all = by[2 * (size_t)k]; sparse[w].inf = by[2 * (size_t)k + 1]; w++; }
+        free(by);
+    } else qsort(sparse, (size_t)nsp, sizeof *sparse, tally_rec_cmp);
     qsort(p->hitbuf, (size_t)nh, sizeof(sk_hit), hit_cmp);
-    c->rows[s] = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
-    for (k = 0, r = 0; k < c->np; k++) {
-        const uint32_t rec = c->prec[k], end = k + 1 < c->np ? c->pstart[k + 1] : 0xFFFFFFFFu;
-        for (; r <= rec; r++) c->hbeg[s][r] = n;          /* records without a piece own an empty range */
-        while (h < nh && p->hitbuf[h].pos < end) c->rows[s][n++] = p->hitbuf[h++].row;
+    sp->rec = (uint32_t *)malloc(((size_t)nsp * 4 + 2) * sizeof(uint32_t));
+    sp->all = sp->rec + nsp; sp->inf = sp->all + nsp; sp->hbeg = sp->inf + nsp;
+    sp->rows = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
+    for (e = 0; e < nsp; ) {                              /* (a record cut into pieces: the pieces' windows add up) */
+        const uint32_t rec = c->prec[sparse[e].rec];
+        uint32_t last = sparse[e].rec, all = 0, inf = 0, end;
+        while (e < nsp && c->prec[sparse[e].rec] == rec) { all += sparse[e].all; inf += sparse[e].inf; last = sparse[e].rec; e++; }
+        while (last + 1 < c->np && c->prec[last + 1] == rec) last++;              /* the record's last piece: its rows end where the next record begins */
+        end = last + 1 < c->np ? c->pstart[last + 1] : 0xFFFFFFFFu;
+        sp->rec[sp->n] = rec; sp->all[sp->n] = all; sp->inf[sp->n] = inf; sp->hbeg[sp->n] = n;
+        while (h < nh && p->hitbuf[h].pos < end) sp->rows[n++] = p->hitbuf[h++].row;
+        sp->n++;
     }
-    for (; r <= c->nrec; r++) c->hbeg[s][r] = n;
+    sp->hbeg[sp->n] = n;
 }
 
 /* Many strains on one device: one union table per group of up to SK_UNION_MAX strains (sk_union_*), so that a batch is
@@ -769,10 +792,7 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *poo
     double t0 = now_s(), t1;
     const int use_union = sd_un.n && c->blen < (1u << 26);
     c->nstrains = ns;
-    c->hits = (uint32_t **)calloc(ns, sizeof *c->hits);
-    c->inf = (uint32_t **)calloc(ns, sizeof *c->inf);
-    c->hbeg = (uint32_t **)calloc(ns, sizeof *c->hbeg);
-    c->rows = (uint32_t **)calloc(ns, sizeof *c->rows);
+    c->sp = (sd_sp *)calloc(ns, sizeof *c->sp);
     if (c->np) {
         if ((rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
         t1 = now_s(); t_fill += t1 - t0; t0 = t1;
@@ -895,52 +915,81 @@ static void emit_trailer(sd_prog *p, const char *f1, const char *what, long long
 /* One strain over a run of n read pairs whose records sit in the current chunks: PE1 reads are records
  * a0, a0 + astep, ... of chunk ca; their mates (cb != NULL) records b0, b0 + astep, ... of chunk cb.
  * This is the body of the reference's read loop (src/strain_detect.c:443-626) for that strain. */
-static void sd_replay_run(sd_prog *p, uint32_t s, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb, uint32_t b0,
-                          uint32_t astep, uint32_t n, int *have_copy_io)
+static uint32_t sp_lower(const sd_sp *q, uint32_t rec)
 {
-    const uint32_t *ah = ca->hits[s], *ai = ca->inf[s], *ab = ca->hbeg[s];
-    const uint32_t *bh = cb ? cb->hits[s] : NULL, *bi = cb ? cb->inf[s] : NULL, *bb = cb ? cb->hbeg[s] : NULL;
-    int have_copy = *have_copy_io;
-    uint32_t j;
-    for (j = 0; j < n; j++) {
-        const uint32_t ra = a0 + j * astep, rb = b0 + j * astep;
+    uint32_t lo = 0, hi = q->n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (q->rec[mid] < rec) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* first_valid: the first pair of the run whose PE1 read has k bases (n if none) -- from there on the copy of "the PE1 read
+ * last seen" exists (have_copy; the same for every strain).
+ * Only the pairs that matter are walked: a pair with a hit, and the pairs behind it for as long as the carried tallies are
+ * not all zero (a read shorter than k refreshes nothing, :444, so it re-emits what the read before it left).  A pair without
+ * hits met with all-zero tallies leaves them all zero and emits nothing: skipped. */
+static void sd_replay_run(sd_prog *p, uint32_t s, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb, uint32_t b0,
+                          uint32_t astep, uint32_t n, int have_copy_in, uint32_t first_valid)
+{
+    const sd_sp *A = &ca->sp[s], *B = cb ? &cb->sp[s] : NULL;
+    const uint64_t a_end = (uint64_t)a0 + (uint64_t)n * astep, b_end = (uint64_t)b0 + (uint64_t)n * astep;
+    uint32_t ia = sp_lower(A, a0), ib = B ? sp_lower(B, b0) : 0, j = 0;
+    while (j < n) {
+        uint32_t ra, rb;
         int b_valid = 0;
+        if (!(p->h1 | p->i1 | p->h2 | p->i2)) {                 /* nothing carried: on to the next pair with a hit */
+            uint32_t ja = n, jb = n;
+            while (ia < A->n && A->rec[ia] < (uint64_t)a0 + (uint64_t)j * astep) ia++;       /* (behind pair j: done with) */
+            while (B && ib < B->n && B->rec[ib] < (uint64_t)b0 + (uint64_t)j * astep) ib++;
+            for (; ia < A->n && A->rec[ia] < a_end; ia++) { const uint32_t off = A->rec[ia] - a0; if (off % astep == 0) { ja = off / astep; break; } }
+            if (B) for (; ib < B->n && B->rec[ib] < b_end; ib++) { const uint32_t off = B->rec[ib] - b0; if (off % astep == 0) { jb = off / astep; break; } }
+            if ((ja < jb ? ja : jb) > j) j = ja < jb ? ja : jb;
+            if (j >= n) break;
+        }
+        ra = a0 + j * astep; rb = b0 + j * astep;
         if (ca->len[ra] >= SK_K) {                       /* a read shorter than k refreshes nothing (:444) */
-            const uint32_t nrows = ab[ra + 1] - ab[ra];
-            p->h1 = (int)ah[ra];
-            p->i1 = (int)ai[ra];
-            have_copy = 1;
-            if (nrows) {
-                if (nrows > p->copy_cap) { p->copy_cap = nrows * 2 + 16; p->copy_rows = (uint32_t *)realloc(p->copy_rows, (size_t)p->copy_cap * 4); }
-                memcpy(p->copy_rows, ca->rows[s] + ab[ra], (size_t)nrows * 4);
-            }
+            uint32_t nrows = 0;
+            while (ia < A->n && A->rec[ia] < ra) ia++;
+            if (ia < A->n && A->rec[ia] == ra) {
+                p->h1 = (int)A->all[ia]; p->i1 = (int)A->inf[ia];
+                nrows = A->hbeg[ia + 1] - A->hbeg[ia];
+                if (nrows) {
+                    if (nrows > p->copy_cap) { p->copy_cap = nrows * 2 + 16; p->copy_rows = (uint32_t *)realloc(p->copy_rows, (size_t)p->copy_cap * 4); }
+                    memcpy(p->copy_rows, A->rows + A->hbeg[ia], (size_t)nrows * 4);
+                }
+            } else p->h1 = p->i1 = 0;
             p->copy_n = nrows;
         }
-        if (cb && cb->len[rb] >= SK_K) { p->h2 = (int)bh[rb]; p->i2 = (int)bi[rb]; b_valid = 1; }
-        if (p->h1 + p->h2 >= 1 && p->i1 + p->i2 >= 1) {
-            if (have_copy) emit_rows(p, p->copy_rows, p->copy_n, f1);
-            if (b_valid) emit_rows(p, cb->rows[s] + bb[rb], bb[rb + 1] - bb[rb], f1);
+        if (cb && cb->len[rb] >= SK_K) {
+            b_valid = 1;
+            while (ib < B->n && B->rec[ib] < rb) ib++;
+            if (ib < B->n && B->rec[ib] == rb) { p->h2 = (int)B->all[ib]; p->i2 = (int)B->inf[ib]; }
+            else { p->h2 = p->i2 = 0; b_valid = 2; }       /* (valid, no rows) */
         }
+        if (p->h1 + p->h2 >= 1 && p->i1 + p->i2 >= 1) {
+            if (have_copy_in || first_valid <= j) emit_rows(p, p->copy_rows, p->copy_n, f1);
+            if (b_valid == 1) emit_rows(p, B->rows + B->hbeg[ib], B->hbeg[ib + 1] - B->hbeg[ib], f1);
+        }
+        j++;
     }
-    *have_copy_io = have_copy;
 }
 
 /* replay one run for every strain; returns the (strain-independent) have_copy afterwards */
-typedef struct { sd_prog *p; const char *f1; const sd_chunk *ca, *cb; uint32_t a0, b0, astep, n; int have_copy; } sd_replay_job;
+typedef struct { sd_prog *p; const char *f1; const sd_chunk *ca, *cb; uint32_t a0, b0, astep, n, first_valid; int have_copy; } sd_replay_job;
 static void replay_one(void *arg, uint32_t s)
 {
     sd_replay_job *j = (sd_replay_job *)arg;
-    int hc = j->have_copy;
-    sd_replay_run(&j->p[s], s, j->f1, j->ca, j->a0, j->cb, j->b0, j->astep, j->n, &hc);
-    j->p[s].hc_out = hc;
+    sd_replay_run(&j->p[s], s, j->f1, j->ca, j->a0, j->cb, j->b0, j->astep, j->n, j->have_copy, j->first_valid);
 }
 static int pool_replay(sd_pool *pl, sd_prog *p, uint32_t ns, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb,
                        uint32_t b0, uint32_t astep, uint32_t n, int have_copy)
 {
     sd_replay_job j;
+    uint32_t k;
     j.p = p; j.f1 = f1; j.ca = ca; j.cb = cb; j.a0 = a0; j.b0 = b0; j.astep = astep; j.n = n; j.have_copy = have_copy;
+    for (k = 0; k < n && ca->len[a0 + k * astep] < SK_K; k++) { }
+    j.first_valid = k;
     pool_run(n < 2 ? NULL : pl, ns, replay_one, &j);
-    return ns ? p[0].hc_out : have_copy;
+    return have_copy || k < n;
 }
 
 /* one metagenome (pair), for every strain at once.  The read lengths -- hence which read refreshes which
