@@ -72,18 +72,21 @@ static uint64_t skzq_stat_direct, skzq_stat_gap, skzq_stat_again;
 
 /* The big buffers come straight from mmap and stay with their worker / slot for the whole member: handing tens of
  * MB back and forth through malloc makes glibc trim and regrow its heap on every segment (measured: 3x slower). */
+/* (sizes in whole pages, as the kernel maps them: ThreadSanitizer forgets a range's history only for the bytes munmap names,
+ * and the tail of a last page that comes back in a later mapping then reads as a race with a thread long gone) */
+#define SKZQ_PAGES(b) (((size_t)(b) + 4095u) & ~(size_t)4095u)
 static void *skzq_big_alloc(size_t bytes)
 {
-    void *q = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    void *q = mmap(NULL, SKZQ_PAGES(bytes), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     return q == MAP_FAILED ? NULL : q;
 }
-static void skzq_big_free(void *q, size_t bytes) { if (q) munmap(q, bytes); }
+static void skzq_big_free(void *q, size_t bytes) { if (q) munmap(q, SKZQ_PAGES(bytes)); }
 /* contents kept; NULL (and the old block untouched) when it cannot grow */
 static void *skzq_big_grow(void *q, size_t old_bytes, size_t new_bytes)
 {
     void *r;
     if (!q) return skzq_big_alloc(new_bytes);
-    r = mremap(q, old_bytes, new_bytes, MREMAP_MAYMOVE);
+    r = mremap(q, SKZQ_PAGES(old_bytes), SKZQ_PAGES(new_bytes), MREMAP_MAYMOVE);
     return r == MAP_FAILED ? NULL : r;
 }
 

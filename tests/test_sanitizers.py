@@ -351,3 +351,65 @@ def test_strain_detect_parser_threads_give_the_serial_result(sd_host_exe, tmp_pa
     assert a == b and a.count(b"\n") > 500
     ora = _oracle.run_sd_oracle_cli(base + ["-o", str(tmp_path / "ora.gz")], str(tmp_path))
     assert ora.returncode == 0 and gzip.open(tmp_path / "ora.gz", "rb").read() == a
+
+
+def test_kmer_scrub_count_one_gz_parsed_by_several_threads(ks_host_exe, tmp_path):
+    """one .gz list entry inflated by three threads (SK_GZ_THREADS) whose text is cut into segments at guessed record starts
+    and parsed by helper threads (parse_gz_split, sk_host.c): FASTQ with quality lines that begin with @ + >, wrapped FASTA,
+    CRLF -- same table as the oracle program; a FASTQ record that ends the file for the reference in the middle of the
+    file fails the cut scan and goes through uncut (SK_NO_SPLIT=1) with the oracle's table"""
+    import gzip
+    import random
+    rng = random.Random(77)
+    strain = "".join(rng.choice("ACGT") for _ in range(30000))
+    (tmp_path / "s.fa").write_text(">s\n" + strain + "\n")
+
+    def fastq(n, seed):
+        r = random.Random(seed)
+        out = []
+        for i in range(n):
+            L = r.choice([31, 60, 150, 150, 250])
+            a = r.randrange(0, len(strain) - L)
+            q = "".join(r.choice("@+>IIIIFF#") for _ in range(L))
+            out.append(f"@r{i} c\n{strain[a:a + L]}\n+\n{q}\n")
+        return "".join(out)
+
+    def fasta(n, seed, width):
+        r = random.Random(seed)
+        out = []
+        for i in range(n):
+            L = r.randrange(100, 4000)
+            a = r.randrange(0, len(strain) - L)
+            seq = strain[a:a + L]
+            out.append(f">c{i}\n" + "\n".join(seq[j:j + width] for j in range(0, L, width)) + "\n")
+        return "".join(out)
+
+    files = {"a.fq.gz": fastq(1500, 1), "b.fa.gz": fasta(120, 2, 60), "c.fq.gz": fastq(400, 3).replace("\n", "\r\n")}
+    for name, text in files.items():
+        with gzip.open(tmp_path / name, "wb", compresslevel=6) as f:
+            f.write(text.encode())
+    (tmp_path / "A.txt").write_text("b.fa.gz\n")
+    (tmp_path / "B.txt").write_text("a.fq.gz\nc.fq.gz\n")
+    argv = ["-r", "s.fa", "-A", "A.txt", "-B", "B.txt"]
+    oracle = os.path.join(REPO, "oracle", "kso_oracle")
+    if not os.path.exists(oracle):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "kso_oracle"], check=True, stdout=subprocess.DEVNULL)
+    want = subprocess.run([oracle] + argv, cwd=tmp_path, capture_output=True)
+    assert want.returncode == 0
+    for chunk, par in (("4096", "3"), ("20000", "8"), ("33554432", "2")):
+        env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_GZ_THREADS="3", SK_GZ_SEG="3000", SK_CHUNK_BYTES=chunk, SK_PARSE_THREADS=par)
+        p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=env, capture_output=True)
+        for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+            assert bad not in p.stderr, p.stderr.decode()[-3000:]
+        assert (p.returncode, p.stdout) == (want.returncode, want.stdout), p.stderr.decode()[-1000:]
+    # a record whose quality is longer than its sequence, in the middle
+    text = fastq(600, 5) + "@bad\n" + strain[100:250] + "\n+\n" + "I" * 170 + "\n" + fastq(600, 6)
+    with gzip.open(tmp_path / "d.fq.gz", "wb") as f:
+        f.write(text.encode())
+    (tmp_path / "B.txt").write_text("d.fq.gz\n")
+    want = subprocess.run([oracle] + argv, cwd=tmp_path, capture_output=True)
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_GZ_THREADS="3", SK_GZ_SEG="3000", SK_CHUNK_BYTES="8192")
+    p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=env, capture_output=True)
+    assert p.returncode != 0 and b"could not be cut at record boundaries" in p.stderr
+    p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=dict(env, SK_NO_SPLIT="1"), capture_output=True)
+    assert (p.returncode, p.stdout) == (want.returncode, want.stdout) and want.returncode == 0
