@@ -788,7 +788,11 @@ static int parse_range(const scan_item *it, rec_fn fn, void *user, int64_t *nrec
  * segments' records are the file's records (src/kseq.h:171-211 reads from the top; nothing here changes what a record is).
  * Counters are sums: the order in which segments reach the device does not matter.  A failed check, or a record that ends the
  * file for the reference (FASTQ quality of the wrong length, :205-209) in a segment that is not the last, fails the scan
- * (SK_E_SPLIT) -- later segments may have been counted already; SK_NO_SPLIT=1 parses on one thread.  */
+ * (SK_E_SPLIT) -- later segments may have been counted already; SK_NO_SPLIT=1 parses on one thread.
+ * MEASURED (tools/one_gz_bench.py, profiles/r02_one_gz.txt; one 3 Gbase .gz, 16 inflating threads): it LOSES -- FASTA.gz
+ * 7.4 Gbase/s with the one parser, 5.1 with four helpers; FASTQ.gz 5.0 against 2.6-4.8.  Gathering the text into segments is
+ * one more copy of every byte on the cutting thread, which is about what parsing it costs, and FASTQ is bound by the inflate
+ * (9.5 GB/s of text = 4.6 Gbase/s) either way.  So it runs only when SK_PARSE_THREADS asks for it (tests do). */
 typedef struct gz_seg { unsigned char *buf; size_t n, cap; int is_last; struct gz_seg *next; } gz_seg;
 typedef struct {
     scan_pool *pool;
@@ -866,7 +870,7 @@ static int64_t parse_gz_split(scan_worker *w, const scan_item *it, uint64_t *bas
     gz_split g;
     pthread_t th[8];
     const char *e = getenv("SK_PARSE_THREADS");
-    int npar = e ? atoi(e) : 4, nth = 0, i;
+    int npar = e ? atoi(e) : 0, nth = 0, i;          /* off unless asked for: measured, it loses -- see the comment above */
     const size_t want = POOL_CHUNK / 2 < (1u << 20) ? POOL_CHUNK : POOL_CHUNK / 2;
     const size_t TAIL = want / 2 < (64u << 10) ? (want / 2 < 256 ? 256 : want / 2) : (64u << 10);
     size_t scan_from = want;

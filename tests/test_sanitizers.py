@@ -408,7 +408,7 @@ def test_kmer_scrub_count_one_gz_parsed_by_several_threads(ks_host_exe, tmp_path
         f.write(text.encode())
     (tmp_path / "B.txt").write_text("d.fq.gz\n")
     want = subprocess.run([oracle] + argv, cwd=tmp_path, capture_output=True)
-    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_GZ_THREADS="3", SK_GZ_SEG="3000", SK_CHUNK_BYTES="8192")
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_GZ_THREADS="3", SK_GZ_SEG="3000", SK_CHUNK_BYTES="8192", SK_PARSE_THREADS="4")
     p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=env, capture_output=True)
     assert p.returncode != 0 and b"could not be cut at record boundaries" in p.stderr
     p = subprocess.run([ks_host_exe] + argv, cwd=tmp_path, env=dict(env, SK_NO_SPLIT="1"), capture_output=True)
