@@ -329,3 +329,34 @@ def test_sd_related_strains_in_two_unions_against_oracle_runs(tmp_path):
         assert gzip.open(tmp_path / f"multi{s}.gz", "rb").read() == want, s
         total += want.count(b"\n")
     assert total > 40 * 200
+
+
+@pytest.mark.gpu
+def test_sd_union_leaves_a_giant_record_to_the_members(tmp_path):
+    """a chunk of 64 MiB or more (one 70 Mbase record: a chunk never cuts a record) does not fit the union's log packing:
+    that chunk is tallied strain by strain, the others through the union -- the outfiles are what SK_SD_NO_UNION=1 writes"""
+    rng = random.Random(99)
+    strains = [_synth.rand_dna(rng, 20_000) for _ in range(3)]
+    lines = []
+    for s, g in enumerate(strains):
+        (tmp_path / f"s{s}.fa").write_bytes(b">s%d\n" % s + g + b"\n")
+        kms = sorted({_canon(g[i:i + 31]) for i in range(0, len(g) - 31, 23)})
+        (tmp_path / f"s{s}.inf").write_bytes(b"\n".join(kms) + b"\n")
+        lines.append(f"{tmp_path}/s{s}.fa\t{tmp_path}/s{s}.inf\t{tmp_path}/out{s}.gz\n")
+    (tmp_path / "strains.txt").write_text("".join(lines))
+    import numpy as np
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(5).integers(0, 4, 70_000_000)].tobytes()
+    big = big[:1_000_000] + strains[1][:5000] + big[1_005_000:40_000_000] + _synth.revcomp(strains[2][100:9000]) + big[40_008_900:]
+    with open(tmp_path / "reads.fa", "wb") as f:
+        f.write(b">r0\n" + strains[0][50:200] + b"\n>giant\n" + big + b"\n>r2\n" + strains[1][300:450] + b"\n")
+    exe = sk.cli_path("strain_detect")
+    outs = {}
+    for union in (True, False):
+        env = dict(os.environ, SK_SD_TIMING="1")
+        if not union:
+            env["SK_SD_NO_UNION"] = "1"
+        p = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-b", str(tmp_path / "reads.fa"), "-t", "SE"], capture_output=True, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-500:]
+        outs[union] = [gzip.open(tmp_path / f"out{s}.gz", "rb").read() for s in range(3)]
+    assert outs[True] == outs[False]
+    assert sum(o.count(b"\n") for o in outs[True]) > 300
