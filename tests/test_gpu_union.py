@@ -2,6 +2,7 @@
 exactly what the member's own table gives (sk_tally_batch) -- per-record tallies and the log of informative hits with
 the member's own rows.  Strains that share most of their k-mers (diverged copies, exact copies, a repeated segment) are
 the point: a shared key has ONE slot in the union."""
+import os
 import random
 
 import numpy as np
@@ -105,9 +106,14 @@ def _check(seed, n, nreads=1500, hits_cap=None):
             k.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+# SK_FUZZ_EXTRA=N: N more worlds on top of the twelve that always run (a longer hunt, run by hand), from SK_FUZZ_BASE on
+EXTRA = int(os.environ.get("SK_FUZZ_EXTRA", "0"))
+BASE = int(os.environ.get("SK_FUZZ_BASE", "1000"))
+
+
+@pytest.mark.parametrize("seed", list(range(12)) + list(range(BASE, BASE + EXTRA)))
 def test_union_equals_member_by_member(seed):
-    _check(seed, 2 + seed % 6)
+    _check(seed, 2 + seed % 6 if seed % 11 else 9 + seed % 23, nreads=1500 if seed < 12 else 300 + (seed * 37) % 2500)
 
 
 def test_union_of_one_and_of_thirty_two():
