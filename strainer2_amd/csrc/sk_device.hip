@@ -1524,9 +1524,22 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     if (hipMalloc((void **)&c->d_flags, 16 * sizeof(uint32_t)) != hipSuccess) { delete c; return SK_E_NOMEM; }
     if (hipMalloc((void **)&c->d_oddlist, (size_t)SK_ODDCAP * sizeof(uint32_t)) != hipSuccess) { hipFree(c->d_flags); delete c; return SK_E_NOMEM; }
     hipMemsetAsync(c->d_flags, 0, 16 * sizeof(uint32_t), c->stream);
-    signed char comp[256];
-    sk_fill_complement(comp);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(sk_comp_dev), comp, sizeof comp) != hipSuccess) { delete c; return SK_E_NODEVICE; }
+    {   // the complement map goes to the device once per process and device, not once per context: the copy to a symbol
+        // waits for the device, and 32 strains opened at once (strain_detect -S) spent 0.19 s each in here
+        static pthread_mutex_t once_mu = PTHREAD_MUTEX_INITIALIZER;
+        static unsigned long long done_mask[4];
+        pthread_mutex_lock(&once_mu);
+        const bool have = device < 256 && ((done_mask[device >> 6] >> (device & 63)) & 1ull);
+        hipError_t e = hipSuccess;
+        if (!have) {
+            signed char comp[256];
+            sk_fill_complement(comp);
+            e = hipMemcpyToSymbol(HIP_SYMBOL(sk_comp_dev), comp, sizeof comp);
+            if (e == hipSuccess && device < 256) done_mask[device >> 6] |= 1ull << (device & 63);
+        }
+        pthread_mutex_unlock(&once_mu);
+        if (e != hipSuccess) { delete c; return SK_E_NODEVICE; }
+    }
     *out = c;
     return SK_OK;
 }

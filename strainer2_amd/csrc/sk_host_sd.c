@@ -527,6 +527,8 @@ static void stream_close(sd_stream *st)
 
 /* SK_SD_TIMING=1: where the wall clock went, on stderr at exit */
 static double t_wait, t_tally, t_setup, t_fill, t_launch, t_post, t_close;
+static double t_open_ctx, t_open_load, t_open_flags;     /* thread time summed over the strains' worker threads (SK_SD_TIMING) */
+static pthread_mutex_t t_open_mu = PTHREAD_MUTEX_INITIALIZER;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 /* The strains are independent once a chunk is on the device: the per-strain work -- collecting and spreading a
@@ -1229,6 +1231,7 @@ static skzo_pool *sd_zpool;             /* compressors of every -o file of the r
 typedef struct {
     sd_prog *p; const char *r, *a, *g, *o; int device, failed, done;
     char *out_buf, *err_buf; size_t out_len, err_len;
+    sk_ctxjob *cj;                        /* the first strain takes the context that was opened while the key sets were built */
 } ks_job;
 typedef struct { ks_job *jobs; uint32_t njobs, next; pthread_mutex_t mu; pthread_cond_t cv; } ks_pool;
 
@@ -1245,6 +1248,7 @@ static void *sd_keyset_pool_thread(void *arg)
         if (k >= kp->njobs) return NULL;
         j = &kp->jobs[k];
         rc = skh_keyset_from_file(&j->p->ks, j->r, SD_ROW_ORDER, SD_PLAIN, 0);
+        if (j->cj) j->p->ctx_rc = sk_ctxjob_join(j->cj, &j->p->ctx);
         real_out = j->p->out; real_err = j->p->err;
         mo = open_memstream(&j->out_buf, &j->out_len);
         me = open_memstream(&j->err_buf, &j->err_len);
@@ -1284,11 +1288,22 @@ static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a,
     if (p->ks.short_records)
         fprintf(err, "strain_detect: skipped %llu reference record(s) shorter than %d bases "
                      "(the original program crashes on these)\n", (unsigned long long)p->ks.short_records, SK_K - 1);
-    rc = p->ctx ? SK_OK : (p->ctx_rc ? p->ctx_rc : sk_ctx_create(&p->ctx, device));
-    if (rc != SK_OK) { fprintf(err, "strain_detect: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); return 1; }
-    rc = skh_keyset_load(p->ctx, &p->ks, SD_NCOLS);
-    if (rc != SK_OK) { fprintf(err, "strain_detect: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
-    return sd_strain_flags(p, a, g, o);
+    {
+        const double t0 = now_s();
+        double t1, t2;
+        int frc;
+        rc = p->ctx ? SK_OK : (p->ctx_rc ? p->ctx_rc : sk_ctx_create(&p->ctx, device));
+        if (rc != SK_OK) { fprintf(err, "strain_detect: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); return 1; }
+        t1 = now_s();
+        rc = skh_keyset_load(p->ctx, &p->ks, SD_NCOLS);
+        if (rc != SK_OK) { fprintf(err, "strain_detect: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
+        t2 = now_s();
+        frc = sd_strain_flags(p, a, g, o);
+        pthread_mutex_lock(&t_open_mu);
+        t_open_ctx += t1 - t0; t_open_load += t2 - t1; t_open_flags += now_s() - t2;
+        pthread_mutex_unlock(&t_open_mu);
+        return frc;
+    }
 }
 
 /* The strain of a kmer_scrub_count run that goes on into strain_detect in the same process (key set, row
@@ -1356,6 +1371,9 @@ static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *
 static void sd_strain_close(sd_prog *p)
 {
     if (p->zo && skzo_close(p->zo)) fprintf(stderr, "strain_detect: error writing the -o file\n");
+    /* SK_LEAK_AT_EXIT=1 (set by bin/strain_detect, whose process ends right after): the result file is complete; taking 32
+     * device contexts and key sets apart one hipFree at a time (0.3-0.7 s for 32 strains) is left to the end of the process */
+    if (getenv("SK_LEAK_AT_EXIT") && strcmp(getenv("SK_LEAK_AT_EXIT"), "0")) { memset(p, 0, sizeof *p); return; }
     if (p->ctx) sk_ctx_destroy(p->ctx);
     skh_keyset_free(&p->ks);
     free(p->type); free(p->copy_rows); free(p->hitbuf); free(p->tallybuf); free(p->cov_path); free(p->o_path);
@@ -1402,6 +1420,7 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
         fclose(fp);
     } else bad = sd_quantify(p, ns, batch, &pool, b, b2, mode);
     pool_stop(&pool);
+    if (getenv("SK_LEAK_AT_EXIT") && strcmp(getenv("SK_LEAK_AT_EXIT"), "0")) return bad;     /* (the process is about to end: see sd_strain_close) */
     sd_unions_close();
     sk_batch_destroy(batch);
     return bad;
@@ -1530,6 +1549,10 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
             ks_pool kp;
             pthread_t th[16];
             uint32_t k, failed = 0;
+            sk_ctxjob cj;
+            /* the HIP runtime comes up (0.25-3 s) while the first key sets are built: the context opened here becomes the first
+             * strain's -- every other sk_ctx_create then finds the runtime ready instead of all workers queueing up behind it */
+            if (ns) sk_ctxjob_start(&cj, device);
             memset(&kp, 0, sizeof kp);
             kp.jobs = (ks_job *)calloc(ns ? ns : 1, sizeof *kp.jobs);
             kp.njobs = ns;
@@ -1539,6 +1562,7 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
                 ks_job *j = &kp.jobs[k];
                 j->p = &p[k]; j->r = paths[4 * k]; j->a = paths[4 * k + 1]; j->o = paths[4 * k + 2]; j->g = paths[4 * k + 3];
                 j->device = device;
+                j->cj = k == 0 ? &cj : NULL;
             }
             if (nth > 16) nth = 16;
             if (nth < 1) nth = 1;
@@ -1578,6 +1602,9 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
         if (sd_coverage_write(&p[s])) goto done;
     status = 0;
 done:
+    if (getenv("SK_SD_TIMING") && ns > 1)
+        fprintf(err, "strain_detect timing: opening the strains, thread time summed: context %.2f s, table load %.2f s, -a/-g flags + outfile %.2f s\n",
+                t_open_ctx, t_open_load, t_open_flags);
     if (getenv("SK_SD_TIMING"))
         fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (upload %.2f, launch %.2f, "
                      "collect+sort+spread per strain on the pool %.2f), total before close %.2f s\n", t_setup, t_wait, t_tally, t_fill,
