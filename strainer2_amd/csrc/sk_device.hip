@@ -1360,6 +1360,13 @@ __global__ void sk_scatter_u32(uint32_t *__restrict__ dst, const uint32_t *__res
     if (i < n) dst[perm[i]] = src[i];
 }
 
+// the permutation is the caller's locality[] without its orientation bit
+__global__ void sk_perm_from_locality(uint32_t *__restrict__ perm, const uint32_t *__restrict__ locality, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = locality[i] & 0x7FFFFFFFu;
+}
+
 __global__ void sk_invert_perm(uint32_t *__restrict__ inv, const uint32_t *__restrict__ perm, uint32_t n, uint32_t *flags)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1399,7 +1406,7 @@ __global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint
 #define SK_STAGE_BYTES   (64ull << 20)
 #define SK_NSTAGE        2
 
-struct sk_pin { void *p; size_t n; bool used; };
+struct sk_pin { void *p; size_t n; bool used; bool registered; };    // registered: malloc'd + hipHostRegister; else hipHostMalloc
 
 struct sk_ctx {
     int          device;
@@ -1590,7 +1597,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
     hipFree(c->t_tally); hipFree(c->t_hits); hipFree(c->t_compact);
     hipFree(c->p_bins); hipFree(c->p_binn); hipFree(c->p_cand);
     if (c->h_tally) hipHostFree(c->h_tally);
-    for (sk_pin &q : c->pins) { hipHostUnregister(q.p); free(q.p); }
+    for (sk_pin &q : c->pins) { if (q.registered) { hipHostUnregister(q.p); free(q.p); } else hipHostFree(q.p); }
     pthread_mutex_destroy(&c->pin_mu);
     hipFree(c->d_flags);
     hipFree(c->d_oddlist);
@@ -1653,7 +1660,7 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
             for (uint32_t i = 0; i < nrows; i++) c->h_perm[i] = locality[i] & 0x7FFFFFFFu;
             SK_HIP(c, hipMalloc((void **)&c->d_locality, (size_t)nrows * 4));
             SK_HIP(c, hipMemcpyAsync(c->d_locality, locality, (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
-            SK_HIP(c, hipMemcpyAsync(c->d_perm, c->h_perm.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(sk_perm_from_locality, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, c->d_perm, (const uint32_t *)c->d_locality, nrows);   // (not a second 4 N bytes over PCIe)
             SK_HIP(c, hipMemsetAsync(c->d_inv, 0xFF, (size_t)nrows * 4, c->stream));
             hipLaunchKernelGGL(sk_invert_perm, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, c->d_inv, c->d_perm, nrows, c->d_flags);
         }
@@ -2442,10 +2449,17 @@ extern "C" int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t nbytes)
     pthread_mutex_unlock(&c->pin_mu);
     if (hipSetDevice(c->device) != hipSuccess) return SK_E_HIP;
     void *m = NULL;
+    bool registered = true;
     if (posix_memalign(&m, 4096, want) != 0) return SK_E_NOMEM;
-    if (hipHostRegister(m, want, hipHostRegisterDefault) != hipSuccess) { free(m); return SK_E_NOMEM; }
+    if (hipHostRegister(m, want, hipHostRegisterDefault) != hipSuccess) {      // (a limit on registered memory, say): the slower way
+        free(m);
+        m = NULL;
+        registered = false;
+        (void)hipGetLastError();
+        if (hipHostMalloc(&m, want, hipHostMallocDefault) != hipSuccess) return sk_fail(c, SK_E_NOMEM, "no page-locked memory (%zu bytes)", want);
+    }
     pthread_mutex_lock(&c->pin_mu);
-    c->pins.push_back((sk_pin){m, want, true});
+    c->pins.push_back((sk_pin){m, want, true, registered});
     pthread_mutex_unlock(&c->pin_mu);
     *p = m;
     return SK_OK;
