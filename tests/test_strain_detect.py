@@ -130,6 +130,19 @@ def test_tally_batch_vs_python_count():
     assert len(hits) == int(tally[:, 1].sum()) > 0
 
 
+def _oracle_runs(tmp_path, n):
+    """the CPU oracle program on strain 0..n-1 of _make_multi_inputs, eight runs at a time; returns the decompressed outfiles"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(s):
+        ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / f"s{s}.fa"), "-a", str(tmp_path / f"s{s}.inf.gz"), "-B", str(tmp_path / "B.txt"),
+                                         "-o", str(tmp_path / f"oracle{s}.gz")], str(tmp_path))
+        assert ora.returncode == 0
+        return gzip.open(tmp_path / f"oracle{s}.gz", "rb").read()
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        return list(ex.map(one, range(n)))
+
+
 def _canon(k):
     r = _synth.revcomp(k)
     return k if k >= r else r
@@ -193,33 +206,37 @@ def _make_multi_inputs(tmp_path, nstrains=3, strain_len=60_000, nreads=320_000, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("union", [True, False])
-def test_sd_many_strains_in_one_pass_equal_separate_runs(tmp_path, union):
+def test_sd_many_strains_in_one_pass_equal_separate_runs(tmp_path):
     """-S <list>: every strain's output is byte-identical (decompressed) to a separate run with its -r/-a/-o,
     and one of the separate runs is checked against the oracle.  With the union table (one scan per batch for all
     strains, the default) and strain by strain (SK_SD_NO_UNION=1)."""
     n = _make_multi_inputs(tmp_path)
     exe = sk.cli_path("strain_detect")
-    env = dict(os.environ, SK_SD_TIMING="1")
-    if not union:
-        env["SK_SD_NO_UNION"] = "1"
-    multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt"), "--coverage-depth"], capture_output=True, env=env)
-    assert (b"union table(s) for 3 strains" in multi.stderr) == union, multi.stderr.decode()[-800:]
-    assert multi.returncode == 0, multi.stderr.decode()[-500:]
-    assert multi.stdout == b"unknown file type skipping line (#comment)\nunknown file type skipping line (XX)\n"
+    single = []
     for s in range(n):
         one = subprocess.run([exe, "-r", str(tmp_path / f"s{s}.fa"), "-a", str(tmp_path / f"s{s}.inf.gz"), "-B", str(tmp_path / "B.txt"),
                               "-o", str(tmp_path / f"single{s}.gz")], capture_output=True)
-        assert one.returncode == 0 and one.stdout == multi.stdout
-        a = gzip.open(tmp_path / f"single{s}.gz", "rb").read()
-        b = gzip.open(tmp_path / f"multi{s}.gz", "rb").read()
-        assert a == b and a.count(b"\n") > 1000
-        cov = subprocess.run([sk.cli_path("coverage_depth"), "-k", str(tmp_path / f"multi{s}.gz")], capture_output=True)
-        assert cov.returncode == 0 and cov.stdout == open(tmp_path / f"multi{s}.gz.coverage_depth", "rb").read()
+        assert one.returncode == 0
+        assert one.stdout == b"unknown file type skipping line (#comment)\nunknown file type skipping line (XX)\n"
+        single.append(gzip.open(tmp_path / f"single{s}.gz", "rb").read())
+        assert single[s].count(b"\n") > 1000
     ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / "s1.fa"), "-a", str(tmp_path / "s1.inf.gz"), "-B", str(tmp_path / "B.txt"),
                                      "-o", str(tmp_path / "oracle1.gz")], str(tmp_path))
     assert ora.returncode == 0
-    assert gzip.open(tmp_path / "oracle1.gz", "rb").read() == gzip.open(tmp_path / "multi1.gz", "rb").read()
+    assert gzip.open(tmp_path / "oracle1.gz", "rb").read() == single[1]
+    for union in (True, False):
+        env = dict(os.environ, SK_SD_TIMING="1")
+        if not union:
+            env["SK_SD_NO_UNION"] = "1"
+        multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt"), "--coverage-depth"], capture_output=True, env=env)
+        assert (b"union table(s) for 3 strains" in multi.stderr) == union, multi.stderr.decode()[-800:]
+        assert multi.returncode == 0, multi.stderr.decode()[-500:]
+        assert multi.stdout == b"unknown file type skipping line (#comment)\nunknown file type skipping line (XX)\n"
+        for s in range(n):
+            assert gzip.open(tmp_path / f"multi{s}.gz", "rb").read() == single[s], (union, s)
+            cov = subprocess.run([sk.cli_path("coverage_depth"), "-k", str(tmp_path / f"multi{s}.gz")], capture_output=True)
+            assert cov.returncode == 0 and cov.stdout == open(tmp_path / f"multi{s}.gz.coverage_depth", "rb").read()
+            os.remove(tmp_path / f"multi{s}.gz")
 
 
 @pytest.mark.gpu
@@ -298,11 +315,7 @@ def test_sd_32_strains_against_32_oracle_runs(tmp_path):
     multi = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", str(tmp_path / "B.txt")], capture_output=True)
     assert multi.returncode == 0, multi.stderr.decode()[-500:]
     total = 0
-    for s in range(n):
-        ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / f"s{s}.fa"), "-a", str(tmp_path / f"s{s}.inf.gz"), "-B", str(tmp_path / "B.txt"),
-                                         "-o", str(tmp_path / f"oracle{s}.gz")], str(tmp_path))
-        assert ora.returncode == 0
-        want = gzip.open(tmp_path / f"oracle{s}.gz", "rb").read()
+    for s, want in enumerate(_oracle_runs(tmp_path, n)):
         assert gzip.open(tmp_path / f"multi{s}.gz", "rb").read() == want, s
         total += want.count(b"\n")
     assert total > 32 * 50
@@ -321,11 +334,7 @@ def test_sd_related_strains_in_two_unions_against_oracle_runs(tmp_path):
     assert multi.returncode == 0, multi.stderr.decode()[-500:]
     assert b"2 union table(s) for 40 strains" in multi.stderr
     total = 0
-    for s in range(n):
-        ora = _oracle.run_sd_oracle_cli(["-r", str(tmp_path / f"s{s}.fa"), "-a", str(tmp_path / f"s{s}.inf.gz"), "-B", str(tmp_path / "B.txt"),
-                                         "-o", str(tmp_path / f"oracle{s}.gz")], str(tmp_path))
-        assert ora.returncode == 0
-        want = gzip.open(tmp_path / f"oracle{s}.gz", "rb").read()
+    for s, want in enumerate(_oracle_runs(tmp_path, n)):
         assert gzip.open(tmp_path / f"multi{s}.gz", "rb").read() == want, s
         total += want.count(b"\n")
     assert total > 40 * 200
