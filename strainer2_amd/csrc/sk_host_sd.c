@@ -113,6 +113,9 @@ typedef struct {
     /* consumer */
     sd_chunk   *c; uint32_t ci;
     int         eof, end_kind; size_t end_len;
+    /* two device batches in turn: while the chunk in one is scanned, the next chunk of the queue is uploaded into the other */
+    sk_batch   *bat[2]; int bcur;
+    sd_chunk   *pre;                         /* the queued chunk whose bytes are already in bat[bcur ^ 1] */
 } sd_stream;
 
 /* Page-locked chunk buffers, recycled.  The upload of a chunk from ordinary memory goes through the runtime's
@@ -518,6 +521,8 @@ static void stream_close(sd_stream *st)
         pthread_mutex_destroy(&st->pmu);
         pthread_cond_destroy(&st->pcv);
     }
+    sk_batch_destroy(st->bat[0]);                       /* (waits for an upload in flight before the chunks go) */
+    sk_batch_destroy(st->bat[1]);
     for (i = 0; i < st->qn; i++) chunk_free(st->q[i]);
     chunk_free(st->c);
     chunk_free(st->cur);
@@ -733,13 +738,32 @@ static void sd_unions_open(sd_prog *p, uint32_t ns)
     if (getenv("SK_SD_TIMING")) fprintf(p[0].err, "strain_detect timing: %u union table(s) for %u strains in %.2f s\n", ng, ns, now_s() - t0);
 }
 
+/* while the device scans the current chunk: the next chunk of the stream's queue (if the reader is ahead) goes up into the
+ * stream's other batch -- the upload of a 32 MiB chunk takes about twice as long as its scan against a union table */
+static void sd_prefetch(sd_stream *st, sk_ctx *ctx)
+{
+    sd_chunk *n = NULL;
+    sk_batch **b;
+    const double t0 = now_s();
+    if (!st) return;
+    pthread_mutex_lock(&st->mu);
+    if (st->qn > 0) n = st->q[0];                          /* (only this thread takes chunks off the queue: n stays) */
+    pthread_mutex_unlock(&st->mu);
+    if (!n || n == st->pre || !n->np) return;
+    b = &st->bat[st->bcur ^ 1];
+    if (!*b && sk_batch_create(ctx, b) != SK_OK) { *b = NULL; return; }
+    if (sk_batch_fill(*b, n->buf, n->blen, n->pstart, n->np) == SK_OK) st->pre = n;
+    t_fill += now_s() - t0;
+}
+
 /* one batch against the unions; the results are dealt to the strains' tallybuf/hitbuf (u_nsp, u_nh entries) */
-static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c)
+static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c, sd_stream *st)
 {
     uint32_t g, s;
     int rc;
     for (g = 0; g < sd_un.n; g++)
         if ((rc = sk_union_tally_launch(sd_un.u[g], batch, sd_un.hcap[g])) != SK_OK) return rc;
+    sd_prefetch(st, p[0].ctx);
     for (s = 0; s < ns; s++) p[s].u_nsp = p[s].u_nh = 0;
     for (g = 0; g < sd_un.n; g++) {
         const uint32_t a = g * SK_UNION_MAX, n = sk_union_members(sd_un.u[g]);
@@ -786,7 +810,7 @@ static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c
     return SK_OK;
 }
 
-static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, sd_chunk *c)
+static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, sd_chunk *c, int uploaded, sd_stream *st)
 {
     sd_tally_job job;
     uint32_t s;
@@ -796,14 +820,16 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *poo
     c->nstrains = ns;
     c->sp = (sd_sp *)calloc(ns, sizeof *c->sp);
     if (c->np) {
-        if ((rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
+        if (!uploaded && (rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
         t1 = now_s(); t_fill += t1 - t0; t0 = t1;
         if (use_union) {
-            if ((rc = sd_tally_unions(p, ns, batch, c)) != SK_OK) return rc;
-        } else
-        for (s = 0; s < ns; s++) {
-            if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
-            if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
+            if ((rc = sd_tally_unions(p, ns, batch, c, st)) != SK_OK) return rc;
+        } else {
+            for (s = 0; s < ns; s++) {
+                if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
+                if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
+            }
+            sd_prefetch(st, p[0].ctx);
         }
         t1 = now_s(); t_launch += t1 - t0; t0 = t1;
     }
@@ -844,7 +870,12 @@ static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, 
         pthread_mutex_unlock(&st->mu);
         {
             const double t0 = now_s();
-            rc = sd_tally_chunk(p, ns, batch, pool, c);
+            const int uploaded = st->pre == c;             /* its bytes went up while the chunk before it was scanned */
+            (void)batch;
+            if (uploaded) st->bcur ^= 1;
+            st->pre = NULL;
+            if (!st->bat[st->bcur] && (rc = sk_batch_create(p[0].ctx, &st->bat[st->bcur])) != SK_OK) { st->bat[st->bcur] = NULL; chunk_free(c); return rc; }
+            rc = sd_tally_chunk(p, ns, st->bat[st->bcur], pool, c, uploaded, st);
             t_tally += now_s() - t0;
         }
         if (rc != SK_OK) { chunk_free(c); return rc; }
@@ -1386,13 +1417,9 @@ static void close_one(void *arg, uint32_t s) { sd_strain_close(&((sd_prog *)arg)
 /* the metagenome side of main (src/strain_detect.c:263-384), for ns strains at once */
 static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const char *b2, int mode, FILE *out, FILE *err)
 {
-    sk_batch *batch = NULL;
+    sk_batch *batch = NULL;                          /* (every stream has its own pair of device batches: stream_fill) */
     sd_pool pool;
-    int bad = 0, rc;
-    if ((rc = sk_batch_create(p[0].ctx, &batch)) != SK_OK) {
-        fprintf(err, "strain_detect: %s (%s)\n", sk_strerror(rc), sk_last_error(p[0].ctx));
-        return 1;
-    }
+    int bad = 0;
     sd_pin_open(p[0].ctx, sd_chunk_bytes());
     sd_unions_open(p, ns);
     pool_start(&pool, ns);
@@ -1400,7 +1427,7 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
         FILE *fp = fopen(B, "r");
         char *line = NULL, *nl, *tok, *f1, *f2;
         size_t cap = 0;
-        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); pool_stop(&pool); sd_unions_close(); sk_batch_destroy(batch); return 1; }
+        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); pool_stop(&pool); sd_unions_close(); return 1; }
         while (!bad && getline(&line, &cap, fp) != -1) {
             int m;
             if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
@@ -1422,7 +1449,6 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
     pool_stop(&pool);
     if (getenv("SK_LEAK_AT_EXIT") && strcmp(getenv("SK_LEAK_AT_EXIT"), "0")) return bad;     /* (the process is about to end: see sd_strain_close) */
     sd_unions_close();
-    sk_batch_destroy(batch);
     return bad;
 }
 
