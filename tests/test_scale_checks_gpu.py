@@ -28,3 +28,11 @@ def test_odd_strain_shapes_scanned_against_themselves():
 def test_programs_against_oracle_programs_with_a_busy_byte_string_path(env):
     out = _run("iupac_diff_check.py", **env)
     assert out.count("identical") == 4 and "DIFFERENT" not in out
+
+
+def test_many_strains_in_one_pass_against_the_oracle_strain_by_strain():
+    """`strain_detect -S` on random worlds of 2-6 related strains, SE/PE/PEI files (plain, .gz, FASTA, FASTQ), a third of the
+    reads below k, tiny chunks, several parser threads, union table on and off -- every strain's outfile against the oracle
+    program's (tests/checks/sd_multi_diff_check.py; a hunt over more seeds is run by hand with SEEDS=a..b)"""
+    out = _run("sd_multi_diff_check.py", SEEDS="0..9")
+    assert out.count("identical") == 11 and "differs" not in out
