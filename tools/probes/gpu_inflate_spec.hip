@@ -1,0 +1,465 @@
+// tools/probes/gpu_inflate_spec.hip -- EXPERIMENT (not product code), second step after gpu_inflate_probe.hip: the WHOLE speculative
+// decode of sk_gzpar.h on the device, with nothing from the host but the file.  One lane per segment of SEG compressed bytes:
+//   search   the first bit in the segment where a non-final dynamic block header passes every check zlib makes (header ranges,
+//            complete code-length code, complete literal/length code, distance code complete or single) and whose block decodes
+//   tables   built by the lane in its own global scratch (11-bit primary + subtables, 8-bit for distances; no literal pairs)
+//   decode   block after block into 16-bit symbols -- a byte, or 256 + p for "the byte at place p of the 32 KiB before this
+//            segment", which the lane cannot know -- until a block ends at or behind the next segment's first bit (or is final)
+// The search runs a WAVE per segment (kernel find_candidates: 64 bit positions at a time through the cheap checks; a lane stepping
+// through half a million bit positions on its own took 1.8 s); the survivors (about one position in a thousand) are listed per segment
+// and tried in order by the segment's decode lane.  A lane whose block ends in a segment without a block start of its own goes on
+// (kernel extend) until it meets the next segment that has one.
+// The host then CHECKS the chain (segment k ends on the bit segment k + 1 started from; segment 0 starts at the member's first
+// block), resolves the placeholders in segment order and compares length and CRC-32 with the gzip trailer.
+// Stored and fixed blocks end a lane with a flag (the FASTQ/FASTA .gz files of interest hold dynamic blocks only).
+//     hipcc -O3 --offload-arch=gfx950 -o gpu_inflate_spec tools/probes/gpu_inflate_spec.hip -lz ; ./gpu_inflate_spec file.gz [SEG_KiB]
+#include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+#include <chrono>
+#include <vector>
+
+#define LB 11
+#define DB 8
+#define NLIT (2048 + 286 * 16)
+#define NDIST (256 + 30 * 128)
+#define WINDOW 32768u
+enum { K_LIT = 0, K_LEN = 2, K_EOB = 3, K_SUB = 4, K_BAD = 5, K_DIST = 6 };
+#define ENTRY(val, extra, kind, nbits) (((uint32_t)(val) << 16) | ((uint32_t)(extra) << 8) | ((uint32_t)(kind) << 4) | (uint32_t)(nbits))
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+struct seg_out { uint64_t start_bit, end_bit; uint32_t n, flags, blocks, tried; uint64_t t_hdr, t_blk; };   // flags: 1 ok, 2 final block seen, 4 hit a stored/fixed block, 8 output cap, 16 nothing found
+
+__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t  c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t  c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t  c_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// bit reader over the file as 32-bit words (zeros past its end)
+struct bits {
+    const uint32_t *w; uint64_t nwords, wp; uint64_t buf; uint32_t cnt;
+    __device__ void seek(uint64_t bit) { wp = bit >> 5; buf = (uint64_t)(wp < nwords ? w[wp] : 0u) >> (bit & 31u); cnt = 32u - (uint32_t)(bit & 31u); wp++; }
+    __device__ void fill() { if (cnt <= 32u) { buf |= (uint64_t)(wp < nwords ? w[wp] : 0u) << cnt; wp++; cnt += 32u; } }
+    __device__ uint32_t peek(uint32_t n) const { return (uint32_t)(buf & (((uint64_t)1 << n) - 1u)); }
+    __device__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
+    __device__ uint64_t pos() const { return wp * 32u - cnt; }
+};
+
+__device__ uint32_t rev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32u - len); }
+
+__device__ uint32_t sym_entry(int is_dist, uint32_t sym, uint32_t nbits)
+{
+    if (is_dist) return sym < 30 ? ENTRY(c_dist_base[sym], c_dist_extra[sym], K_DIST, nbits) : ENTRY(0, 0, K_BAD, nbits);
+    if (sym < 256) return ENTRY(sym, 0, K_LIT, nbits);
+    if (sym == 256) return ENTRY(0, 0, K_EOB, nbits);
+    if (sym < 286) return ENTRY(c_len_base[sym - 257], c_len_extra[sym - 257], K_LEN, nbits);
+    return ENTRY(0, 0, K_BAD, nbits);
+}
+
+// canonical Huffman decode table (primary of tbits + subtables), as skz_build of sk_gzfast.h without the literal pairs
+__device__ int build(uint32_t *table, uint32_t tbits, uint32_t cap, const uint8_t *lens, uint32_t nsym, int is_dist)
+{
+    uint32_t count[16], next[16], next2[16];
+    for (int i = 0; i < 16; i++) count[i] = 0;
+    for (uint32_t s = 0; s < nsym; s++) count[lens[s]]++;
+    count[0] = 0;
+    uint32_t left = 1, code = 0;
+    for (uint32_t len = 1; len <= 15; len++) { left <<= 1; if (count[len] > left) return -1; left -= count[len]; }
+    for (uint32_t len = 1; len <= 15; len++) { code = (code + count[len - 1]) << 1; next[len] = next2[len] = code; }
+    const uint32_t prim = 1u << tbits;
+    for (uint32_t i = 0; i < prim; i++) table[i] = ENTRY(0, 0, K_BAD, 1);
+    // pass 1: short codes; the longest code through every primary slot is kept in the slot itself (kind K_BAD, value = depth)
+    for (uint32_t s = 0; s < nsym; s++) {
+        const uint32_t len = lens[s];
+        if (!len) continue;
+        const uint32_t r = rev(next[len]++, len);
+        if (len <= tbits) { const uint32_t e = sym_entry(is_dist, s, len); for (uint32_t i = r; i < prim; i += 1u << len) table[i] = e; }
+        else { const uint32_t p = r & (prim - 1u); const uint32_t d = table[p] >> 16; if (len > d) table[p] = ENTRY(len, 0, K_BAD, 1); }
+    }
+    uint32_t used = prim;
+    for (uint32_t i = 0; i < prim; i++) {
+        const uint32_t d = table[i] >> 16;
+        if (((table[i] >> 4) & 15u) == K_BAD && d > tbits) {
+            const uint32_t sbits = d - tbits;
+            if (used + (1u << sbits) > cap || used > 0xFFFFu) return -1;
+            table[i] = ENTRY(used, sbits, K_SUB, tbits);
+            for (uint32_t j = 0; j < (1u << sbits); j++) table[used + j] = ENTRY(0, 0, K_BAD, 1);
+            used += 1u << sbits;
+        }
+    }
+    for (uint32_t s = 0; s < nsym; s++) {
+        const uint32_t len = lens[s];
+        if (len <= tbits) continue;
+        const uint32_t r = rev(next2[len]++, len), p = r & (prim - 1u);
+        const uint32_t start = table[p] >> 16, sbits = (table[p] >> 8) & 255u, e = sym_entry(is_dist, s, len - tbits);
+        for (uint32_t i = r >> tbits; i < (1u << sbits); i += 1u << (len - tbits)) table[start + i] = e;
+    }
+    return 0;
+}
+
+__device__ bool complete(const uint8_t *lens, uint32_t n) { uint32_t sum = 0; for (uint32_t i = 0; i < n; i++) if (lens[i]) sum += 1u << (15 - lens[i]); return sum == (1u << 15); }
+
+// the dynamic header behind BFINAL/BTYPE: code lengths, both tables; as skz_read_dynamic(strict) of sk_gzfast.h
+__device__ int read_lens(bits &b, uint8_t *lens, uint32_t &hlit_out, uint32_t &hdist_out);
+__device__ int read_dynamic(bits &b, uint32_t *lt, uint32_t *dt, uint8_t *lens)
+{
+    uint32_t hlit, hdist;
+    if (read_lens(b, lens, hlit, hdist)) return -1;
+    if (build(lt, LB, NLIT, lens, hlit, 0)) return -1;
+    if (build(dt, DB, NDIST, lens + hlit, hdist, 1)) return -1;
+    return 0;
+}
+// the header's code lengths and every check on them (no tables yet)
+__device__ int read_lens(bits &b, uint8_t *lens, uint32_t &hlit_out, uint32_t &hdist_out)
+{
+    uint8_t cl[19];
+    uint16_t cltab[128];
+    b.fill();
+    const uint32_t hlit = b.peek(5) + 257; b.drop(5);
+    const uint32_t hdist = b.peek(5) + 1; b.drop(5);
+    const uint32_t hclen = b.peek(4) + 4; b.drop(4);
+    if (hlit > 286 || hdist > 30) return -1;
+    for (int i = 0; i < 19; i++) cl[i] = 0;
+    for (uint32_t i = 0; i < hclen; i++) { b.fill(); cl[c_order[i]] = (uint8_t)b.peek(3); b.drop(3); }
+    {
+        uint32_t count[8], next[8], code = 0, left = 1;
+        for (int i = 0; i < 8; i++) count[i] = 0;
+        for (int s = 0; s < 19; s++) count[cl[s]]++;
+        count[0] = 0;
+        for (uint32_t len = 1; len <= 7; len++) { left <<= 1; if (count[len] > left) return -1; left -= count[len]; }
+        for (uint32_t len = 1; len <= 7; len++) { code = (code + count[len - 1]) << 1; next[len] = code; }
+        for (int i = 0; i < 128; i++) cltab[i] = 0xFFFFu;
+        for (uint32_t s = 0; s < 19; s++) {
+            const uint32_t len = cl[s];
+            if (!len) continue;
+            const uint32_t r = rev(next[len]++, len);
+            for (uint32_t j = r; j < 128; j += 1u << len) cltab[j] = (uint16_t)((s << 8) | len);
+        }
+    }
+    uint32_t n = 0;
+    while (n < hlit + hdist) {
+        b.fill();
+        const uint32_t e = cltab[b.peek(7)];
+        if (e == 0xFFFFu) return -1;
+        b.drop(e & 255u);
+        const uint32_t sym = e >> 8;
+        uint32_t rep, val;
+        if (sym < 16) { lens[n++] = (uint8_t)sym; continue; }
+        if (sym == 16) { if (n == 0) return -1; val = lens[n - 1]; rep = 3 + b.peek(2); b.drop(2); }
+        else if (sym == 17) { val = 0; rep = 3 + b.peek(3); b.drop(3); }
+        else { val = 0; rep = 11 + b.peek(7); b.drop(7); }
+        if (n + rep > hlit + hdist) return -1;
+        while (rep--) lens[n++] = (uint8_t)val;
+    }
+    if (b.pos() > b.nwords * 32u || lens[256] == 0) return -1;
+    uint32_t nd = 0;
+    for (uint32_t i = 0; i < hdist; i++) nd += lens[hlit + i] != 0;
+    if (!complete(lens, hlit)) return -1;
+    if (nd > 1 && !complete(lens + hlit, hdist)) return -1;
+    hlit_out = hlit; hdist_out = hdist;
+    return 0;
+}
+
+// one Huffman block into 16-bit symbols; 0 = ended on its end-of-block code, 1 = output cap, -1 = not a block
+__device__ int block16(bits &b, const uint32_t *lt, const uint32_t *dt, uint16_t *o, uint32_t &n, uint32_t cap)
+{
+    for (;;) {
+        if (n + 260u > cap) return 1;
+        b.fill();
+        uint32_t e = lt[b.peek(LB)];
+        uint32_t kind = (e >> 4) & 15u;
+        if (kind == K_LIT) { b.drop(e & 15u); o[n++] = (uint16_t)(e >> 16); continue; }
+        if (kind == K_SUB) {
+            b.drop(LB);
+            e = lt[(e >> 16) + b.peek((e >> 8) & 255u)];
+            kind = (e >> 4) & 15u;
+            if (kind == K_LIT) { b.drop(e & 15u); o[n++] = (uint16_t)(e >> 16); continue; }
+        }
+        b.drop(e & 15u);
+        if (kind == K_LEN) {
+            const uint32_t xb = (e >> 8) & 255u;
+            const uint32_t len = (e >> 16) + b.peek(xb);
+            b.drop(xb);
+            b.fill();
+            uint32_t d = dt[b.peek(DB)];
+            if (((d >> 4) & 15u) == K_SUB) { b.drop(DB); d = dt[(d >> 16) + b.peek((d >> 8) & 255u)]; }
+            b.drop(d & 15u);
+            if (((d >> 4) & 15u) != K_DIST) return -1;
+            const uint32_t db = (d >> 8) & 255u;
+            const uint32_t dist = (d >> 16) + b.peek(db);
+            b.drop(db);
+            // place n of the output = place WINDOW + n of (window, output); a source place below WINDOW is a placeholder
+            for (uint32_t k = 0; k < len; k++) {
+                const uint32_t src = WINDOW + n + k - dist;                  // (dist <= 32768 <= WINDOW + n: never negative)
+                o[n + k] = src < WINDOW ? (uint16_t)(256u + src) : o[src - WINDOW];
+            }
+            n += len;
+            continue;
+        }
+        if (kind == K_EOB) return b.pos() > b.nwords * 32u ? -1 : 0;
+        return -1;
+    }
+}
+
+#define CANDMAX 1024u
+// every bit position of segment k (k >= 1) through the cheap checks, 64 at a time; survivors in ascending order in cand[k][..]
+__global__ void find_candidates(const uint32_t *__restrict__ comp32, uint64_t nwords, uint64_t total_bits, uint32_t seg_bytes, uint64_t base_byte,
+                                uint32_t nseg, uint32_t *cand, uint32_t *ncand)
+{
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= nseg || k == 0) return;
+    const uint64_t lo = (base_byte + (uint64_t)k * seg_bytes) * 8u;
+    uint64_t hi = (base_byte + (uint64_t)(k + 1) * seg_bytes) * 8u;
+    if (hi > total_bits) hi = total_bits;
+    uint32_t n = 0;
+    for (uint64_t base = lo; base < hi; base += 64u) {                         // (wave-uniform)
+        const uint64_t bit = base + lane;
+        bool ok = bit < hi;
+        if (ok) {
+            const uint64_t wp = bit >> 5;
+            const uint32_t sh = (uint32_t)(bit & 31u);
+            const uint64_t w0 = wp < nwords ? comp32[wp] : 0u, w1 = wp + 1 < nwords ? comp32[wp + 1] : 0u, w2 = wp + 2 < nwords ? comp32[wp + 2] : 0u, w3 = wp + 3 < nwords ? comp32[wp + 3] : 0u;
+            const uint64_t a = ((w0 | (w1 << 32)) >> sh) | (sh ? (w2 << (64u - sh)) : 0ull);        // bits 0..63 from `bit`
+            const uint64_t b2 = ((w2 | (w3 << 32)) >> sh);                                            // bits 64.. (top sh bits missing: 74 - 64 = 10 needed, sh <= 31: fine)
+            const uint32_t w = (uint32_t)a & 0x1FFFFu;
+            ok = (w & 7u) == 4u && ((w >> 3) & 31u) <= 29u && ((w >> 8) & 31u) <= 29u;
+            if (ok) {
+                const uint32_t hclen = ((w >> 13) & 15u) + 4u;
+                uint32_t sum = 0;
+                for (uint32_t i = 0; i < hclen; i++) {
+                    const uint32_t at = 17u + 3u * i;
+                    const uint32_t l = (uint32_t)(at + 3u <= 64u ? (a >> at) : at >= 64u ? (b2 >> (at - 64u)) : ((a >> at) | (b2 << (64u - at)))) & 7u;
+                    if (l) sum += 128u >> l;
+                }
+                ok = sum == 128u;
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (ok) { const uint32_t at = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); if (at < CANDMAX) cand[(size_t)k * CANDMAX + at] = (uint32_t)(bit - lo); }
+        n += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) ncand[k] = n < CANDMAX ? n : CANDMAX;
+}
+
+// a lane per CANDIDATE: the whole header through every check; the ones that fail are struck from the list (top bit).  Done apart from
+// the decode so that a wave's lanes are all in the same kind of work at the same time: with the checks inside the decode lane's loop,
+// every lane of a wave met its true start in another iteration and the 64 first-block decodes of a wave ran one after the other.
+__global__ void validate(const uint32_t *__restrict__ comp32, uint64_t nwords, uint32_t seg_bytes, uint64_t base_byte, uint32_t nseg, uint32_t *cand, const uint32_t *__restrict__ ncand)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = (uint32_t)(idx / CANDMAX), c = (uint32_t)(idx % CANDMAX);
+    if (k >= nseg || k == 0 || c >= ncand[k]) return;
+    uint8_t lens[320];
+    uint32_t hlit, hdist;
+    bits b; b.w = comp32; b.nwords = nwords;
+    b.seek((base_byte + (uint64_t)k * seg_bytes) * 8u + cand[(size_t)k * CANDMAX + c] + 3u);
+    if (read_lens(b, lens, hlit, hdist)) cand[(size_t)k * CANDMAX + c] |= 0x80000000u;
+}
+
+// lane per segment: its first candidate whose header stands up to every check and whose block decodes; then block after block until
+// one ends at or behind the next segment's first bit (or is final)
+__global__ void spec_decode(const uint32_t *__restrict__ comp32, uint64_t nwords, uint64_t first_bit, uint64_t total_bits, uint32_t seg_bytes, uint64_t base_byte,
+                            uint32_t nseg, const uint32_t *__restrict__ cand, const uint32_t *__restrict__ ncand, uint32_t *tabs, uint16_t *sym, uint32_t cap, seg_out *out, int first_only, uint32_t vlimit)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nseg) return;
+    uint32_t *lt = tabs + (size_t)k * (NLIT + NDIST), *dt = lt + NLIT;
+    uint16_t *o = sym + (size_t)k * cap;
+    uint8_t lens[320];
+    const uint64_t lo = k == 0 ? first_bit : (base_byte + (uint64_t)k * seg_bytes) * 8u;
+    const uint64_t stop = k + 1 < nseg ? (base_byte + (uint64_t)(k + 1) * seg_bytes) * 8u : 0;     // 0: to the final block
+    bits b; b.w = comp32; b.nwords = nwords;
+    seg_out r; r.start_bit = r.end_bit = 0; r.n = 0; r.flags = 0; r.blocks = 0; r.tried = 0; r.t_hdr = r.t_blk = 0;
+    uint32_t n = 0;
+    bool have = false;
+    const uint32_t nc = k == 0 ? 1u : ncand[k];
+    uint32_t c = 0;
+    for (;;) {
+        // (the cheap walk to the next candidate that validate left standing is kept apart from the decode: all lanes of a wave
+        // then decode their first block in the same pass of this loop, whatever place their candidate has in its list)
+        while (k && c < nc && (cand[(size_t)k * CANDMAX + c] & 0x80000000u)) c++;
+        if (c >= nc) break;
+        const uint64_t bit = k == 0 ? first_bit : lo + cand[(size_t)k * CANDMAX + c];
+        b.seek(bit);
+        b.fill();
+        if (k == 0 && (b.peek(3) & 6u) != 4u) { r.flags = 4; break; }        // the first block: any BFINAL, must be dynamic for this probe
+        r.tried++;
+        const uint32_t final = b.peek(1);
+        b.drop(3);
+        const long long c0 = clock64();
+        const int hrc = read_dynamic(b, lt, dt, lens);
+        r.t_hdr += (uint64_t)(clock64() - c0);
+        if (hrc == 0) {
+            const long long c1 = clock64();
+            n = 0;
+            // (a header that only looks like one decodes noise: give it the room of a big block, not the segment's whole buffer)
+            const int rc = block16(b, lt, dt, o, n, k == 0 ? cap : (cap < vlimit ? cap : vlimit));
+            r.tried += 1u << 16;                                               // (high half: headers that passed every check and went on to decode)
+            r.t_blk += (uint64_t)(clock64() - c1);
+            if (rc == 0) { have = true; r.start_bit = bit; r.blocks = 1; if (final) r.flags |= 2; break; }
+        }
+        c++;
+    }
+    if (!have) { if (!r.flags) r.flags = 16; out[k] = r; return; }
+    while (!(r.flags & 2) && !first_only) {
+        const uint64_t at = b.pos();
+        if (stop && at >= stop) break;
+        b.fill();
+        const uint32_t final = b.peek(1), type = (b.peek(3) >> 1);
+        b.drop(3);
+        if (type != 2) { r.flags |= 4; break; }
+        if (read_dynamic(b, lt, dt, lens)) { r.flags |= 32; break; }
+        const int rc = block16(b, lt, dt, o, n, cap);
+        if (rc == 1) { r.flags |= 8; break; }
+        if (rc) { r.flags |= 32; break; }
+        r.blocks++;
+        if (final) r.flags |= 2;
+    }
+    r.end_bit = b.pos();
+    r.n = n;
+    if (!(r.flags & (4 | 8 | 32))) r.flags |= 1;
+    out[k] = r;
+}
+
+// a lane whose last block ended in (or behind) a segment that has no block start of its own goes on from there until it meets the next
+// segment that has one (or the final block)
+__global__ void extend(const uint32_t *__restrict__ comp32, uint64_t nwords, uint32_t nseg, uint32_t *tabs, uint16_t *sym, uint32_t cap, seg_out *out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nseg) return;
+    seg_out r = out[k];
+    if (!(r.flags & 1) || (r.flags & 2)) return;
+    uint32_t j = k + 1;
+    while (j < nseg && !(out[j].flags & 1)) j++;                               // the next segment with a start of its own (read-only here: flags & 1 of others never change)
+    const uint64_t target = j < nseg ? out[j].start_bit : ~0ull;
+    if (r.end_bit >= target) return;
+    uint32_t *lt = tabs + (size_t)k * (NLIT + NDIST), *dt = lt + NLIT;
+    uint16_t *o = sym + (size_t)k * cap;
+    uint8_t lens[320];
+    bits b; b.w = comp32; b.nwords = nwords;
+    b.seek(r.end_bit);
+    uint32_t n = r.n;
+    while (!(r.flags & 2) && b.pos() < target) {
+        b.fill();
+        const uint32_t final = b.peek(1), type = (b.peek(3) >> 1);
+        b.drop(3);
+        if (type != 2) { r.flags = (r.flags & ~1u) | 4; break; }
+        if (read_dynamic(b, lt, dt, lens)) { r.flags = (r.flags & ~1u) | 32; break; }
+        const int rc = block16(b, lt, dt, o, n, cap);
+        if (rc) { r.flags = (r.flags & ~1u) | (rc == 1 ? 8 : 32); break; }
+        r.blocks++;
+        if (final) r.flags |= 2;
+    }
+    r.end_bit = b.pos();
+    r.n = n;
+    out[k].end_bit = r.end_bit; out[k].n = r.n; out[k].blocks = r.blocks;
+    out[k].flags = r.flags | 64u;                                               // 64: extended
+}
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: gpu_inflate_spec file.gz [SEG_KiB]\n"); return 2; }
+    const uint32_t seg_bytes = (argc > 2 ? (uint32_t)atoi(argv[2]) : 64u) << 10;
+    struct stat st;
+    int fd = open(argv[1], O_RDONLY);
+    if (fd < 0 || fstat(fd, &st)) return 2;
+    const size_t ncomp = (size_t)st.st_size;
+    const unsigned char *m = (const unsigned char *)mmap(NULL, ncomp, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED || ncomp < 32 || m[0] != 0x1f || m[1] != 0x8b || m[2] != 8) { fprintf(stderr, "not a gzip file\n"); return 2; }
+    size_t hdr = 10;                                                           // (FEXTRA/FNAME/FCOMMENT/FHCRC as gzip writes them)
+    if (m[3] & 4) hdr += 2 + (m[hdr] | (m[hdr + 1] << 8));
+    if (m[3] & 8) { while (m[hdr]) hdr++; hdr++; }
+    if (m[3] & 16) { while (m[hdr]) hdr++; hdr++; }
+    if (m[3] & 2) hdr += 2;
+    const uint32_t want_crc = m[ncomp - 8] | (m[ncomp - 7] << 8) | (m[ncomp - 6] << 16) | ((uint32_t)m[ncomp - 5] << 24);
+    const uint32_t want_len = m[ncomp - 4] | (m[ncomp - 3] << 8) | (m[ncomp - 2] << 16) | ((uint32_t)m[ncomp - 1] << 24);
+    const uint64_t first_bit = hdr * 8, total_bits = (ncomp - 8) * 8;
+    const uint32_t nseg = (uint32_t)((ncomp - 8 - hdr + seg_bytes - 1) / seg_bytes);
+    const uint32_t cap = seg_bytes * 8u + 66000u;                              // symbols per segment (ratio up to 8 + one block of slack)
+    const size_t nwords = (ncomp + 3) / 4;
+    printf("%s: %.2f GB, %u segments of %u KiB, symbol buffers %.1f GB, table scratch %.1f GB\n", argv[1], ncomp / 1e9, nseg, seg_bytes >> 10,
+           (double)nseg * cap * 2 / 1e9, (double)nseg * (NLIT + NDIST) * 4 / 1e9);
+    uint32_t *d_comp, *d_tabs;
+    uint16_t *d_sym;
+    seg_out *d_out;
+    uint32_t *d_cand, *d_ncand;
+    CK(hipMalloc(&d_cand, (size_t)nseg * CANDMAX * 4));
+    CK(hipMalloc(&d_ncand, (size_t)nseg * 4));
+    CK(hipMemset(d_ncand, 0, (size_t)nseg * 4));
+    CK(hipMalloc(&d_comp, nwords * 4 + 16));
+    CK(hipMemset(d_comp, 0, nwords * 4 + 16));
+    CK(hipMemcpy(d_comp, m, ncomp, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_tabs, (size_t)nseg * (NLIT + NDIST) * 4));
+    CK(hipMalloc(&d_sym, (size_t)nseg * cap * 2));
+    CK(hipMalloc(&d_out, nseg * sizeof(seg_out)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEvent_t ea, eb;
+        float ms_a = 0, ms_b = 0, ms_c = 0;
+        CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(find_candidates, dim3((nseg + 3) / 4), dim3(256), 0, 0, d_comp, (uint64_t)nwords, total_bits, seg_bytes, (uint64_t)hdr, nseg, d_cand, d_ncand);
+        hipLaunchKernelGGL(validate, dim3((uint32_t)(((uint64_t)nseg * CANDMAX + 255) / 256)), dim3(256), 0, 0, d_comp, (uint64_t)nwords, seg_bytes, (uint64_t)hdr, nseg, d_cand, (const uint32_t *)d_ncand);
+        CK(hipEventRecord(ea));
+        hipLaunchKernelGGL(spec_decode, dim3((nseg + 63) / 64), dim3(64), 0, 0, d_comp, (uint64_t)nwords, first_bit, total_bits, seg_bytes, (uint64_t)hdr, nseg,
+                           (const uint32_t *)d_cand, (const uint32_t *)d_ncand, d_tabs, d_sym, cap, d_out, getenv("FIRST_ONLY") ? 1 : 0, getenv("VLIMIT") ? (uint32_t)atoi(getenv("VLIMIT")) : 300000u);
+        CK(hipEventRecord(eb));
+        hipLaunchKernelGGL(extend, dim3((nseg + 63) / 64), dim3(64), 0, 0, d_comp, (uint64_t)nwords, nseg, d_tabs, d_sym, cap, d_out);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipEventElapsedTime(&ms_a, e0, ea)); CK(hipEventElapsedTime(&ms_b, ea, eb)); CK(hipEventElapsedTime(&ms_c, eb, e1));
+        printf("  on the device: %.1f ms in all (header search + checks %.1f, tables + decode %.1f, going on over segments without a start %.1f)\n", ms, ms_a, ms_b, ms_c);
+    }
+    std::vector<seg_out> out(nseg);
+    CK(hipMemcpy(out.data(), d_out, nseg * sizeof(seg_out), hipMemcpyDeviceToHost));
+    // the chain over the segments that found a start of their own: each must begin where the one before it ended
+    uint64_t nsym = 0, blocks = 0, tried = 0, passed = 0, t_hdr = 0, t_blk = 0;
+    uint32_t empty = 0, broken = 0, chain_bad = 0, extended = 0, last = 0;
+    std::vector<uint32_t> order;
+    for (uint32_t k = 0; k < nseg; k++) {
+        tried += out[k].tried & 0xFFFFu; passed += out[k].tried >> 16; t_hdr += out[k].t_hdr; t_blk += out[k].t_blk;
+        if (out[k].flags & 64u) extended++;
+        if (!(out[k].flags & 1)) { if (out[k].flags & 16u) empty++; else broken++; continue; }
+        if (!order.empty() && out[k].start_bit != out[order.back()].end_bit) chain_bad++;
+        order.push_back(k);
+        nsym += out[k].n; blocks += out[k].blocks;
+        last = k;
+    }
+    printf("  %llu symbols = bytes of text (trailer says %u mod 2^32), %llu blocks, %llu headers tried (%.1f per segment, %llu of them passed every check and were decoded); segments without a start: %u, "
+           "that went on: %u, failed: %u, chain breaks: %u, final block seen: %s\n", (unsigned long long)nsym, want_len, (unsigned long long)blocks,
+           (unsigned long long)tried, (double)tried / nseg, (unsigned long long)passed, empty, extended, broken, chain_bad, (out[last].flags & 2) ? "yes" : "NO");
+    printf("  => %.1f GB/s of text for the whole speculative decode; per lane on average: %.2f M clocks in the header checks, %.2f M in the first block\n",
+           nsym / (ms * 1e-3) / 1e9, (double)t_hdr / nseg / 1e6, (double)t_blk / nseg / 1e6);
+    if (chain_bad || order.empty() || order[0] != 0 || !(out[last].flags & 2) || (uint32_t)nsym != want_len) { printf("  NOT VERIFIED (a real one would hand this file to the host path)\n"); return 1; }
+    // resolve the placeholders in segment order on the host and check the CRC-32 (slow: one thread, for the check only)
+    {
+        const double t0 = now();
+        std::vector<uint16_t> s((size_t)cap);
+        std::vector<unsigned char> win(WINDOW, 0), bytes;
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (uint32_t k : order) {
+            const uint32_t n = out[k].n;
+            CK(hipMemcpy(s.data(), d_sym + (size_t)k * cap, (size_t)n * 2, hipMemcpyDeviceToHost));
+            bytes.resize(n);
+            for (uint32_t i = 0; i < n; i++) bytes[i] = s[i] < 256 ? (unsigned char)s[i] : win[s[i] - 256];
+            crc = (uint32_t)crc32(crc, bytes.data(), n);
+            if (n >= WINDOW) memcpy(win.data(), bytes.data() + n - WINDOW, WINDOW);
+            else { memmove(win.data(), win.data() + n, WINDOW - n); memcpy(win.data() + WINDOW - n, bytes.data(), n); }
+        }
+        printf("  placeholders resolved on the host in %.1f s: CRC-32 %08x, trailer %08x: %s\n", now() - t0, crc, want_crc, crc == want_crc ? "VERIFIED" : "WRONG");
+        return crc == want_crc ? 0 : 1;
+    }
+}
