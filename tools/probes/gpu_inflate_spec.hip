@@ -31,7 +31,7 @@
 #define NLIT (2048 + 286 * 16)
 #define NDIST (256 + 30 * 128)
 #define WINDOW 32768u
-enum { K_LIT = 0, K_LEN = 2, K_EOB = 3, K_SUB = 4, K_BAD = 5, K_DIST = 6 };
+enum { K_LIT = 0, K_LIT2 = 1, K_LEN = 2, K_EOB = 3, K_SUB = 4, K_BAD = 5, K_DIST = 6 };
 #define ENTRY(val, extra, kind, nbits) (((uint32_t)(val) << 16) | ((uint32_t)(extra) << 8) | ((uint32_t)(kind) << 4) | (uint32_t)(nbits))
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -101,6 +101,22 @@ __device__ int build(uint32_t *table, uint32_t tbits, uint32_t cap, const uint8_
         const uint32_t r = rev(next2[len]++, len), p = r & (prim - 1u);
         const uint32_t start = table[p] >> 16, sbits = (table[p] >> 8) & 255u, e = sym_entry(is_dist, s, len - tbits);
         for (uint32_t i = r >> tbits; i < (1u << sbits); i += 1u << (len - tbits)) table[start + i] = e;
+    }
+    // literal pairs, as the host's tables have them: where the bits of a primary index spell one literal and then, completely, a
+    // second one, the entry yields both.  In place, from the high indices down?  No: entry i looks at entry i >> l1 (a LOWER index
+    // unless l1 = 0), which must still be the single-literal entry -- so a first pass marks (kind K_LIT2 needs both literals in the
+    // value), reading only K_LIT entries' original values kept in the low byte of the value field of what it reads.
+    if (!is_dist) {
+        for (uint32_t i = prim; i-- > 0;) {                                    // descending: entry i >> l1 <= i is rewritten only after i was
+            const uint32_t e1 = table[i], l1 = e1 & 15u;
+            if (((e1 >> 4) & 15u) != K_LIT || l1 >= tbits) continue;
+            const uint32_t e2 = table[i >> l1];
+            const uint32_t k2 = (e2 >> 4) & 15u;
+            // (e2 may already be a pair when i >> l1 == i, i.e. i = 0 and... l1 > 0 makes i >> l1 < i except for i = 0: entry 0 is
+            // handled last and reads itself before it is rewritten)
+            if (k2 != K_LIT || (e2 & 15u) > tbits - l1) continue;
+            table[i] = ENTRY(((e1 >> 16) & 255u) | (((e2 >> 16) & 255u) << 8), 0, K_LIT2, l1 + (e2 & 15u));
+        }
     }
     return 0;
 }
@@ -176,7 +192,13 @@ __device__ int block16(bits &b, const uint32_t *lt, const uint32_t *dt, uint16_t
         b.fill();
         uint32_t e = lt[b.peek(LB)];
         uint32_t kind = (e >> 4) & 15u;
-        if (kind == K_LIT) { b.drop(e & 15u); o[n++] = (uint16_t)(e >> 16); continue; }
+        if (kind <= K_LIT2) {
+            b.drop(e & 15u);
+            o[n] = (uint16_t)((e >> 16) & 255u);
+            o[n + 1] = (uint16_t)(e >> 24);                                    // (the second of a pair; overwritten by the next symbol otherwise)
+            n += 1u + (kind == K_LIT2);
+            continue;
+        }
         if (kind == K_SUB) {
             b.drop(LB);
             e = lt[(e >> 16) + b.peek((e >> 8) & 255u)];
@@ -220,18 +242,21 @@ __global__ void find_candidates(const uint32_t *__restrict__ comp32, uint64_t nw
     uint64_t hi = (base_byte + (uint64_t)(k + 1) * seg_bytes) * 8u;
     if (hi > total_bits) hi = total_bits;
     uint32_t n = 0;
-    for (uint64_t base = lo; base < hi; base += 64u) {                         // (wave-uniform)
-        const uint64_t bit = base + lane;
-        bool ok = bit < hi;
-        if (ok) {
-            const uint64_t wp = bit >> 5;
-            const uint32_t sh = (uint32_t)(bit & 31u);
-            const uint64_t w0 = wp < nwords ? comp32[wp] : 0u, w1 = wp + 1 < nwords ? comp32[wp + 1] : 0u, w2 = wp + 2 < nwords ? comp32[wp + 2] : 0u, w3 = wp + 3 < nwords ? comp32[wp + 3] : 0u;
-            const uint64_t a = ((w0 | (w1 << 32)) >> sh) | (sh ? (w2 << (64u - sh)) : 0ull);        // bits 0..63 from `bit`
-            const uint64_t b2 = ((w2 | (w3 << 32)) >> sh);                                            // bits 64.. (top sh bits missing: 74 - 64 = 10 needed, sh <= 31: fine)
+    for (uint64_t base = lo; base < hi; base += 256u) {                        // (wave-uniform) four bit positions per lane out of one set of loads
+        const uint64_t bit0 = base + 4u * lane;
+        const uint64_t wp = bit0 >> 5;
+        const uint32_t sh = (uint32_t)(bit0 & 31u);
+        const unsigned __int128 win = ((unsigned __int128)(wp + 3 < nwords ? comp32[wp + 3] : 0u) << 96) | ((unsigned __int128)(wp + 2 < nwords ? comp32[wp + 2] : 0u) << 64) |
+                                      ((unsigned __int128)(wp + 1 < nwords ? comp32[wp + 1] : 0u) << 32) | (unsigned __int128)(wp < nwords ? comp32[wp] : 0u);
+        bool ok[4];
+        unsigned long long m[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const unsigned __int128 x = win >> (sh + j);                       // >= 94 bits from position bit0 + j; 74 are looked at
+            const uint64_t a = (uint64_t)x, b2 = (uint64_t)(x >> 64);
             const uint32_t w = (uint32_t)a & 0x1FFFFu;
-            ok = (w & 7u) == 4u && ((w >> 3) & 31u) <= 29u && ((w >> 8) & 31u) <= 29u;
-            if (ok) {
+            ok[j] = bit0 + j < hi && (w & 7u) == 4u && ((w >> 3) & 31u) <= 29u && ((w >> 8) & 31u) <= 29u;
+            if (ok[j]) {
                 const uint32_t hclen = ((w >> 13) & 15u) + 4u;
                 uint32_t sum = 0;
                 for (uint32_t i = 0; i < hclen; i++) {
@@ -239,12 +264,16 @@ __global__ void find_candidates(const uint32_t *__restrict__ comp32, uint64_t nw
                     const uint32_t l = (uint32_t)(at + 3u <= 64u ? (a >> at) : at >= 64u ? (b2 >> (at - 64u)) : ((a >> at) | (b2 << (64u - at)))) & 7u;
                     if (l) sum += 128u >> l;
                 }
-                ok = sum == 128u;
+                ok[j] = sum == 128u;
             }
+            m[j] = __ballot(ok[j]);
         }
-        const unsigned long long m = __ballot(ok);
-        if (ok) { const uint32_t at = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); if (at < CANDMAX) cand[(size_t)k * CANDMAX + at] = (uint32_t)(bit - lo); }
-        n += (uint32_t)__popcll(m);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t at = n + (uint32_t)(__popcll(m[0] & below) + __popcll(m[1] & below) + __popcll(m[2] & below) + __popcll(m[3] & below));
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+            if (ok[j]) { if (at < CANDMAX) cand[(size_t)k * CANDMAX + at] = (uint32_t)(bit0 + j - lo); at++; }
+        n += (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
     }
     if (lane == 0) ncand[k] = n < CANDMAX ? n : CANDMAX;
 }
@@ -254,14 +283,16 @@ __global__ void find_candidates(const uint32_t *__restrict__ comp32, uint64_t nw
 // every lane of a wave met its true start in another iteration and the 64 first-block decodes of a wave ran one after the other.
 __global__ void validate(const uint32_t *__restrict__ comp32, uint64_t nwords, uint32_t seg_bytes, uint64_t base_byte, uint32_t nseg, uint32_t *cand, const uint32_t *__restrict__ ncand)
 {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t k = (uint32_t)(idx / CANDMAX), c = (uint32_t)(idx % CANDMAX);
-    if (k >= nseg || k == 0 || c >= ncand[k]) return;
-    uint8_t lens[320];
-    uint32_t hlit, hdist;
-    bits b; b.w = comp32; b.nwords = nwords;
-    b.seek((base_byte + (uint64_t)k * seg_bytes) * 8u + cand[(size_t)k * CANDMAX + c] + 3u);
-    if (read_lens(b, lens, hlit, hdist)) cand[(size_t)k * CANDMAX + c] |= 0x80000000u;
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;     // a wave per segment, its lanes over the list
+    if (k >= nseg || k == 0) return;
+    const uint32_t nc = ncand[k];
+    for (uint32_t c = lane; c < nc; c += 64u) {
+        uint8_t lens[320];
+        uint32_t hlit, hdist;
+        bits b; b.w = comp32; b.nwords = nwords;
+        b.seek((base_byte + (uint64_t)k * seg_bytes) * 8u + cand[(size_t)k * CANDMAX + c] + 3u);
+        if (read_lens(b, lens, hlit, hdist)) cand[(size_t)k * CANDMAX + c] |= 0x80000000u;
+    }
 }
 
 // lane per segment: its first candidate whose header stands up to every check and whose block decodes; then block after block until
@@ -411,7 +442,7 @@ int main(int argc, char **argv)
         CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(find_candidates, dim3((nseg + 3) / 4), dim3(256), 0, 0, d_comp, (uint64_t)nwords, total_bits, seg_bytes, (uint64_t)hdr, nseg, d_cand, d_ncand);
-        hipLaunchKernelGGL(validate, dim3((uint32_t)(((uint64_t)nseg * CANDMAX + 255) / 256)), dim3(256), 0, 0, d_comp, (uint64_t)nwords, seg_bytes, (uint64_t)hdr, nseg, d_cand, (const uint32_t *)d_ncand);
+        hipLaunchKernelGGL(validate, dim3((nseg + 3) / 4), dim3(256), 0, 0, d_comp, (uint64_t)nwords, seg_bytes, (uint64_t)hdr, nseg, d_cand, (const uint32_t *)d_ncand);
         CK(hipEventRecord(ea));
         hipLaunchKernelGGL(spec_decode, dim3((nseg + 63) / 64), dim3(64), 0, 0, d_comp, (uint64_t)nwords, first_bit, total_bits, seg_bytes, (uint64_t)hdr, nseg,
                            (const uint32_t *)d_cand, (const uint32_t *)d_ncand, d_tabs, d_sym, cap, d_out, getenv("FIRST_ONLY") ? 1 : 0, getenv("VLIMIT") ? (uint32_t)atoi(getenv("VLIMIT")) : 300000u);
