@@ -36,6 +36,7 @@
 #include "sk_gzpipe.h"
 #include "sk_cpus.h"
 #include "sk_rendezvous.h"
+#include "sk_internal.h"
 
 int sk_rendezvous_exchange(int rank, int world, const char *base_path, int my_status, unsigned char *payload128, double timeout_s)
 {
@@ -669,6 +670,7 @@ typedef struct {
     sk_ctx         *ctx;
     uint32_t        col;
     int             pipe;              /* fewer files than cores: each file's inflate gets a helper thread (> 1: that many) */
+    int             gpu_inflate;       /* SK_GPU_INFLATE=1: .gz items go through the device-side decoder first (experimental) */
     pthread_mutex_t submit_mu;         /* sk_scan_stream is one-caller-at-a-time per context */
     pthread_mutex_t queue_mu;
     scan_item      *item;              /* work list of this call (what this rank scans), in list order */
@@ -685,6 +687,8 @@ typedef struct {
     uint8_t   *pinned[2];
     uint64_t   ticket[2];
     int        used[2], cur;
+    sk_inflater *inf;                  /* SK_GPU_INFLATE=1: this worker's device-side gzip decoder ... */
+    uint8_t   *text; uint64_t text_cap;/* ... and the page-locked buffer its text lands in */
 } scan_worker;
 
 /* size of a worker's chunk buffer: SK_CHUNK_BYTES (4096 .. 63 MiB; tests use small ones: many flushes per file), default 32 MiB */
@@ -732,6 +736,8 @@ static int worker_init(scan_worker *w, scan_pool *p)
 
 static void worker_done(scan_worker *w)
 {
+    if (w->inf) sk_inflater_destroy(w->inf);
+    if (w->text) sk_pinned_free(w->pool->ctx, w->text);
     pthread_mutex_lock(&w->pool->submit_mu);
     if (w->pinned[0]) sk_pinned_free(w->pool->ctx, w->pinned[0]);      /* (synchronises the stream first) */
     if (w->pinned[1]) sk_pinned_free(w->pool->ctx, w->pinned[1]);
@@ -931,12 +937,80 @@ static int64_t parse_gz_split(scan_worker *w, const scan_item *it, uint64_t *bas
     return g.rc ? (int64_t)g.rc : g.nrec;
 }
 
+/* SK_GPU_INFLATE=1 (experimental): a .gz item of one member and dynamic blocks only is inflated ON THE DEVICE (sk_inflate.hip: the speculative
+ * scheme of sk_gzpar.h, a lane per 16 KiB segment; every guess checked, the chain checked here in the library, the CRC-32 here) and its text
+ * parsed by this thread.  -100: not such a file, or a check failed -- the caller decodes it on the host as before, so the bytes are zlib's
+ * either way. */
+static int64_t parse_gz_on_device(scan_worker *w, const scan_item *it, uint64_t *bases)
+{
+    int fd;
+    struct stat st;
+    const unsigned char *m;
+    uint64_t want, len = 0;
+    uint32_t crc = 0;
+    int rc;
+    if (!w->pool->gpu_inflate) return -100;
+    fd = open(it->path, O_RDONLY);
+    if (fd < 0) return -100;                              /* (the ordinary path reports it) */
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32) { close(fd); return -100; }
+    m = (const unsigned char *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return -100;
+    want = sk_inflate_gz_size(m, (uint64_t)st.st_size);
+    if (!want) {
+        if (w->pool->gpu_inflate > 1 && m[0] == 0x1f && m[1] == 0x8b) fprintf(stderr, "%s: left to the host decoder (not one member of a size the device path takes)\n", it->path);
+        munmap((void *)m, (size_t)st.st_size);
+        return -100;
+    }
+    if (!w->inf && sk_inflater_create(sk_ctx_device_(w->pool->ctx), &w->inf) != SK_OK) { w->inf = NULL; munmap((void *)m, (size_t)st.st_size); return -100; }
+    if (want > w->text_cap) {
+        const uint64_t cap = (want + (64u << 20)) & ~(uint64_t)((64u << 20) - 1);      /* (few distinct sizes: the context keeps what is given back) */
+        if (w->text) sk_pinned_free(w->pool->ctx, w->text);
+        w->text = NULL; w->text_cap = 0;
+        if (sk_pinned_alloc(w->pool->ctx, (void **)&w->text, cap) != SK_OK) { w->text = NULL; munmap((void *)m, (size_t)st.st_size); return -100; }
+        w->text_cap = cap;
+    }
+    {
+        const double t0 = now_s();
+        double t1;
+        rc = sk_inflate_gz(w->inf, m, (uint64_t)st.st_size, w->text, w->text_cap, &len, &crc);
+        munmap((void *)m, (size_t)st.st_size);
+        t1 = now_s();
+        if (rc == SK_OK) { pthread_once(&skz_crc_once, skz_crc_init); if (skz_crc32(0, w->text, (size_t)len) != crc) rc = SK_E_UNSUPPORTED; }
+        if (w->pool->gpu_inflate > 1)                      /* (SK_GPU_INFLATE=2: say which way every file went) */
+            fprintf(stderr, rc == SK_OK ? "%s: inflated on the device (%llu bytes of text; %.0f ms, CRC-32 %.0f ms)\n"
+                                        : "%s: left to the host decoder (a check of the device path did not hold)\n",
+                    it->path, (unsigned long long)len, (t1 - t0) * 1e3, (now_s() - t1) * 1e3);
+    }
+    if (rc != SK_OK) return -100;                         /* (unsupported, or a device hiccup: the host path decides what the file is) */
+    {
+        stream_writer sw;
+        parser ps;
+        int64_t nrec;
+        uint64_t at;
+        memset(&sw, 0, sizeof sw);
+        sw.cap = POOL_CHUNK; sw.sink = worker_sink; sw.user = w; sw.next_buf = worker_next_buf;
+        parser_init(&ps, writer_record, &sw);
+        for (at = 0; at < len && ps.state != P_STOP; at += 4u << 20) parser_feed(&ps, w->text + at, (size_t)(len - at < (4u << 20) ? len - at : (4u << 20)));
+        if (ps.state != P_STOP) parser_eof(&ps);
+        writer_flush(&sw);
+        *bases += sw.bases;
+        nrec = ps.nrecords;
+        parser_free(&ps);
+        return sw.rc ? (int64_t)sw.rc : nrec;
+    }
+}
+
 /* decode one item into the worker's pinned buffers; returns records or a negative SK_E_* */
 static int64_t worker_item(scan_worker *w, const scan_item *it, uint64_t *bases)
 {
     stream_writer sw;
     int64_t nrec = 0;
     int rc;
+    if (!it->ranged) {
+        const int64_t r = parse_gz_on_device(w, it, bases);
+        if (r != -100) return r;
+    }
     if (!it->ranged && w->pool->pipe > 1 && !getenv("SK_NO_SPLIT") && !getenv("SK_ZLIB")) {
         const int64_t r = parse_gz_split(w, it, bases);
         if (r != -100) return r;
@@ -1120,6 +1194,7 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
         if (pool.pipe && pool.nitem && nthreads / (int)pool.nitem >= 3) pool.pipe = nthreads / (int)pool.nitem;
         if (gzt && nthreads > 1) pool.pipe = atoi(gzt) < 1 ? 1 : atoi(gzt);
         if (pool.pipe > 16) pool.pipe = 16;
+        pool.gpu_inflate = getenv("SK_GPU_INFLATE") ? atoi(getenv("SK_GPU_INFLATE")) : 0;
     }
     if (nthreads == 1) {                                      /* strict sequence, as the reference */
         scan_worker seq;

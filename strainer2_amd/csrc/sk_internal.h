@@ -21,6 +21,15 @@ void skc_destroy(skc_acc *a);
 int skc_add_hit(skc_acc *a, const char *metagenome, int64_t hits_pe1, int64_t hits_pe2, uint32_t row);
 int skc_add_trailer(skc_acc *a, const char *metagenome, const char *name, int64_t value);
 int skc_report(skc_acc *a, sk_ctx *ctx, const char *hits_file_name, FILE *out, FILE *err);
+/* gzip on the device (sk_inflate.hip; experimental, SK_GPU_INFLATE=1).  SK_E_UNSUPPORTED: not a file this path takes, or a check failed --
+ * the caller decodes it on the host as before. */
+#define SK_E_UNSUPPORTED -100
+typedef struct sk_inflater sk_inflater;
+int  sk_inflater_create(int device, sk_inflater **out);
+void sk_inflater_destroy(sk_inflater *f);
+const char *sk_inflater_error(const sk_inflater *f);
+uint64_t sk_inflate_gz_size(const uint8_t *gz, uint64_t n);
+int  sk_inflate_gz(sk_inflater *f, const uint8_t *gz, uint64_t n, uint8_t *host_text, uint64_t host_cap, uint64_t *text_len, uint32_t *trailer_crc);
 #ifdef __cplusplus
 }
 #endif

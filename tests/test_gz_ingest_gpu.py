@@ -79,3 +79,33 @@ def test_same_hit_list_from_text_one_thread_and_four(world, tmp_path, plain, pac
     assert _detect(world, packed, {"SK_GZ_THREADS": "1"}, tmp_path / "b.gz") == want
     assert _detect(world, packed, {"SK_GZ_THREADS": "4"}, tmp_path / "c.gz") == want
     assert _detect(world, packed, {}, tmp_path / "d.gz") == want
+
+
+def test_same_table_with_the_inflate_on_the_device(world, tmp_path):
+    """SK_GPU_INFLATE=1 (experimental, sk_inflate.hip): a .gz of one member and dynamic blocks is inflated on the device -- speculative
+    segment starts, every guess and the chain of segments checked, CRC-32 checked -- and must give the table the text gives; anything
+    the device path does not take (a file cut short, two members, stored blocks, a flipped bit, FASTA with long lines) goes to the
+    host decoder as before, with the same result as without the switch."""
+    import zlib
+    d = world
+    want = _count(d, "reads.fq", {"SK_THREADS": "4"})
+    got = _count(d, "reads.fq.gz", {"SK_THREADS": "4", "SK_GPU_INFLATE": "2"})
+    assert got[0] == want[0] and got[1].count(b"inflated on the device") == 2          # (the -A and the -B list name the file)
+    text = (d / "reads.fq").read_bytes()
+    cases = {}
+    cases["two_members.fq.gz"] = gzip.compress(text[:len(text) // 2], 6, mtime=0) + gzip.compress(text[len(text) // 2:], 6, mtime=0)
+    cases["stored.fq.gz"] = gzip.compress(text[:3_000_000], 0, mtime=0)
+    cases["level9.fq.gz"] = gzip.compress(text, 9, mtime=0)
+    blob = bytearray(gzip.compress(text, 4, mtime=0))
+    blob[len(blob) // 2] ^= 0x10
+    cases["flipped.fq.gz"] = bytes(blob)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    cases["flushed.fq.gz"] = co.compress(text[:5_000_000]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(text[5_000_000:]) + co.flush()   # an empty stored block inside
+    for name, data in cases.items():
+        (d / name).write_bytes(data)
+        a = _count(d, name, {"SK_THREADS": "4"})
+        b = _count(d, name, {"SK_THREADS": "4", "SK_GPU_INFLATE": "2"})
+        assert a[0] == b[0], name
+        assert (b"inflated on the device" in b[1]) == (name == "level9.fq.gz") and b"left to the host decoder" in b[1] or name == "level9.fq.gz", (name, b[1][-300:])
+    assert _count(d, "level9.fq.gz", {"SK_THREADS": "4", "SK_GPU_INFLATE": "1"})[0] == want[0]
+    assert _count(d, "cut.fq.gz", {"SK_THREADS": "4", "SK_GPU_INFLATE": "1"}) == _count(d, "cut.fq", {"SK_THREADS": "4"})
