@@ -92,6 +92,9 @@ def test_same_table_with_the_inflate_on_the_device(world, tmp_path):
     got = _count(d, "reads.fq.gz", {"SK_THREADS": "4", "SK_GPU_INFLATE": "2"})
     assert got[0] == want[0] and got[1].count(b"inflated on the device") == 2          # (the -A and the -B list name the file)
     text = (d / "reads.fq").read_bytes()
+    text = text[:text.rfind(b"\n@read", 0, 24_000_000) + 1]        # (a third of it is plenty for the variants)
+    (d / "part.fq").write_bytes(text)
+    want_part = _count(d, "part.fq", {"SK_THREADS": "4"})
     cases = {}
     cases["two_members.fq.gz"] = gzip.compress(text[:len(text) // 2], 6, mtime=0) + gzip.compress(text[len(text) // 2:], 6, mtime=0)
     cases["stored.fq.gz"] = gzip.compress(text[:3_000_000], 0, mtime=0)
@@ -107,5 +110,5 @@ def test_same_table_with_the_inflate_on_the_device(world, tmp_path):
         b = _count(d, name, {"SK_THREADS": "4", "SK_GPU_INFLATE": "2"})
         assert a[0] == b[0], name
         assert (b"inflated on the device" in b[1]) == (name == "level9.fq.gz") and b"left to the host decoder" in b[1] or name == "level9.fq.gz", (name, b[1][-300:])
-    assert _count(d, "level9.fq.gz", {"SK_THREADS": "4", "SK_GPU_INFLATE": "1"})[0] == want[0]
+    assert _count(d, "level9.fq.gz", {"SK_THREADS": "4", "SK_GPU_INFLATE": "1"})[0] == want_part[0]
     assert _count(d, "cut.fq.gz", {"SK_THREADS": "4", "SK_GPU_INFLATE": "1"}) == _count(d, "cut.fq", {"SK_THREADS": "4"})
