@@ -61,6 +61,7 @@ extern "C" {
 #define SK_E_STATE      -7   /* call out of order (e.g. scan before table load)              */
 #define SK_E_RCCL       -8
 #define SK_E_SPLIT      -9   /* a big text file could not be cut at record boundaries: the run fails rather than count something else */
+#define SK_E_PLAN       -10  /* the ranks of a multi-GPU run computed different work plans for a list: every rank leaves */
 
 typedef struct sk_ctx sk_ctx;
 
@@ -213,6 +214,9 @@ int  sk_comm_init_ex(sk_ctx *ctx, int rank, int world, const char *id_file, int 
 int  sk_rendezvous_exchange(int rank, int world, const char *base_path, int my_status, unsigned char *payload128, double timeout_s);
 void sk_comm_destroy(sk_ctx *ctx);
 int  sk_comm_sum_u32(sk_ctx *ctx, uint32_t value, uint32_t *sum);
+/* *agree = 1 iff every rank passed the same value (one max all-reduce of {v, ~v}); without a communicator: 1.
+ * skh_scan_list uses it to compare the ranks' work plans before any of them scans. */
+int  sk_comm_agree_u64(sk_ctx *ctx, uint64_t value, int *agree);
 int  sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);
 
 /* Device-side timing of the scan kernel, from HIP events recorded on the context's stream
@@ -276,12 +280,25 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases);
 /* Walk a newline-separated file list.  `skip` (may be NULL): a line equal to it is not
  * scanned and "skipping %s (identical match)" goes to `err`.  `progress` (may be NULL) gets
  * "<line>\t<asctime>".  On an unreadable list or file the reference's message is written to
- * `err` and SK_E_OPEN returned.  Lines with index % world != rank are logged but left to
- * other ranks (world=1, rank=0 for the single-GPU program).
+ * `err` and SK_E_OPEN returned (the progress file then ends with the unreadable file's line and no later
+ * skip message is printed, as in the reference, which exits there).  With world > 1 the list's items -- files,
+ * or byte ranges of big plain-text files -- are dealt to the ranks by size and this rank scans its own; rank 0
+ * writes the progress file and the messages (world=1, rank=0 for the single-GPU program).
  * Replaces GEN_all_kmer_counts(): src/genome_compare.c:149-177 and
  * GEN_all_kmer_counts_skip_file(): src/genome_compare.c:115-146. */
 int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col,
                   FILE *progress, FILE *err, uint32_t rank, uint32_t world, uint64_t *bases);
+/* Hash of the work plan skh_scan_list(list, skip, .., world) follows (items, byte ranges, file sizes, owners): a function
+ * of the list, the files and `world` (and of SK_SPLIT_BYTES / SK_NO_SPLIT) only, never of a rank's thread count.  With the
+ * library's own communicator skh_scan_list compares it across ranks itself (SK_E_PLAN); a caller that reduces the counters
+ * through a collective of its own (torch.distributed) compares this value first.  New (the reference is one process). */
+int skh_list_plan_hash(const char *list_path, const char *skip, uint32_t world, uint64_t *hash);
+/* The same plan, line by line: owner[i] = the rank that scans list line i, SKH_PLAN_SKIPPED for the line equal to `skip`,
+ * SKH_PLAN_SHARED for a big plain-text file whose byte ranges go to several ranks; *nlines = lines in the list (owner[]
+ * is filled up to `cap`). */
+#define SKH_PLAN_SKIPPED 0xFFFFFFFFu
+#define SKH_PLAN_SHARED  0xFFFFFFFEu
+int skh_list_plan_owners(const char *list_path, const char *skip, uint32_t world, uint32_t *owner, uint32_t cap, uint32_t *nlines);
 
 /* Print the TSV: src/kmer_scrub_count.c:134-156 (5 header names always; 4 or 5 fields). */
 int skh_print_counts(sk_ctx *ctx, const skh_keyset *ks, FILE *out, int with_drug_column);

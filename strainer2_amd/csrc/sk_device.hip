@@ -62,6 +62,7 @@
 #define SK_NCHUNK_GRID  (SK_NCHUNK + 1)
 #define SK_AGG_LOG2     8
 #define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
+#define SK_EV_PAIRS     64u                 // launches whose timing events are kept before they are added up
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
 #ifndef SK_SHIFTED_TEST
 #define SK_SHIFTED_TEST 0                   // phase 2: ask the level-1 filter about the half-shifted 16-mers before level 2.  Measured
@@ -1449,7 +1450,8 @@ struct sk_ctx {
     uint32_t    *d_flags;
     uint32_t    *d_oddlist;           // chunks with a byte for the byte-string kernel (SK_ODDCAP entries)
     // timing
-    std::vector<hipEvent_t> ev;        // begin/end pairs
+    std::vector<hipEvent_t> ev;        // begin/end pairs of launches not yet added up: a ring of at most SK_EV_PAIRS
+    std::vector<hipEvent_t> ev_free;   // pairs that have been added up, for the next launches
     double       timed_ms;
     uint64_t     timed_launches;
     // options
@@ -1505,6 +1507,7 @@ extern "C" const char *sk_strerror(int code)
     case SK_E_STATE: return "call out of order";
     case SK_E_RCCL: return "RCCL error";
     case SK_E_SPLIT: return "a file could not be cut at record boundaries";
+    case SK_E_PLAN: return "the ranks computed different work plans";
     default: return "unknown error";
     }
 }
@@ -1592,6 +1595,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
         if (c->stage_done[i]) hipEventDestroy(c->stage_done[i]);
     }
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_free) hipEventDestroy(e);
     for (int i = 0; i < 64; i++) if (c->copied[i]) hipEventDestroy(c->copied[i]);
     if (c->own_batch) sk_batch_destroy(c->own_batch);
     hipFree(c->t_tally); hipFree(c->t_hits); hipFree(c->t_compact);
@@ -1614,7 +1618,13 @@ extern "C" int sk_set_option(sk_ctx *c, const char *name, long value)
     if (!strcmp(name, "dev_alloc_uncached")) { c->dev_uncached = value != 0; return SK_OK; }
     if (!strcmp(name, "text_stage")) { c->no_text = value == 0; return SK_OK; }
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 2) return SK_E_ARG; c->pipeline = value; return SK_OK; }
+#ifdef SK_EXPERIMENTS
     if (!strcmp(name, "ablate")) { c->ablate = value; return SK_OK; }
+#else
+    // the timing variants of the hot kernel that leave memory stages out (some of them count wrongly) are compiled
+    // only into an experiments build (make EXPERIMENTS=1): the product library has no switch that changes a count
+    if (!strcmp(name, "ablate")) return value == 0 ? SK_OK : sk_fail(c, SK_E_ARG, "option \"ablate\" needs a library built with make EXPERIMENTS=1");
+#endif
     return sk_fail(c, SK_E_ARG, "unknown option %s", name);
 }
 
@@ -1831,13 +1841,29 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     if (!c->d_grid1) return sk_fail(c, SK_E_STATE, "no table loaded");
 
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(uint32_t), c->stream));     // [0] odd bytes seen, [2] listed chunks
+    // timing: a begin/end event pair per launch from a small ring -- the oldest pair is added to the totals (its launch is
+    // long over, SK_EV_PAIRS launches later) and used again, so a program that never asks for the timing holds 128 events,
+    // not two per launch
     hipEvent_t e0 = NULL, e1 = NULL;
-    const bool timed = c->ev.size() < 2 * 8192;
-    if (timed) {
+    const bool timed = true;
+    if (c->ev.size() >= 2 * SK_EV_PAIRS) {
+        float ms = 0.f;
+        SK_HIP(c, hipEventSynchronize(c->ev[1]));
+        SK_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->timed_ms += ms;
+        c->timed_launches++;
+        c->ev_free.push_back(c->ev[0]);
+        c->ev_free.push_back(c->ev[1]);
+        c->ev.erase(c->ev.begin(), c->ev.begin() + 2);
+    }
+    if (c->ev_free.size() >= 2) {
+        e1 = c->ev_free.back(); c->ev_free.pop_back();
+        e0 = c->ev_free.back(); c->ev_free.pop_back();
+    } else {
         SK_HIP(c, hipEventCreate(&e0));
         SK_HIP(c, hipEventCreate(&e1));
-        SK_HIP(c, hipEventRecord(e0, c->stream));
     }
+    SK_HIP(c, hipEventRecord(e0, c->stream));
     // The partitioned pipeline (the level-1 question answered from LDS) is an experiment kept selectable (option
     // "pipeline" = 2; parity-tested): as measured it LOSES to the single kernel (0.43 against 0.34 ms per 0.6 Gbase at
     // 2 % strain reads; profiles/r02_lds_pipeline.txt) -- its one full pass over the stream plus the
@@ -1879,17 +1905,21 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     if (tally_sink && tally_sink->ns)
         hipLaunchKernelGGL((sk_scan_grid<true, 0, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, c->d_flags, d_cand);
     else if (piped && tally_sink) SK_LAUNCH_GRID(true, 0, true);
+#ifdef SK_EXPERIMENTS
     else if (piped && c->ablate == 7) SK_LAUNCH_GRID(false, 7, true);
     else if (piped && c->ablate == 8) SK_LAUNCH_GRID(false, 8, true);
     else if (piped && c->ablate == 9) SK_LAUNCH_GRID(false, 9, true);
+#endif
     else if (piped)          SK_LAUNCH_GRID(false, 0, true);
     else if (tally_sink)     SK_LAUNCH_GRID(true, 0, false);
+#ifdef SK_EXPERIMENTS
     else if (c->ablate == 1) SK_LAUNCH_GRID(false, 1, false);
     else if (c->ablate == 2) SK_LAUNCH_GRID(false, 2, false);
     else if (c->ablate == 3) SK_LAUNCH_GRID(false, 3, false);
     else if (c->ablate == 4) SK_LAUNCH_GRID(false, 4, false);
     else if (c->ablate == 5) SK_LAUNCH_GRID(false, 5, false);
     else if (c->ablate == 6) SK_LAUNCH_GRID(false, 6, false);
+#endif
     else                     SK_LAUNCH_GRID(false, 0, false);
 #undef SK_LAUNCH_GRID
     if (timed) {
@@ -2613,8 +2643,8 @@ extern "C" int sk_scan_timing(sk_ctx *c, double *total_ms, uint64_t *launches, i
         SK_HIP(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
         c->timed_ms += ms;
         c->timed_launches++;
-        hipEventDestroy(c->ev[i]);
-        hipEventDestroy(c->ev[i + 1]);
+        c->ev_free.push_back(c->ev[i]);
+        c->ev_free.push_back(c->ev[i + 1]);
     }
     c->ev.clear();
     if (total_ms) *total_ms = c->timed_ms;
@@ -2733,6 +2763,25 @@ extern "C" int sk_comm_sum_u32(sk_ctx *c, uint32_t value, uint32_t *sum)
     if (g_rccl.allreduce(d, d, 1, ncclUint32, ncclSum, c->comm, c->stream) != 0) return sk_fail(c, SK_E_RCCL, "ncclAllReduce failed");
     SK_HIP(c, hipMemcpyAsync(sum, d, 4, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(c, hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+// Do all ranks hold the same 64-bit value (a hash of the work plan, before anyone scans)?  One max all-reduce over
+// {v, ~v}: the values agree iff max(v) == min(v) == ~max(~v).  No communicator: a world of one agrees with itself.
+extern "C" int sk_comm_agree_u64(sk_ctx *c, uint64_t value, int *agree)
+{
+    if (!agree) return SK_E_ARG;
+    *agree = 1;
+    if (!c || !c->comm) return SK_OK;
+    SK_HIP(c, hipSetDevice(c->device));
+    uint64_t *d = (uint64_t *)(c->d_flags + 12);      // spare words of the flag block (8-byte aligned: 48 bytes in)
+    uint64_t h[2] = {value, ~value};
+    SK_HIP(c, hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, c->stream));
+    const int ncclUint64 = 5, ncclMax = 2;            // rccl.h: ncclDataType_t / ncclRedOp_t
+    if (g_rccl.allreduce(d, d, 2, ncclUint64, ncclMax, c->comm, c->stream) != 0) return sk_fail(c, SK_E_RCCL, "ncclAllReduce failed");
+    SK_HIP(c, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    *agree = h[0] == value && h[1] == ~value;         // (max v == v and min v == v on this rank <=> on every rank)
     return SK_OK;
 }
 

@@ -666,6 +666,10 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases)
  * CHECKED, not assumed (parse_range). */
 typedef struct { char *path; uint64_t a, b, size; uint32_t line; int ranged; } scan_item;
 
+/* one line of the list as the reference reports it: "<line>\t<time>" in the progress file just before the file is opened
+ * (src/genome_compare.c:133-136,167-170), "skipping ..." on stderr for the -C line that equals -r (:138-141) */
+typedef struct { char *text; int skipped; long end; } list_line;
+
 typedef struct {
     sk_ctx         *ctx;
     uint32_t        col;
@@ -678,7 +682,22 @@ typedef struct {
     int             rc;                /* first failure ...                                         */
     uint32_t        rc_index;          /* ... and the item it belongs to                            */
     uint64_t        bases;
+    FILE           *progress;          /* rank 0's progress file (or NULL) ...                      */
+    list_line      *ll;                /* ... the list's lines ...                                  */
+    uint32_t        nll, ll_next;      /* ... and the first one not yet written there               */
 } scan_pool;
+
+/* The progress file gets a list line when a decode thread TAKES the line's (first) item, and every line before it that is
+ * not there yet -- the reference writes the line, then opens the file.  Called under queue_mu (or from the one thread). */
+static void progress_upto(scan_pool *p, uint32_t line)
+{
+    if (!p->progress) { if (line + 1 > p->ll_next) p->ll_next = line + 1; return; }
+    for (; p->ll_next <= line && p->ll_next < p->nll; p->ll_next++) {
+        time_t now = time(NULL);
+        fprintf(p->progress, "%s\t%s", p->ll[p->ll_next].text, asctime(localtime(&now)));
+        p->ll[p->ll_next].end = ftell(p->progress);
+    }
+}
 
 /* one decode worker: two pinned chunk buffers filled in turn; a buffer is rewritten only after the
  * DMA that read it has finished (ticket) */
@@ -1042,6 +1061,7 @@ static void *pool_worker(void *arg)
         i = p->next;
         if (i >= p->nitem || p->rc != SK_OK) { pthread_mutex_unlock(&p->queue_mu); break; }
         p->next++;
+        progress_upto(p, p->item[i].line);
         pthread_mutex_unlock(&p->queue_mu);
         rc = wrc != SK_OK ? wrc : worker_item(&w, &p->item[i], &bases);
         pthread_mutex_lock(&p->queue_mu);
@@ -1080,18 +1100,48 @@ static void plan_owners(const scan_item *items, const uint64_t *est, uint32_t n,
     free(k); free(load);
 }
 
-int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
-                  FILE *err, uint32_t rank, uint32_t world, uint64_t *bases)
+/* FNV-1a over everything the ranks must agree on: the items (path, byte range, size as seen by stat) and their owners */
+static uint64_t fnv_bytes(uint64_t h, const void *p, size_t n)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    while (n--) { h ^= *b++; h *= 0x100000001B3ull; }
+    return h;
+}
+static uint64_t plan_digest(const scan_item *items, const uint32_t *owner, uint32_t n, uint32_t world)
+{
+    uint64_t h = 0xCBF29CE484222325ull;
+    uint32_t i;
+    h = fnv_bytes(h, &n, sizeof n);
+    h = fnv_bytes(h, &world, sizeof world);
+    for (i = 0; i < n; i++) {
+        const uint32_t rg = (uint32_t)items[i].ranged;
+        h = fnv_bytes(h, items[i].path, strlen(items[i].path) + 1);
+        h = fnv_bytes(h, &items[i].a, sizeof items[i].a);
+        h = fnv_bytes(h, &items[i].b, sizeof items[i].b);
+        h = fnv_bytes(h, &items[i].size, sizeof items[i].size);
+        h = fnv_bytes(h, &items[i].line, sizeof items[i].line);
+        h = fnv_bytes(h, &rg, sizeof rg);
+        h = fnv_bytes(h, &owner[i], sizeof owner[i]);
+    }
+    return h;
+}
+
+#define SK_PLAN_LANES 16u     /* decode lanes per rank the multi-rank plan is laid out for (the programs' thread cap) */
+
+typedef struct { uint64_t *hash; uint32_t *owner; uint32_t cap, *nlines; } plan_report;
+
+static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
+                          FILE *err, uint32_t rank, uint32_t world, uint64_t *bases, int plan_only, const plan_report *report)
 {
     FILE *fp = fopen(list_path, "r");
     char *line = NULL, *nl;
     size_t cap = 0;
-    uint32_t nline = 0, nall = 0, acap = 0, i;
+    uint32_t nline = 0, nall = 0, acap = 0, lcap = 0, i;
     int nthreads = 1;
     const char *env = getenv("SK_THREADS");
     scan_pool pool;
     scan_item *all = NULL;
-    uint64_t *est = NULL, total = 0;
+    uint64_t *est = NULL, total = 0, plan_hash = 0;
     uint32_t *owner = NULL;
     if (!fp) {
         if (err) fprintf(err, "could not read file %s in GEN_all_kmer_counts()\n", list_path);
@@ -1107,18 +1157,16 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     else { long n = sk_cpu_budget(); nthreads = n > 16 ? 16 : (int)n; }
     if (nthreads < 1) nthreads = 1;
 
-    /* the reference logs "<line>\t<time>" before it scans each file (src/genome_compare.c:167-170);
-     * with a pool the time is the time of the list walk */
+    /* the list's lines; what the reference says about each of them (progress line, skip message) is said in list
+     * order: the progress line when a decode thread takes the line's file, the skip messages behind the scans */
     while (getline(&line, &cap, fp) != -1) {
         struct stat st;
         if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
-        if (progress && rank == 0) {
-            time_t now = time(NULL);
-            fprintf(progress, "%s\t%s", line, asctime(localtime(&now)));
-        }
+        if (nline == lcap) { lcap = lcap ? lcap * 2 : 64; pool.ll = (list_line *)realloc(pool.ll, lcap * sizeof *pool.ll); }
+        memset(&pool.ll[nline], 0, sizeof pool.ll[nline]);
+        pool.ll[nline].text = strdup(line);
         if (skip && strcmp(skip, line) == 0) {
-            if (err && rank == 0) fprintf(err, "skipping %s (identical match)\n", line);
-            nline++;
+            pool.ll[nline++].skipped = 1;
             continue;
         }
         if (nall == acap) { acap = acap ? acap * 2 : 64; all = (scan_item *)realloc(all, acap * sizeof *all); }
@@ -1130,11 +1178,17 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     }
     free(line);
     fclose(fp);
+    pool.nll = nline;
+    pool.progress = rank == 0 ? progress : NULL;
 
-    /* cut big plain-text files into pieces (never with one thread and one rank: that is the reference's strict sequence) */
+    /* cut big plain-text files into pieces (never with one thread and one rank: that is the reference's strict sequence).
+     * With several ranks the plan must be the SAME on every rank, so it is a function of the list, the files' sizes and
+     * the world size only: a fixed number of decode lanes per rank stands in for the local thread count (which follows
+     * SK_THREADS, the cgroup quota, LOCAL_WORLD_SIZE ... and may differ from rank to rank) -- and the ranks compare a
+     * hash of their plans before any of them scans (below). */
     {
-        const uint64_t lanes = (uint64_t)world * (uint64_t)(nthreads > 1 ? nthreads : 1);
-        uint64_t target;
+        const uint64_t lanes = world > 1 ? (uint64_t)world * SK_PLAN_LANES : (uint64_t)(nthreads > 1 ? nthreads : 1);
+        uint64_t target, floor_bytes = 32u << 20;
         uint32_t n0 = nall, out = 0;
         scan_item *cut;
         uint64_t *gz = (uint64_t *)calloc((size_t)nall + 1, sizeof *gz);
@@ -1146,7 +1200,8 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
             total += gz[i] ? all[i].size * 4 : all[i].size;           /* (a .gz FASTQ inflates about fourfold) */
         }
         target = total / (4 * lanes);
-        if (target < (32u << 20)) target = 32u << 20;
+        if ((env = getenv("SK_SPLIT_FLOOR_BYTES")) != NULL && atoll(env) > 0) floor_bytes = (uint64_t)atoll(env);   /* (tests) */
+        if (target < floor_bytes) target = floor_bytes;
         if ((env = getenv("SK_SPLIT_BYTES")) != NULL && atoll(env) > 0) target = (uint64_t)atoll(env);     /* (tests) */
         {   /* how many items there will be */
             size_t total_items = 0;
@@ -1178,6 +1233,32 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     }
     owner = (uint32_t *)malloc(((size_t)nall + 1) * sizeof *owner);
     plan_owners(all, est, nall, world, owner);
+    plan_hash = plan_digest(all, owner, nall, world);
+    if (report && report->hash) *report->hash = plan_hash;
+    if (report && report->nlines) *report->nlines = nline;
+    if (report && report->owner) {                        /* who scans which list line (SKH_PLAN_SKIPPED / SKH_PLAN_SHARED) */
+        for (i = 0; i < nline && i < report->cap; i++) report->owner[i] = SKH_PLAN_SKIPPED;
+        for (i = 0; i < nall; i++)
+            if (all[i].line < report->cap) {
+                uint32_t *o = &report->owner[all[i].line];
+                *o = *o == SKH_PLAN_SKIPPED || *o == owner[i] ? owner[i] : SKH_PLAN_SHARED;
+            }
+    }
+    if (world > 1 && !plan_only) {
+        /* local settings that change the plan (SK_SPLIT_BYTES, SK_NO_SPLIT) or a file whose size another rank sees
+         * differently would have byte ranges scanned twice or never and the summed table silently wrong: every rank
+         * leaves instead.  (Without an in-library communicator -- a caller that reduces the counters itself -- the
+         * caller compares skh_list_plan_hash() through its own collective.) */
+        int same = 1;
+        const int arc = sk_comm_agree_u64(ctx, plan_hash, &same);
+        if (arc != SK_OK || !same) {
+            if (err) fprintf(err, "kmer_scrub_count: the ranks computed different work plans for %s (rank %u: %016llx) -- check "
+                                  "SK_SPLIT_BYTES / SK_NO_SPLIT and that every rank sees the same files; nothing is reported\n",
+                             list_path, rank, (unsigned long long)plan_hash);
+            pool.rc = arc != SK_OK ? arc : SK_E_PLAN;
+            plan_only = 1;                                /* (fall through to the clean-up) */
+        }
+    }
     pool.item = (scan_item *)malloc(((size_t)nall + 1) * sizeof *pool.item);
     for (i = 0; i < nall; i++) {
         if (owner[i] == rank) pool.item[pool.nitem++] = all[i];
@@ -1196,13 +1277,17 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
         if (pool.pipe > 16) pool.pipe = 16;
         pool.gpu_inflate = getenv("SK_GPU_INFLATE") ? atoi(getenv("SK_GPU_INFLATE")) : 0;
     }
-    if (nthreads == 1) {                                      /* strict sequence, as the reference */
+    if (plan_only) {
+        /* nothing is scanned */
+    } else if (nthreads == 1) {                               /* strict sequence, as the reference */
         scan_worker seq;
         int seq_rc = SK_OK;
         if (pool.nitem) seq_rc = worker_init(&seq, &pool);
         for (i = 0; i < pool.nitem; i++) {
             uint64_t b = 0;
-            const int64_t rc = seq_rc != SK_OK ? seq_rc : worker_item(&seq, &pool.item[i], &b);
+            int64_t rc;
+            progress_upto(&pool, pool.item[i].line);
+            rc = seq_rc != SK_OK ? seq_rc : worker_item(&seq, &pool.item[i], &b);
             pool.bases += b;
             if (rc < 0) { pool.rc = (int)rc; pool.rc_index = i; break; }
         }
@@ -1215,7 +1300,26 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
         for (i = 0; i < (uint32_t)nthreads; i++) pthread_join(th[i], NULL);
         free(th);
     }
-    if (pool.rc == SK_E_OPEN) {
+    if (!plan_only) {
+        /* What the reference has said by now.  All went well: every progress line, every skip message.  A file could not be
+         * opened: it stopped right there (src/genome_compare.c:195-198) -- the progress file ends with that file's line
+         * (lines of later files that other decode threads had taken meanwhile are cut off again) and no skip message of a
+         * later line was printed.  (With several ranks only rank 0 writes, and knows only of its own failures.) */
+        uint32_t upto = pool.nll;
+        if (pool.rc == SK_E_OPEN) upto = pool.item[pool.rc_index].line + 1;
+        if (pool.rc == SK_OK || pool.rc == SK_E_OPEN) {
+            if (upto) progress_upto(&pool, upto - 1);
+            if (pool.progress && upto < pool.ll_next && upto > 0 && fflush(pool.progress) == 0 &&
+                ftruncate(fileno(pool.progress), (off_t)pool.ll[upto - 1].end) == 0)
+                fseek(pool.progress, pool.ll[upto - 1].end, SEEK_SET);
+        }
+        if (err && rank == 0)
+            for (i = 0; i < upto; i++)
+                if (pool.ll[i].skipped) fprintf(err, "skipping %s (identical match)\n", pool.ll[i].text);
+    }
+    if (plan_only) {
+        /* (said above, or nothing to say) */
+    } else if (pool.rc == SK_E_OPEN) {
         if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", pool.item[pool.rc_index].path);
     } else if (pool.rc == SK_E_SPLIT) {
         if (err) fprintf(err, "kmer_scrub_count: %s could not be cut at record boundaries (bytes %llu-%llu): nothing is reported; "
@@ -1227,10 +1331,32 @@ int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t
     }
     for (i = 0; i < pool.nitem; i++) free(pool.item[i].path);
     free(pool.item);
+    for (i = 0; i < pool.nll; i++) free(pool.ll[i].text);
+    free(pool.ll);
     pthread_mutex_destroy(&pool.submit_mu);
     pthread_mutex_destroy(&pool.queue_mu);
     if (bases) *bases += pool.bases;
     return pool.rc;
+}
+
+int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
+                  FILE *err, uint32_t rank, uint32_t world, uint64_t *bases)
+{
+    return scan_list_impl(ctx, list_path, skip, col, progress, err, rank, world, bases, 0, NULL);
+}
+
+int skh_list_plan_hash(const char *list_path, const char *skip, uint32_t world, uint64_t *hash)
+{
+    plan_report rp = {hash, NULL, 0, NULL};
+    if (!list_path || !hash) return SK_E_ARG;
+    return scan_list_impl(NULL, list_path, skip, 0, NULL, NULL, 0, world ? world : 1, NULL, 1, &rp);
+}
+
+int skh_list_plan_owners(const char *list_path, const char *skip, uint32_t world, uint32_t *owner, uint32_t cap, uint32_t *nlines)
+{
+    plan_report rp = {NULL, owner, cap, nlines};
+    if (!list_path || !nlines || (cap && !owner)) return SK_E_ARG;
+    return scan_list_impl(NULL, list_path, skip, 0, NULL, NULL, 0, world ? world : 1, NULL, 1, &rp);
 }
 
 /* =========================================================================================
@@ -1319,8 +1445,9 @@ static int env_int(const char *a, const char *b, const char *c3, int dflt)
  *   SK_WORLD_SIZE | WORLD_SIZE | OMPI_COMM_WORLD_SIZE,  SK_RANK | RANK | OMPI_COMM_WORLD_RANK,
  *   SK_LOCAL_RANK | LOCAL_RANK | OMPI_COMM_WORLD_LOCAL_RANK (HIP device; SK_DEVICE overrides),
  *   SK_RCCL_ID_FILE (rendezvous file for the RCCL unique id; default /tmp/sk_rccl_id.<MASTER_PORT|uid>).
- * List lines are dealt round-robin to the ranks, every rank's counters are summed with one RCCL
- * all-reduce, rank 0 alone writes stdout, the progress file and the skip/progress messages. */
+ * List items (files, byte ranges of big plain-text files) are dealt to the ranks by size -- the same plan on every rank,
+ * compared before anyone scans (SK_E_PLAN) --, every rank's counters are summed with one RCCL all-reduce, rank 0 alone
+ * writes stdout, the progress file and the skip/progress messages. */
 int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
 {
     const char *A = NULL, *B = NULL, *C = NULL, *R = NULL, *P = NULL, *env;
@@ -1444,6 +1571,10 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
     if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); failed = 1; }
     if (rc == SK_OK && world > 1) rc = sk_counts_zero(ctx, 0);      /* column 0 must not be summed world times: keep it on rank 0 */
     if (rc == SK_OK && world > 1 && rank == 0) rc = sk_counts_set(ctx, 0, ks.first_count);
+    if (rc != SK_OK && !failed) {                                   /* (a wrong column 0 must not reach the all-reduce) */
+        fprintf(err, "kmer_scrub_count: could not set up the reference_count column: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx));
+        failed = 1;
+    }
 
     if (!failed && skh_scan_list(ctx, A, NULL, 1, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;
     if (!failed && skh_scan_list(ctx, B, NULL, 2, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;

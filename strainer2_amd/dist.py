@@ -12,9 +12,21 @@ class _DevBlock:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
-def shard_of(index: int, rank: int, world: int) -> bool:
-    """List line `index` belongs to `rank` (round-robin; same rule as skh_scan_list)."""
-    return index % world == rank
+def plans_agree(list_path, world, skip=None) -> bool:
+    """Every rank of the default process group computed the same work plan for `list_path` (skh_list_plan_hash: items
+    dealt by size, big plain files cut into byte ranges -- a function of the list, the file sizes and the world size).
+    Call before scan_list(rank=.., world=..) when the counters are reduced through torch.distributed; the programs'
+    own RCCL path (skh_scan_list with sk_comm_init) makes the same comparison inside the library."""
+    import torch
+    import torch.distributed as dist
+    from .native import KmerContext
+    h = KmerContext.list_plan_hash(list_path, world, skip)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([h & 0x7FFFFFFF, (h >> 31) & 0x7FFFFFFF, h >> 62], dtype=torch.int64, device=dev)
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool((lo == hi).all().item())
 
 
 def allreduce_counts(ctx, col=None):

@@ -43,10 +43,10 @@ ABI_SYMBOLS = [
     "sk_table_load_wide", "sk_table_load_text", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
     "sk_ticket_wait", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
-    "sk_counts_allreduce", "sk_comm_init", "sk_comm_init_ex", "sk_rendezvous_exchange", "sk_comm_destroy", "sk_comm_sum_u32", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
+    "sk_counts_allreduce", "sk_comm_init", "sk_comm_init_ex", "sk_rendezvous_exchange", "sk_comm_destroy", "sk_comm_sum_u32", "sk_comm_agree_u64", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
-    "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_print_counts",
+    "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_list_plan_hash", "skh_list_plan_owners", "skh_print_counts",
     "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_strain_detect_resident", "skh_decode_file",
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
@@ -113,6 +113,10 @@ lib.skh_keyset_key.argtypes = [C.POINTER(_KeysetStruct), C.c_uint32, C.c_char_p]
 lib.skh_keyset_key.restype = None
 lib.skh_keyset_load.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_uint32]
 lib.skh_scan_file.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.skh_list_plan_hash.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.skh_list_plan_hash.restype = C.c_int
+lib.skh_list_plan_owners.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+lib.skh_list_plan_owners.restype = C.c_int
 lib.skh_scan_list.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p,
                               C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
 lib.skh_print_counts.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_void_p, C.c_int]
@@ -309,8 +313,30 @@ class KmerContext:
                                    col, None, None, rank, world, C.byref(bases)))
         return bases.value
 
+    @staticmethod
+    def list_plan_owners(list_path, world, skip=None):
+        """per list line the rank that scans it (skh_list_plan_owners; 0xFFFFFFFF skipped, 0xFFFFFFFE cut across ranks)"""
+        n = C.c_uint32(0)
+        args = (os.fsencode(list_path), None if skip is None else os.fsencode(skip), world)
+        rc = lib.skh_list_plan_owners(*args, None, 0, C.byref(n))
+        own = np.empty(max(n.value, 1), dtype=np.uint32)
+        if rc == SK_OK:
+            rc = lib.skh_list_plan_owners(*args, own.ctypes.data, n.value, C.byref(n))
+        if rc != SK_OK:
+            raise OSError(f"skh_list_plan_owners({list_path}) failed: {rc}")
+        return own[: n.value]
+
     def sync(self):
         self._ck(lib.sk_sync(self._h))
+
+    @staticmethod
+    def list_plan_hash(list_path, world, skip=None):
+        """hash of the work plan scan_list(list_path, .., world=world) follows on every rank (skh_list_plan_hash)"""
+        h = C.c_uint64(0)
+        rc = lib.skh_list_plan_hash(os.fsencode(list_path), None if skip is None else os.fsencode(skip), world, C.byref(h))
+        if rc != SK_OK:
+            raise OSError(f"skh_list_plan_hash({list_path}) failed: {rc}")
+        return h.value
 
     def counts(self, col):
         out = np.empty(self.nrows, dtype=np.uint32)

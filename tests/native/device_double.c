@@ -224,6 +224,7 @@ int sk_sync(sk_ctx *c) { (void)c; return SK_OK; }
 int sk_comm_init(sk_ctx *c, int r, int w, const char *f, int t) { (void)c; (void)r; (void)w; (void)f; (void)t; return die("sk_comm_init"); }
 int sk_comm_init_ex(sk_ctx *c, int r, int w, const char *f, int t, int s) { (void)c; (void)r; (void)w; (void)f; (void)t; (void)s; return die("sk_comm_init_ex"); }
 int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s) { (void)c; (void)v; (void)s; return die("sk_comm_sum_u32"); }
+int sk_comm_agree_u64(sk_ctx *c, uint64_t v, int *a) { (void)c; (void)v; *a = 1; return SK_OK; }
 int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return die("sk_counts_zero"); }
 int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return die("sk_counts_allreduce"); }
 int skh_scrub_filter_resident(sk_ctx *c, const skh_keyset *k, int d, double m, int i, FILE *o, FILE *e) { (void)c; (void)k; (void)d; (void)m; (void)i; (void)o; (void)e; return die("skh_scrub_filter_resident"); }

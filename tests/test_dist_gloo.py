@@ -1,6 +1,8 @@
-"""world_size-2 gloo test of the N>1 path's host logic: list sharding + the count all-reduce
-identity (sum over ranks of shard counts == unsharded counts).  The per-rank counts here come from
-the oracle (this is a CPU test of the distributed plumbing, not of the kernels)."""
+"""world_size-2 gloo test of the N>1 path's host logic: the PRODUCT's list plan (skh_list_plan_owners: items dealt to ranks
+by size -- the plan skh_scan_list follows; whole files here, SK_NO_SPLIT=1, because the per-rank counts come from the
+oracle, which scans files) + the agreement on the plan the ranks reach before scanning (dist.plans_agree) + the count
+all-reduce identity (sum over ranks of shard counts == unsharded counts).  A CPU test of the distributed plumbing, not
+of the kernels."""
 import os
 import sys
 
@@ -16,13 +18,20 @@ def _worker(rank, world, port, files, strain, out_dir):
     sys.path.insert(0, HERE)
     import torch.distributed as dist
     import _oracle
-    from strainer2_amd.dist import allreduce_count_array, shard_of
+    import strainer2_amd as sk
+    from strainer2_amd.dist import allreduce_count_array, plans_agree
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["SK_NO_SPLIT"] = "1"
+    os.environ["SK_THREADS"] = str(1 + 4 * rank)                       # (the plan must not depend on it)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    list_path = os.path.join(out_dir, "list.txt")
+    assert plans_agree(list_path, world)
+    owners = sk.KmerContext.list_plan_owners(list_path, world)
+    assert len(owners) == len(files) and set(owners.tolist()) == set(range(world))
     t = _oracle.OracleTable()
     assert t.build_file(strain) == 0
-    mine = [f for i, f in enumerate(files) if shard_of(i, rank, world)]
+    mine = [f for i, f in enumerate(files) if owners[i] == rank]
     for f in mine:
         t.scan_file(f, 2)
     _keys, counts = t.rows()
@@ -40,6 +49,8 @@ def test_sharded_allreduce_equals_unsharded(golden, tmp_path):
     files = [os.path.join(d, f) for f in ["m1.fasta", "m2.fq.gz", "m3_crlf.fa", "g1.fa", "g2.fa.gz"]]
     strain = os.path.join(d, "strain.fna.gz")
     port = 29500 + os.getpid() % 2000
+    with open(tmp_path / "list.txt", "w") as f:
+        f.write("".join(p + "\n" for p in files))
     tmp.spawn(_worker, args=(2, port, files, strain, str(tmp_path)), nprocs=2, join=True)
     t = _oracle.OracleTable()
     t.build_file(strain)

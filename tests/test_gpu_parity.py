@@ -17,7 +17,8 @@ from strainer2_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["mixed", "drug", "iupac_strain", "truncated_fastq", "missing_in_list", "missing_flag", "contig30"]
+CASES = ["mixed", "drug", "iupac_strain", "truncated_fastq", "missing_in_list", "missing_flag", "contig30",
+         "progress_missing", "skip_after_missing"]
 
 
 @pytest.fixture(scope="module")
@@ -372,9 +373,13 @@ def test_program_cfg3_shape_vs_oracle_program(tmp_path):
     assert cols.shape[1] == 4 and (cols.sum(axis=0) > [190_000, 200_000, 100_000, 200_000]).all(), cols.sum(axis=0)
 
 
-def test_single_launch_beyond_4_gib(ctx):
-    """One device-resident batch of more than 2^32 bytes (64-bit positions inside the kernel): the
-    same 1.51 GB stream three times in a row must count exactly three times one copy."""
+def test_single_launch_beyond_4_gib(ctx, golden):
+    """BASELINE configs[1] at full size through sk_scan_device, pinned to the UNMODIFIED reference: the metagenome_count
+    column of the rank-0 stream (10 M x 150 bp vs the 5 Mbp strain) must have the sum, the number of non-zero rows and
+    the md5 the reference program produced for this very stream (tests/golden/cfg2_facts.json, made by
+    tests/golden/make_cfg2_facts.py; src/kmer_scrub_count.c:89-98,134-156).  And one device-resident batch of more than
+    2^32 bytes (64-bit positions inside the kernel): the same 1.51 GB stream three times in a row must count exactly
+    three times one copy."""
     contigs = synth.make_strain()
     ks = sk.Keyset.from_stream(synth.strain_stream(contigs))
     ctx.load_keyset(ks, 4)
@@ -389,7 +394,12 @@ def test_single_launch_beyond_4_gib(ctx):
     ctx.sync()
     one, three = ctx.counts(1), ctx.counts(2)
     ctx.dev_free(buf)
-    assert int(one.sum()) > 20_000_000
+    facts = json.load(open(os.path.join(golden, "cfg2_facts.json")))
+    want = facts["ranks"][0]
+    assert facts["reads"] == 10_000_000 and facts["read_len"] == 150 and want["rows"] == ks.nrows
+    got = {"sum": int(one.astype(np.uint64).sum()), "nonzero_rows": int(np.count_nonzero(one)), "max": int(one.max()),
+           "md5_u32_le": hashlib.md5(one.astype("<u4").tobytes()).hexdigest()}
+    assert got == {k: want[k] for k in got}, (got, want)
     assert np.array_equal(three, 3 * one)
 
 

@@ -11,7 +11,7 @@ import _oracle
 import _synth
 
 CASES = ["mixed", "drug", "iupac_strain", "truncated_fastq", "missing_in_list", "missing_flag",
-         "short_contig", "contig30"]
+         "short_contig", "contig30", "progress_missing", "skip_after_missing"]
 
 
 def _case(golden, name):

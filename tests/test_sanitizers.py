@@ -193,19 +193,25 @@ def ks_host_exe(request, tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("name", ["truncated_fastq", "contig30", "missing_in_list", "missing_flag"])
+@pytest.mark.parametrize("name", ["truncated_fastq", "contig30", "missing_in_list", "missing_flag", "progress_missing", "skip_after_missing"])
 def test_kmer_scrub_count_host_logic_under_sanitizers(ks_host_exe, golden, name, tmp_path):
     """kmer_scrub_count's host half (key-set build, order replay, decode thread pool with its double buffers,
     table print) under ASan+UBSan and TSan with the CPU test double, against the reference's output"""
     d = os.path.join(golden, "cases", name)
     meta = json.load(open(os.path.join(d, "case.json")))
     env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_CHUNK_BYTES="4096")     # (many chunk flushes per file, both buffers in use)
-    p = subprocess.run([ks_host_exe] + meta["argv"], cwd=d, env=env, capture_output=True)
+    argv = [a if a != "progress.txt" else str(tmp_path / "progress") for a in meta["argv"]]
+    p = subprocess.run([ks_host_exe] + argv, cwd=d, env=env, capture_output=True)
     for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
         assert bad not in p.stderr, p.stderr.decode()[-3000:]
     assert p.returncode == meta["returncode"]
     assert p.stdout == open(os.path.join(d, "expected.stdout"), "rb").read()
     assert p.stderr == open(os.path.join(d, "expected.stderr"), "rb").read()
+    if meta["progress_col1"] is not None:
+        # with four decode threads the files behind the unreadable one are taken (and announced) meanwhile: the progress
+        # file must still end where the reference's does (src/genome_compare.c:167-172,195-198)
+        with open(tmp_path / "progress") as f:
+            assert [ln.split("\t")[0].rstrip("\n") for ln in f] == meta["progress_col1"]
 
 
 def test_kmer_scrub_count_thread_pool_under_sanitizers(ks_host_exe, tmp_path):

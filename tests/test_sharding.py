@@ -87,6 +87,37 @@ def test_sharded_sums_equal_the_unsharded_scan(exe, world_files, world, split):
     assert tag == b"OK" and int(total) > 100000 and int(bases) > 1000000
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_the_plan_does_not_follow_a_ranks_thread_count(exe, world_files, world):
+    """the piece size came from the LOCAL thread count (SK_THREADS, cgroup quota ...), so ranks with
+    different settings cut files differently and byte ranges were scanned twice or never.  The automatic piece size (no
+    SK_SPLIT_BYTES; its 32 MiB floor lowered so that these small files are cut) is now a function of the list, the sizes
+    and the world size: every rank scans with a different SK_THREADS and the sums still equal the unsharded scan."""
+    env = dict(os.environ, SK_THREADS="3", ASAN_OPTIONS="detect_leaks=0", SK_SPLIT_FLOOR_BYTES="3000", SHARD_VARY_THREADS="1")
+    p = subprocess.run([exe, str(world_files / "strain.fa"), str(world_files / "list.txt"), str(world)], env=env,
+                       capture_output=True, timeout=600)
+    assert p.returncode == 0, (p.stdout, p.stderr[-2000:])
+    assert p.stdout.startswith(b"OK")
+
+
+def test_plan_hash_and_owners(exe, world_files):
+    """skh_list_plan_hash / skh_list_plan_owners: the same for every thread count, different when a setting that does change
+    the plan differs (what the ranks compare before scanning: SK_E_PLAN), every line owned, the big file shared"""
+    def plan(**kw):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", SK_SPLIT_FLOOR_BYTES="3000", **kw)
+        p = subprocess.run([exe, "--plan", str(world_files / "list.txt"), "4"], env=env, capture_output=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        f = p.stdout.split()
+        return f[0], [int(x) for x in f[1:]]
+    h1, o1 = plan(SK_THREADS="1")
+    h16, o16 = plan(SK_THREADS="16")
+    assert h1 == h16 and o1 == o16
+    assert len(o1) == 9 and all(o in (0, 1, 2, 3, -2) for o in o1) and o1[0] == -2          # big.fq: pieces on several ranks
+    h_other, _ = plan(SK_THREADS="1", SK_SPLIT_BYTES="20000")
+    h_nosplit, o_ns = plan(SK_THREADS="1", SK_NO_SPLIT="1")
+    assert len({h1, h_other, h_nosplit}) == 3 and -2 not in o_ns and set(o_ns) == {0, 1, 2, 3}
+
+
 def test_a_file_that_cannot_be_cut_safely_fails_the_run(exe, tmp_path):
     """wrapped FASTQ whose quality lines imitate a header two lines before a '+' line: the guess lands inside a record,
     the check after the piece before it notices (parser not between two records) and the scan FAILS (SK_E_SPLIT = -9)
