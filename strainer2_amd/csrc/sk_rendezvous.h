@@ -15,6 +15,10 @@
  *   rank 0      removes <base> and every hello.* it finds (leftovers; a live rank rewrites its hello within 200 ms), then
  *               polls until all n-1 hellos are there, and publishes <base> with everyone's token, the verdict
  *               (0 = go, 1 = somebody's set-up failed) and the payload.
+ *               Just before it publishes it reads every hello ONCE MORE: a rank that gave up meanwhile (its own timeout) has
+ *               removed its hello, and the others must not walk into a collective that is one rank short -- verdict 1.
+ *   Every file carries the launch's NONCE (a hash of SK_LAUNCH_ID, TORCHELASTIC_RUN_ID or MASTER_ADDR:MASTER_PORT, whichever
+ *   is set): two launches of one user that share the default path do not take each other's hellos or boards.
  *   Everyone returns SKR_OK / SKR_ABORT (verdict 1: leave without touching the collective) / SKR_TIMEOUT.
  * The path defaults to node-local /tmp: for several nodes SK_RCCL_ID_FILE must name a path all of them see.
  */
@@ -33,12 +37,28 @@
 #define SKR_ABORT    1      /* some rank reported a failed set-up: nobody enters the collective */
 #define SKR_TIMEOUT  2
 #define SKR_IO       3
-#define SKR_MAGIC    0x534B5244565A3031ull     /* "SKRDVZ01" */
+#define SKR_MAGIC    0x534B5244565A3032ull     /* "SKRDVZ02" */
 #define SKR_MAX_WORLD 64
 #define SKR_PAYLOAD  128
 
-typedef struct { uint64_t magic; uint32_t rank, world; uint64_t token; uint32_t status, pad; } skr_hello;
-typedef struct { uint64_t magic; uint32_t world, verdict; uint64_t tokens[SKR_MAX_WORLD]; unsigned char payload[SKR_PAYLOAD]; } skr_board;
+typedef struct { uint64_t magic; uint32_t rank, world; uint64_t token; uint32_t status, pad; uint64_t nonce; } skr_hello;
+typedef struct { uint64_t magic; uint32_t world, verdict; uint64_t nonce; uint64_t tokens[SKR_MAX_WORLD]; unsigned char payload[SKR_PAYLOAD]; } skr_board;
+
+/* what tells this launch from another one of the same user: whatever the launcher set for all its ranks */
+static uint64_t skr_nonce(void)
+{
+    const char *names[] = {"SK_LAUNCH_ID", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"};
+    uint64_t h = 0xCBF29CE484222325ull;
+    int i, any = 0;
+    for (i = 0; i < 4; i++) {
+        const char *v = getenv(names[i]);
+        if (!v || (i >= 2 && any == 1)) continue;          /* (an explicit launch id makes the address irrelevant) */
+        if (i < 2) any = 1; else any = 2;
+        for (; *v; v++) { h ^= (unsigned char)*v; h *= 0x100000001B3ull; }
+        h ^= 0xFFu; h *= 0x100000001B3ull;
+    }
+    return any ? h : 0;
+}
 
 static double skr_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
@@ -88,13 +108,14 @@ static int skr_exchange(int rank, int world, const char *base, int my_status, un
         memset(&bd, 0, sizeof bd);
         unlink(base);
         for (r = 1; r < world; r++) { snprintf(path, sizeof path, "%s.hello.%d", base, r); unlink(path); }
-        bd.magic = SKR_MAGIC; bd.world = (uint32_t)world; bd.verdict = my_status ? 1u : 0u;
+        bd.magic = SKR_MAGIC; bd.world = (uint32_t)world; bd.verdict = my_status ? 1u : 0u; bd.nonce = skr_nonce();
         for (;;) {
             for (r = 1; r < world; r++) {
                 skr_hello h;
                 if ((seen >> r) & 1u) continue;
                 snprintf(path, sizeof path, "%s.hello.%d", base, r);
-                if (skr_read_whole(path, &h, sizeof h) == 0 && h.magic == SKR_MAGIC && h.rank == (uint32_t)r && h.world == (uint32_t)world && h.token) {
+                if (skr_read_whole(path, &h, sizeof h) == 0 && h.magic == SKR_MAGIC && h.rank == (uint32_t)r && h.world == (uint32_t)world && h.token &&
+                    h.nonce == bd.nonce) {
                     bd.tokens[r] = h.token;
                     if (h.status) bd.verdict = 1u;
                     seen |= (uint64_t)1 << r;
@@ -110,6 +131,14 @@ static int skr_exchange(int rank, int world, const char *base, int my_status, un
             }
             usleep(20000);
         }
+        /* everybody was seen -- but is everybody still there?  A rank that ran into its own timeout while this one waited
+         * for a later rank has taken its hello away: publishing "go" now would send the others into a collective that is
+         * one rank short */
+        for (r = 1; r < world; r++) {
+            skr_hello h;
+            snprintf(path, sizeof path, "%s.hello.%d", base, r);
+            if (skr_read_whole(path, &h, sizeof h) != 0 || h.magic != SKR_MAGIC || h.token != bd.tokens[r] || h.nonce != bd.nonce) bd.verdict = 1u;
+        }
         memcpy(bd.payload, payload, SKR_PAYLOAD);
         if (skr_write_atomic(base, &bd, sizeof bd) != 0) return SKR_IO;
         return bd.verdict ? SKR_ABORT : SKR_OK;
@@ -118,7 +147,7 @@ static int skr_exchange(int rank, int world, const char *base, int my_status, un
         skr_board bd;
         double last_write = -1.0;
         memset(&h, 0, sizeof h);
-        h.magic = SKR_MAGIC; h.rank = (uint32_t)rank; h.world = (uint32_t)world; h.token = skr_token(); h.status = my_status ? 1u : 0u;
+        h.magic = SKR_MAGIC; h.rank = (uint32_t)rank; h.world = (uint32_t)world; h.token = skr_token(); h.status = my_status ? 1u : 0u; h.nonce = skr_nonce();
         snprintf(path, sizeof path, "%s.hello.%d", base, rank);
         for (;;) {
             const double now = skr_now();
@@ -126,7 +155,7 @@ static int skr_exchange(int rank, int world, const char *base, int my_status, un
                 if (skr_write_atomic(path, &h, sizeof h) != 0) return SKR_IO;
                 last_write = now;
             }
-            if (skr_read_whole(base, &bd, sizeof bd) == 0 && bd.magic == SKR_MAGIC && bd.world == (uint32_t)world && bd.tokens[rank] == h.token) {
+            if (skr_read_whole(base, &bd, sizeof bd) == 0 && bd.magic == SKR_MAGIC && bd.world == (uint32_t)world && bd.nonce == h.nonce && bd.tokens[rank] == h.token) {
                 memcpy(payload, bd.payload, SKR_PAYLOAD);
                 unlink(path);
                 return bd.verdict ? SKR_ABORT : SKR_OK;

@@ -11,10 +11,11 @@ import pytest
 
 import strainer2_amd.native as native
 
-MAGIC = 0x534B5244565A3031
+MAGIC = 0x534B5244565A3032
 
 
-def _rank(rank, world, base, status, timeout, delay, q):
+def _rank(rank, world, base, status, timeout, delay, q, env=None):
+    os.environ.update(env or {})
     if delay:
         time.sleep(delay)
     buf = (C.c_ubyte * 128)()
@@ -25,14 +26,15 @@ def _rank(rank, world, base, status, timeout, delay, q):
     q.put((rank, rc, bytes(buf)))
 
 
-def _run(world, base, status=None, timeout=10.0, absent=(), delays=None):
+def _run(world, base, status=None, timeout=10.0, absent=(), delays=None, timeouts=None, envs=None):
     ctx = mp.get_context("fork")
     q = ctx.Queue()
     ps = []
     for r in range(world):
         if r in absent:
             continue
-        p = ctx.Process(target=_rank, args=(r, world, base, (status or {}).get(r, 0), timeout, (delays or {}).get(r, 0), q))
+        p = ctx.Process(target=_rank, args=(r, world, base, (status or {}).get(r, 0), (timeouts or {}).get(r, timeout),
+                                            (delays or {}).get(r, 0), q, (envs or {}).get(r)))
         p.start()
         ps.append(p)
     out = {}
@@ -58,10 +60,10 @@ def test_leftovers_of_a_crashed_launch_are_ignored(tmp_path):
     base = str(tmp_path / "id")
     world = 4
     # a board and hello files with the right magic and shape, but the tokens of another launch
-    board = struct.pack("<QII", MAGIC, world, 0) + struct.pack("<64Q", *([0x1111] * 64)) + bytes(128)
+    board = struct.pack("<QIIQ", MAGIC, world, 0, 0) + struct.pack("<64Q", *([0x1111] * 64)) + bytes(128)
     open(base, "wb").write(board)
     for r in range(1, world):
-        open(f"{base}.hello.{r}", "wb").write(struct.pack("<QIIQII", MAGIC, r, world, 0x2222, 0, 0))
+        open(f"{base}.hello.{r}", "wb").write(struct.pack("<QIIQIIQ", MAGIC, r, world, 0x2222, 0, 0, 0))
     # rank 0 starts late: the others meet the stale board first and must not take it
     out = _run(world, base, delays={0: 0.8})
     assert all(rc == 0 for rc, _ in out.values()), out
@@ -80,6 +82,25 @@ def test_a_rank_that_never_shows_up_is_a_bounded_wait(tmp_path):
     assert time.time() - t0 < 15
     assert out[0][0] == 2                                        # rank 0 timed out ...
     assert all(rc in (1, 2) for rc, _ in out.values()), out      # ... and told the ones that did arrive to leave (or they timed out too)
+
+
+def test_a_rank_that_gave_up_before_the_board_makes_everyone_leave(tmp_path):
+    """rank 1 runs into its own (short) timeout and takes its hello away while rank 0 -- which has already seen
+    that hello -- still waits for rank 2, who is late.  Rank 0 reads every hello once more before it publishes: the
+    verdict is "leave", not a collective that is one rank short."""
+    out = _run(3, str(tmp_path / "id"), timeout=8.0, timeouts={1: 0.6}, delays={2: 1.5})
+    assert out[1][0] == 2                                        # rank 1 timed out on its own
+    assert out[0][0] == 1 and out[2][0] == 1, out                # the others are told to leave (SKR_ABORT)
+
+
+def test_two_launches_on_one_path_do_not_mix(tmp_path):
+    """Every file carries the launch's nonce (MASTER_ADDR:MASTER_PORT, TORCHELASTIC_RUN_ID or SK_LAUNCH_ID): rank 1 of ANOTHER
+    launch on the same default path is not taken for this launch's rank 1 -- rank 0 keeps waiting for its own."""
+    base = str(tmp_path / "id")
+    out = _run(2, base, timeout=1.5, envs={0: {"SK_LAUNCH_ID": "A"}, 1: {"SK_LAUNCH_ID": "B"}})
+    assert out[0][0] == 2 and out[1][0] == 2, out                # neither accepts the other: both time out
+    out = _run(2, base, timeout=5.0, envs={0: {"SK_LAUNCH_ID": "A"}, 1: {"SK_LAUNCH_ID": "A"}})
+    assert out[0][0] == 0 and out[1][0] == 0 and out[1][1] == WANT
 
 
 def test_without_rank0_the_others_time_out(tmp_path):
