@@ -218,6 +218,130 @@ def measured_traffic(args, kernel_name):
     return tj.get("hbm_bytes_per_launch"), tj.get("correction")
 
 
+# ----------------------------------------------------------------------------- strain_detect side measurement
+def strain_detect_leg(device, oracle_sample_reads=20_000, repeat=10):
+    """The second deliverable's kernel (sk_scan_grid<TALLY, UNION>: per-read tallies against ONE table over 32 resident strains,
+    BASELINE configs[4] at one GPU's share: 256 strains / 8) on resident batches of 32 MiB and 512 MiB of 150-base reads, 2 % of them
+    cut from the strains, 1 % of every strain's rows informative.  Reported beside `value`, never as it: kernel ms from HIP events
+    on the union's stream (sk_union_scan_timing), wall per launch + collect round, roofline fraction on compulsory bytes (the batch
+    read once + 16 B per (read, strain) pair that was hit + 8 B per log entry).  Checked in the run: the union's results ==
+    member by member (32 x sk_tally_launch on the strains' own tables, record for record and log entry for log entry), and for two
+    strains the sums over a sample of reads == the oracle's counts for that sample (all hits; hits on informative rows)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    import strainer2_amd as sk
+    from strainer2_amd import cfg5
+    from strainer2_amd.native import lib
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import _oracle
+    ns = cfg5.NSTRAINS
+    t0 = time.perf_counter()
+    strains = [cfg5.strain(s) for s in range(ns)]
+    with ThreadPoolExecutor(min(8, host_cpus())) as ex:                       # (the key-set build releases the GIL)
+        sets = list(ex.map(lambda g: sk.Keyset.from_stream(g.tobytes() + b"\n", default_val=1, incr=0), strains))
+    t_sets = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ctxs, types = [], []
+    for s in range(ns):
+        c = sk.KmerContext(device)
+        c.load_keyset(sets[s], 6)
+        typ = np.ones(sets[s].nrows, dtype=np.uint32)
+        typ[np.random.default_rng(cfg5.SEED_I + s).choice(sets[s].nrows, sets[s].nrows // 100, replace=False)] = 2
+        c.set_counts(0, typ)
+        ctxs.append(c)
+        types.append(typ)
+    for c in ctxs:
+        c.sync()
+    t_load = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    u = sk.KmerUnion(ctxs, 0, 2)
+    t_union = time.perf_counter() - t0
+    genome = np.concatenate(strains)
+    out = {"strains": ns, "strain_bp": cfg5.STRAIN_BP, "union_rows": int(u.rows), "strain_read_fraction": 0.02, "informative_row_fraction": 0.01,
+           "key_sets_s": round(t_sets, 2), "table_loads_s": round(t_load, 2), "union_build_s": round(t_union, 3), "batches": []}
+    rec = cfg5.READ_LEN + 1
+    for mib in (32, 512):
+        nrec = (mib << 20) // rec
+        stream = np.empty((nrec, rec), dtype=np.uint8)
+        for a in range(0, nrec, cfg5.BLOCK):
+            m = min(cfg5.BLOCK, nrec - a)
+            stream[a:a + m, :] = cfg5.reads_block(1000 + a // cfg5.BLOCK, m, genome)[:, 3:]       # (the FASTA block without its header lines)
+        starts = (np.arange(nrec, dtype=np.uint64) * rec).astype(np.uint32)
+        nbytes = nrec * rec
+        assert lib.sk_batch_fill(u._batch, stream.ctypes.data, nbytes, starts.ctypes.data, nrec) == 0
+        cap = max(nrec // 2, 1 << 16)
+        recs = np.zeros((min(nrec * ns, 1 << 26) + 1, 3), dtype=np.uint32)
+        hits = np.zeros((cap, 2), dtype=np.uint32)
+        nr, nh = C.c_uint64(0), C.c_uint64(0)
+
+        def one_round():
+            assert lib.sk_union_tally_launch(u._h, u._batch, cap) == 0, lib.sk_union_last_error(u._h)
+            assert lib.sk_union_tally_collect(u._h, recs.ctypes.data, len(recs) - 1, C.byref(nr), hits.ctypes.data, C.byref(nh)) == 0
+            assert nh.value <= cap and nr.value < len(recs)
+        one_round()                                                            # warm-up (scratch buffers grow here)
+        lib.sk_union_scan_timing(u._h, None, None, 1)
+        t0 = time.perf_counter()
+        for _ in range(repeat):
+            one_round()
+        wall = (time.perf_counter() - t0) / repeat
+        ms, nl = C.c_double(0), C.c_uint64(0)
+        assert lib.sk_union_scan_timing(u._h, C.byref(ms), C.byref(nl), 1) == 0
+        kern_ms = ms.value / max(nl.value, 1)
+        pairs, nlog = int(nr.value), int(nh.value)
+        got_recs = recs[:pairs].copy()
+        got_hits = hits[:nlog].copy()
+        compulsory = nbytes + 16.0 * pairs + 8.0 * nlog
+        entry = {"batch_mib": mib, "reads": nrec, "bases": nrec * cfg5.READ_LEN, "kernel": "sk_scan_grid<TALLY,UNION>", "kernel_ms": kern_ms,
+                 "launches_timed": int(nl.value), "wall_ms_launch_and_collect": wall * 1e3,
+                 "bases_per_s_kernel": nrec * cfg5.READ_LEN / (kern_ms * 1e-3), "strain_x_bases_per_s_kernel": ns * nrec * cfg5.READ_LEN / (kern_ms * 1e-3),
+                 "read_strain_pairs_hit": pairs, "log_entries": nlog,
+                 "roofline": {"bound": "hbm", "compulsory_bytes": compulsory, "achieved": compulsory / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": compulsory / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if mib == 32:
+            # ---- union == member by member, record for record and log entry for log entry
+            dense = np.zeros((nrec * ns, 2), dtype=np.uint32)
+            dense[got_recs[:, 0]] = got_recs[:, 1:]
+            dense = dense.reshape(nrec, ns, 2)
+            one = np.zeros((nrec + 1, 3), dtype=np.uint32)
+            mh = np.zeros((cap, 2), dtype=np.uint32)
+            same = True
+            for s, c in enumerate(ctxs):
+                assert lib.sk_tally_launch(c._h, u._batch, 0, 2, cap) == 0
+                assert lib.sk_tally_collect_sparse(c._h, one.ctypes.data, nrec, C.byref(nr), mh.ctypes.data, C.byref(nh)) == 0
+                md = np.zeros((nrec, 2), dtype=np.uint32)
+                md[one[:nr.value, 0]] = one[:nr.value, 1:]
+                sel = got_hits[(got_hits[:, 1] >> 27) == s]
+                mine = np.stack([sel[:, 0], sel[:, 1] & ((1 << 27) - 1)], axis=1)
+                theirs = mh[:nh.value]
+                same = same and np.array_equal(md, dense[:, s, :]) and \
+                    np.array_equal(mine[np.lexsort((mine[:, 1], mine[:, 0]))], theirs[np.lexsort((theirs[:, 1], theirs[:, 0]))])
+            assert same, "union and member-by-member tallies differ"
+            entry["union_equals_member_by_member"] = True
+            # ---- two strains against the oracle on a sample of reads
+            sample = stream[:oracle_sample_reads].tobytes()
+            oc = {}
+            for s in cfg5.PINNED_STRAINS:
+                t = _oracle.OracleTable(ncols=6)
+                assert t.build_stream(strains[s].tobytes() + b"\n", default=1, incr=0, short_policy=1) == 0
+                t.scan_stream(sample, 1)
+                okeys, ocounts = t.rows()
+                assert okeys == sets[s].keys(), "row order differs from the oracle"
+                col = ocounts[:, 1].astype(np.int64)
+                want = (int(col.sum()), int(col[types[s] == 2].sum()))
+                got = (int(dense[:oracle_sample_reads, s, 0].sum()), int(dense[:oracle_sample_reads, s, 1].sum()))
+                assert want == got, f"strain {s}: tallies of the sample differ from the oracle ({got} vs {want})"
+                oc[str(s)] = {"all_hits": got[0], "informative_hits": got[1]}
+                t.close()
+            entry["oracle_sample"] = {"reads": oracle_sample_reads, "strains": oc, "equal": True}
+        out["batches"].append(entry)
+        del stream
+    u.close()
+    for c in ctxs:
+        c.close()
+    return out
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -229,6 +353,7 @@ def main():
     ap.add_argument("--strain-bp", type=int, default=5_000_000, help="size of the synthetic strain (cfg 2: 5 Mbp); other sizes are for sweeps, not for `value`")
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of reads drawn from the strain (cfg 2: 0.02)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-sd", action="store_true", help="skip the strain_detect (TALLY/UNION kernel) side measurement")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive host-buffer passes (keeps profiles clean)")
     ap.add_argument("--file-reads", type=int, default=1_000_000, help="reads per FASTQ file of the file-fed, rank-sharded side measurement (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -469,6 +594,16 @@ def main():
         if rank == 0:
             shutil.rmtree(root, ignore_errors=True)
 
+    sd_leg = None
+    if rank == 0 and world == 1 and not args.no_sd and not args.ablate:
+        ctx.dev_free(dev)                                   # (the 1.5 GB stream is no longer needed)
+        try:
+            sd_leg = strain_detect_leg(device)
+        except AssertionError:
+            raise
+        except Exception as e:                              # noqa: BLE001  (a side measurement must not take the headline line down)
+            sd_leg = {"skipped": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         total_bases = nbases * args.steps * world
         value = total_bases / elapsed
@@ -503,6 +638,7 @@ def main():
                          "note": "frac = compulsory bytes / kernel time / 8 TB/s.  survey_model_* is SURVEY 8(d)'s 7.4 B/base "
                                  "(one 8 B probe per window), a model of a different algorithm kept for continuity only"},
             "cpu_baseline": cpu,
+            "strain_detect": sd_leg,
         }
         if cpu is not None:
             # the north star's ">= 50 x the CPU reference" read against protocol (b) of SURVEY 8(d): P processes on the CPUs

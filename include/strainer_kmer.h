@@ -168,15 +168,18 @@ int  sk_tally_collect_sparse(sk_ctx *ctx, sk_tally_rec *out, uint64_t cap, uint6
  * caller then tallies member by member (sk_tally_launch).
  * sk_union_tally_collect: out[i] = {record * n + member, windows that hit a key of that member, those whose key is
  * informative_value in the member's type_col} for the (record, member) pairs with at least one hit, unordered;
- * out_hits[j] = {member << 26 | window-end offset, the MEMBER's own row}, one per informative hit and member.  A batch
- * tallied against a union must be shorter than 64 MiB.  New: the reference holds one strain per process
+ * out_hits[j] = {window-end offset, member << SK_UNION_ROW_BITS | the MEMBER's own row}, one per informative hit and member
+ * (a member has fewer than 2^27 - 1 rows, else SK_E_STATE).  Batches of any size below 4 GiB.  New: the reference holds one
+ * strain per process
  * (src/strain_detect.c:137-146) and re-reads the metagenome for each (:263-384). */
 #define SK_UNION_MAX 32
+#define SK_UNION_ROW_BITS 27
 typedef struct sk_union sk_union;
 int  sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type_col, uint32_t informative_value, sk_union **out); /* errors: members[0] */
 void sk_union_destroy(sk_union *u);
 int  sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hits_cap);
 int  sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *out_hits /* hits_cap */, uint64_t *out_nhits);
+int  sk_union_scan_timing(sk_union *u, double *total_ms, uint64_t *launches, int reset);   /* sk_scan_timing of the union's scans */
 const char *sk_union_last_error(const sk_union *u);          /* of launch/collect */
 uint32_t sk_union_members(const sk_union *u);
 uint32_t sk_union_rows(const sk_union *u);                   /* the members' rows added up */

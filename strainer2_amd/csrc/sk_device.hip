@@ -130,25 +130,29 @@ struct sk_sink {
     uint32_t            ns;
 };
 __device__ __forceinline__ const uint2 *sk_umask(const sk_sink &k) { return (const uint2 *)k.type; }
+// union table: one byte per record, set when any of its (record, strain) tallies was touched -- the compaction behind the scan
+// then reads (and zeroes again) only the rows of records that were hit, instead of the whole records x strains array.  It stands
+// where the bitmap of informative rows would (`infbits`; the union has the masks for that): no scalar register to spare.
+__device__ __forceinline__ uint8_t *sk_uflag(const sk_sink &k) { return (uint8_t *)const_cast<uint32_t *>(k.infbits); }
 
 // union table: a hit of `count` windows on a key held by the strains in `members`, in record `rec`
 __device__ __forceinline__ void sk_union_credit(const sk_sink &k, uint32_t rec, uint32_t members, uint32_t count)
 {
+    if (members) sk_uflag(k)[rec] = 1;
     while (members) {
         const uint32_t s = (uint32_t)__builtin_ctz(members);
         members &= members - 1u;
         atomicAdd(&k.tally[2u * (rec * k.ns + s)], count);
     }
 }
-// ... and its informative side: one tally and one log entry per strain in `infm`
-__device__ __forceinline__ void sk_union_informative(const sk_sink &k, uint32_t rec, uint32_t infm, uint32_t pos, uint32_t row)
+// ... and its informative side: one tally per strain in `infm` (the LOG gets one entry per hit, (position, global row), whatever
+// the number of strains: sk_union_resolve deals it out to the strains behind the scan)
+__device__ __forceinline__ void sk_union_informative(const sk_sink &k, uint32_t rec, uint32_t infm)
 {
     while (infm) {
         const uint32_t s = (uint32_t)__builtin_ctz(infm);
         infm &= infm - 1u;
         atomicAdd(&k.tally[2u * (rec * k.ns + s) + 1u], 1u);
-        const unsigned long long i = atomicAdd(k.nhits, 1ull);
-        if (i < k.hits_cap) k.hits[i] = make_uint2(pos | (s << 26), row);
     }
 }
 
@@ -206,10 +210,14 @@ __device__ __forceinline__ void sk_on_hit(const sk_sink &k, uint32_t row, uint32
     if (NOATOMIC) { if (row == 0x7FFFFFFFu) k.counts[0] = pos; return; }      // timing experiment only
     if (!TALLY) { atomicAdd(&k.counts[row], 1u); return; }
     const uint32_t lo = sk_record_of(k, pos);
-    if (UNION) {
+    if (UNION) {                                                    // (lane by lane: only sk_scan_wide comes this way)
         const uint2 mk = sk_umask(k)[row];
         sk_union_credit(k, lo, mk.x, 1u);
-        sk_union_informative(k, lo, mk.y, pos, row);
+        if (mk.y) {
+            sk_union_informative(k, lo, mk.y);
+            const unsigned long long i = atomicAdd(k.nhits, 1ull);
+            if (i < k.hits_cap) k.hits[i] = make_uint2(pos, row);
+        }
         return;
     }
     atomicAdd(&k.tally[2u * lo], 1u);
@@ -227,7 +235,33 @@ template <bool UNION = false>
 __device__ __forceinline__ void sk_tally_wave(const sk_sink &k, uint32_t hit, uint32_t pos, uint32_t lane)
 {
     const bool is_hit = hit != 0xFFFFFFFFu;
-    if (UNION) { if (is_hit) sk_on_hit<true, false, true>(k, hit, pos); return; }       // (union table: per (record, strain), lane by lane)
+    if (UNION) {
+        // union table: per (record, strain).  Lanes of one read are neighbours and mostly name the same strains: a run of lanes
+        // with the same record and the same members adds its hits with one atomic per member; the log takes (position, global
+        // row) once per informative hit, gathered in LDS like the single strain's
+        uint32_t rec = 0xFFFFFF00u | lane, mx = 0u, my = 0u;
+        if (is_hit) {
+            rec = sk_record_of(k, pos);
+            const uint2 mk = sk_umask(k)[hit];
+            mx = mk.x; my = mk.y;
+        }
+        const uint32_t prev_r = (uint32_t)__shfl_up((int)rec, 1), prev_m = (uint32_t)__shfl_up((int)mx, 1);
+        const bool first = (lane == 0u) | (rec != prev_r) | (mx != prev_m);
+        const unsigned long long fm = __ballot(first), hm = __ballot(is_hit), im = __ballot(my != 0u);
+        if (first & is_hit) {
+            const unsigned long long above = lane == 63u ? 0ull : fm & ~((2ull << lane) - 1ull);
+            const uint32_t end = above ? (uint32_t)__builtin_ctzll(above) : 64u;
+            const unsigned long long seg = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+            sk_union_credit(k, rec, mx, (uint32_t)__popcll(hm & seg));
+        }
+        if (my) sk_union_informative(k, rec, my);
+        if (im) {                                                  // (wave-uniform)
+            bool in_lds;
+            const unsigned long long base = sk_log_reserve(k, (uint32_t)__popcll(im), lane, &in_lds);
+            if (my) sk_log_put(k, in_lds, base + (unsigned long long)__popcll(im & ((1ull << lane) - 1ull)), make_uint2(pos, hit));
+        }
+        return;
+    }
     uint32_t rec = 0xFFFFFF00u | lane;                    // distinct per lane when there is no hit
     bool is_inf = false;
     if (is_hit) {
@@ -881,20 +915,60 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 fb = un | (dir ? __builtin_bitreverse32(dups) >> 16 : dups);
             }
             if (TALLY && UNION) {
-                // union table: the windows' rows each name their strains; consecutive rows mostly name the same ones
-                if (hits) {
-                    const uint32_t rcd = sk_record_of(sink, (uint32_t)tile0 + ch * 16u);
+                // union table: the windows' rows each name their strains; consecutive rows mostly name the same ones, and so do
+                // the chunks of one read (neighbouring lanes).  A chunk whose hits all name the same members (m1) hands its
+                // count to the run of lanes with the same record and members -- one atomic per member and run --; a chunk
+                // with several runs of members credits them itself.  Informative hits: one log entry (position, global row)
+                // each, gathered in the workgroup's LDS share.
+                const uint32_t nh = (uint32_t)__popc(hits);
+                uint32_t rcd = 0xFFFFFF00u | lane, ihm = 0u, m1 = 0u, c1 = 0u;
+                if (nh) {
+                    rcd = sk_record_of(sink, (uint32_t)tile0 + ch * 16u);
                     uint32_t h = hits, cur = 0u, cnt = 0u;
+                    bool several = false;
                     while (h) {
                         const uint32_t a = (uint32_t)__builtin_ctz(h);
                         h &= h - 1u;
                         const uint32_t row = r0 + (uint32_t)__popc(bits16 & ((1u << a) - 1u));
                         const uint2 mk = sk_umask(sink)[row];
-                        if (mk.x != cur) { sk_union_credit(sink, rcd, cur, cnt); cur = mk.x; cnt = 0u; }
+                        if (mk.x != cur) {
+                            if (cnt) { sk_union_credit(sink, rcd, cur, cnt); several = true; }
+                            cur = mk.x; cnt = 0u;
+                        }
                         cnt++;
-                        if (mk.y) sk_union_informative(sink, rcd, mk.y, (uint32_t)tile0 + ch * 16u + 15u + (dir ? 15u - a : a), row);
+                        if (mk.y) { ihm |= 1u << a; sk_union_informative(sink, rcd, mk.y); }
                     }
-                    sk_union_credit(sink, rcd, cur, cnt);
+                    if (several) sk_union_credit(sink, rcd, cur, cnt);
+                    else { m1 = cur; c1 = cnt; }
+                }
+                const uint32_t ni = (uint32_t)__popc(ihm);
+                const uint32_t prev_r = (uint32_t)__shfl_up((int)rcd, 1), prev_m = (uint32_t)__shfl_up((int)m1, 1);
+                const bool first = (lane == 0u) | (rcd != prev_r) | (m1 != prev_m);
+                const unsigned long long fm = __ballot(first);
+                const unsigned long long above = lane == 63u ? 0ull : fm & ~((2ull << lane) - 1ull);
+                const uint32_t end = above ? (uint32_t)__builtin_ctzll(above) : 64u;
+                const unsigned long long seg = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+                const unsigned long long ltm = (1ull << lane) - 1ull;
+                uint32_t sum_c = 0u, off_i = 0u, tot_i = 0u;
+#pragma unroll
+                for (int b = 0; b < 5; b++) {
+                    const unsigned long long bc = __ballot((c1 >> b) & 1u), bi = __ballot((ni >> b) & 1u);
+                    sum_c += (uint32_t)__popcll(bc & seg) << b;
+                    off_i += (uint32_t)__popcll(bi & ltm) << b;
+                    tot_i += (uint32_t)__popcll(bi) << b;
+                }
+                if (first && m1) sk_union_credit(sink, rcd, m1, sum_c);
+                if (tot_i) {                                                             // (wave-uniform)
+                    bool in_lds;
+                    unsigned long long at = sk_log_reserve(sink, tot_i, lane, &in_lds) + off_i;
+                    uint32_t h = ihm;
+                    while (h) {
+                        const uint32_t a = (uint32_t)__builtin_ctz(h);
+                        h &= h - 1u;
+                        const uint32_t row = r0 + (uint32_t)__popc(bits16 & ((1u << a) - 1u));
+                        sk_log_put(sink, in_lds, at, make_uint2((uint32_t)tile0 + ch * 16u + 15u + (dir ? 15u - a : a), row));
+                        at++;
+                    }
                 }
             } else if (TALLY) {
                 // A chunk's windows all lie in the record that holds the chunk, and their rows are consecutive ranks:
@@ -2219,31 +2293,69 @@ __global__ void sk_union_rank_copy(sk_u4 *__restrict__ dst, const sk_u4 *__restr
     else dst[b] = (sk_u4){after, 0u, 0u, 0u};             // padding: no row starts here
 }
 
-// the log's rows: from the union's global row to the named member's own row of the same key
-__global__ void sk_union_resolve(uint2 *hits, const unsigned long long *__restrict__ nhits, unsigned long long cap,
-                                 const uint64_t *__restrict__ ukeys, const sk_union_member *__restrict__ mem)
+// The scan logged (position, global row) once per informative hit.  Dealt out here: one entry per strain in which the row's key
+// is informative, {position, strain << SK_UNION_ROW_BITS | that member's OWN row of the key} (a probe of the key in the member's
+// table).  *nout counts every entry, stored or not (the caller asks again with more room if it exceeds cap_out).
+__global__ void sk_union_resolve(const uint2 *__restrict__ raw, const unsigned long long *__restrict__ nraw, unsigned long long cap_raw,
+                                 uint2 *__restrict__ out, unsigned long long *nout, unsigned long long cap_out,
+                                 const uint64_t *__restrict__ ukeys, const uint2 *__restrict__ umask, const sk_union_member *__restrict__ mem)
 {
-    const unsigned long long n = *nhits < cap ? *nhits : cap;
+    const unsigned long long n = *nraw < cap_raw ? *nraw : cap_raw;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint2 e = hits[i];
-        const sk_union_member m = mem[e.x >> 26];
+        const uint2 e = raw[i];
+        uint32_t infm = umask[e.y].y;
         const uint64_t k = ukeys[e.y];
-        uint32_t slot = sk_slot0(sk_khash(k), m.mask), row = 0xFFFFFFFFu;
-        for (;;) {
-            const sk_u4 u = m.slots[slot];
-            const uint64_t uk = sk_slot_key(u);
-            if (uk == k) { row = m.inv ? m.inv[u.z] : u.z; break; }
-            if (uk == SK_EMPTY64) break;
-            slot = (slot + 1u) & m.mask;
+        unsigned long long at = atomicAdd(nout, (unsigned long long)__popc(infm));
+        while (infm) {
+            const uint32_t s = (uint32_t)__builtin_ctz(infm);
+            infm &= infm - 1u;
+            const sk_union_member m = mem[s];
+            uint32_t slot = sk_slot0(sk_khash(k), m.mask), row = (1u << SK_UNION_ROW_BITS) - 1u;
+            for (;;) {
+                const sk_u4 u = m.slots[slot];
+                const uint64_t uk = sk_slot_key(u);
+                if (uk == k) { row = m.inv ? m.inv[u.z] : u.z; break; }
+                if (uk == SK_EMPTY64) break;
+                slot = (slot + 1u) & m.mask;
+            }
+            if (at < cap_out) out[at] = make_uint2(e.x, (s << SK_UNION_ROW_BITS) | row);
+            at++;
         }
-        hits[i].y = row;
+    }
+}
+
+// The (record, strain) tallies of a union scan live in a dense array that is ALL ZERO between launches: the scan marks the
+// records it touched (one byte each), and this pass visits only those -- appends {record * ns + strain, all, informative} for
+// the pairs that were hit, zeroes them again and clears the mark.  Its cost follows the reads that hit a strain, not
+// records x strains (57 MB per 32 MiB batch of 150-base reads and 32 strains; zeroing and sweeping that much took longer
+// than the scan itself).
+__global__ void sk_union_compact(uint2 *__restrict__ tally, uint8_t *__restrict__ flag, uint32_t nrec, uint32_t ns,
+                                 uint32_t *__restrict__ out, unsigned long long *n)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec || !flag[r]) return;
+    flag[r] = 0;
+    uint2 *row = tally + (size_t)r * ns;
+    uint32_t cnt = 0;
+    for (uint32_t s = 0; s < ns; s++) cnt += (uint32_t)((row[s].x | row[s].y) != 0u);
+    if (!cnt) return;
+    unsigned long long at = atomicAdd(n, (unsigned long long)cnt);
+    for (uint32_t s = 0; s < ns; s++) {
+        const uint2 t = row[s];
+        if (!(t.x | t.y)) continue;
+        out[3 * at] = r * ns + s; out[3 * at + 1] = t.x; out[3 * at + 2] = t.y;
+        at++;
+        row[s] = make_uint2(0u, 0u);
     }
 }
 
 struct sk_union {
     sk_ctx   *uc;                    // the union as a context of its own (table, text, filters, scratch, stream)
     uint32_t  n;
+    void     *d_tally, *d_flag, *d_raw;       // dense (record, strain) tallies (all zero between launches), touched marks, raw hit log
+    size_t    tally_cap, flag_cap, raw_cap;
+    unsigned long long *d_cnt;       // [0] raw log entries, [1] compacted pairs, [2] dealt-out log entries
     uint64_t *d_ukeys;               // [rows] key of every global row
     uint2    *d_umask;               // [rows]
     sk_union_member *d_members;
@@ -2256,6 +2368,7 @@ extern "C" void sk_union_destroy(sk_union *u)
         hipSetDevice(u->uc->device);
         hipStreamSynchronize(u->uc->stream);
         hipFree(u->d_ukeys); hipFree(u->d_umask); hipFree(u->d_members);
+        hipFree(u->d_tally); hipFree(u->d_flag); hipFree(u->d_raw); hipFree(u->d_cnt);
         sk_ctx_destroy(u->uc);
     }
     delete u;
@@ -2276,6 +2389,7 @@ extern "C" int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type
         if (type_col >= m->ncols) return sk_fail(first, SK_E_ARG, "column %u out of range", type_col);
         if (m->nwide) return sk_fail(first, SK_E_STATE, "member %u has byte-string keys: no union", s);
         if (!m->d_text2 || !m->d_rank || m->no_text) return sk_fail(first, SK_E_STATE, "member %u has no text stage: no union", s);
+        if (m->nrows >= (1u << SK_UNION_ROW_BITS) - 1u) return sk_fail(first, SK_E_STATE, "member %u has too many rows for the union's hit log", s);
         rows += m->nrows;
         tbases += ((uint64_t)m->text_bases + 63u) / 64u * 64u + 64u;
     }
@@ -2284,6 +2398,7 @@ extern "C" int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type
     sk_union *u = new (std::nothrow) sk_union();
     if (!u) return SK_E_NOMEM;
     u->uc = NULL; u->n = n; u->d_ukeys = NULL; u->d_umask = NULL; u->d_members = NULL;
+    u->d_tally = u->d_flag = u->d_raw = NULL; u->tally_cap = u->flag_cap = u->raw_cap = 0; u->d_cnt = NULL;
     int rc = sk_ctx_create(&u->uc, first->device);
     if (rc != SK_OK) { delete u; return rc; }
     sk_ctx *c = u->uc;
@@ -2364,6 +2479,19 @@ extern "C" int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type
     return SK_OK;
 }
 
+// grow-only device buffer of a union that must read as zero when it is handed out
+static int sk_union_zeroed(sk_union *u, void **p, size_t *cap, size_t need)
+{
+    sk_ctx *c = u->uc;
+    if (need <= *cap) return SK_OK;
+    if (*p) { SK_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(*p); *p = NULL; *cap = 0; }
+    const size_t want = need + need / 4 + 4096;
+    SK_HIP(c, hipMalloc(p, want));
+    SK_HIP(c, hipMemsetAsync(*p, 0, want, c->stream));
+    *cap = want;
+    return SK_OK;
+}
+
 // Start the tallies of batch `b` against every member at once; returns at once.  Results: sk_union_tally_collect.
 extern "C" int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hits_cap)
 {
@@ -2371,31 +2499,34 @@ extern "C" int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hi
     sk_ctx *c = u->uc;
     if (b->owner->device != c->device) return sk_fail(c, SK_E_ARG, "batch lives on another device");
     if (b->nrec == 0) return sk_fail(c, SK_E_STATE, "empty batch");
-    if (b->nbytes >= (1ull << 26)) return sk_fail(c, SK_E_ARG, "a union tallies batches below 64 MiB (the log packs the member beside the offset)");
     const uint64_t vrec = (uint64_t)b->nrec * u->n;
     if (vrec > 0x7FFFFFF0ull) return sk_fail(c, SK_E_ARG, "too many records x members");
     SK_HIP(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = sk_scratch(c, &c->t_tally, &c->t_tally_cap, (size_t)vrec * 8 + 16)) != SK_OK) return rc;
+    if ((rc = sk_union_zeroed(u, &u->d_tally, &u->tally_cap, (size_t)vrec * 8 + 16)) != SK_OK) return rc;
+    if ((rc = sk_union_zeroed(u, &u->d_flag, &u->flag_cap, (size_t)b->nrec + 16)) != SK_OK) return rc;
+    if (!u->d_cnt) SK_HIP(c, hipMalloc((void **)&u->d_cnt, 32));
+    if ((rc = sk_scratch(c, &u->d_raw, &u->raw_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
     if ((rc = sk_scratch(c, &c->t_compact, &c->t_compact_cap, (size_t)vrec * 12 + 16)) != SK_OK) return rc;
     if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
     if (!c->h_tally) { SK_HIP(c, hipHostMalloc((void **)&c->h_tally, 4096, hipHostMallocDefault)); c->h_tally_cap = 4096; }
-    unsigned long long *d_n = (unsigned long long *)((uint8_t *)c->t_tally + (size_t)vrec * 8);
     SK_HIP(c, hipStreamWaitEvent(c->stream, b->ready, 0));
-    SK_HIP(c, hipMemsetAsync(c->t_tally, 0, (size_t)vrec * 8 + 16, c->stream));
+    SK_HIP(c, hipMemsetAsync(u->d_cnt, 0, 32, c->stream));
     sk_sink sink;
     memset(&sink, 0, sizeof sink);
-    sink.rec_start = (const uint32_t *)b->d_rec; sink.nrec = b->nrec; sink.tally = (uint32_t *)c->t_tally;
+    sink.rec_start = (const uint32_t *)b->d_rec; sink.nrec = b->nrec; sink.tally = (uint32_t *)u->d_tally;
     sink.tile_first = (const uint32_t *)b->d_rec + b->nrec;
-    sink.hits = (uint2 *)c->t_hits; sink.nhits = d_n; sink.hits_cap = hits_cap;
+    sink.hits = (uint2 *)u->d_raw; sink.nhits = u->d_cnt; sink.hits_cap = hits_cap;
     sink.type = (const uint32_t *)u->d_umask; sink.ns = u->n;
+    sink.infbits = (const uint32_t *)u->d_flag;                   // (sk_uflag: the records' touched marks)
     rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink);
     if (rc) return rc;
-    hipLaunchKernelGGL(sk_tally_compact, dim3((uint32_t)((vrec + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)c->t_tally, (uint32_t)vrec,
-                       (uint32_t *)c->t_compact, d_n + 1);
-    hipLaunchKernelGGL(sk_union_resolve, dim3(256), dim3(256), 0, c->stream, (uint2 *)c->t_hits, (const unsigned long long *)d_n,
-                       (unsigned long long)hits_cap, (const uint64_t *)u->d_ukeys, (const sk_union_member *)u->d_members);
-    SK_HIP(c, hipMemcpyAsync(c->h_tally, d_n, 16, hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(sk_union_compact, dim3((b->nrec + 255) / 256), dim3(256), 0, c->stream, (uint2 *)u->d_tally, (uint8_t *)u->d_flag,
+                       b->nrec, u->n, (uint32_t *)c->t_compact, u->d_cnt + 1);
+    hipLaunchKernelGGL(sk_union_resolve, dim3(256), dim3(256), 0, c->stream, (const uint2 *)u->d_raw, (const unsigned long long *)u->d_cnt,
+                       (unsigned long long)hits_cap, (uint2 *)c->t_hits, u->d_cnt + 2, (unsigned long long)hits_cap,
+                       (const uint64_t *)u->d_ukeys, (const uint2 *)u->d_umask, (const sk_union_member *)u->d_members);
+    SK_HIP(c, hipMemcpyAsync(c->h_tally, u->d_cnt, 24, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(c, hipGetLastError());
     c->t_inflight_nrec = (uint32_t)vrec;
     c->t_inflight_cap = hits_cap;
@@ -2403,14 +2534,36 @@ extern "C" int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hi
 }
 
 // out[i] = {record * members + member, all hits, informative hits} for the pairs with at least one hit (unordered);
-// out_hits[j] = {member << 26 | window-end offset, the member's own row}.  *out_nhits may exceed the launch's hits_cap:
+// out_hits[j] = {window-end offset, member << 27 | the member's own row}.  *out_nhits may exceed the launch's hits_cap:
 // launch again with more room.
 extern "C" int sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *out_hits, uint64_t *out_nhits)
 {
-    if (!u) return SK_E_ARG;
-    return sk_tally_collect_sparse(u->uc, out, cap, n, out_hits, out_nhits);
+    if (!u || !n || !out_nhits || (cap && !out)) return SK_E_ARG;
+    sk_ctx *c = u->uc;
+    if (!c->t_inflight_nrec) return sk_fail(c, SK_E_STATE, "no tally in flight");
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    c->t_inflight_nrec = 0;
+    unsigned long long cnt[3];
+    memcpy(cnt, c->h_tally, 24);
+    const unsigned long long take_r = cnt[1] < cap ? cnt[1] : cap;
+    if (take_r) SK_HIP(c, hipMemcpy(out, c->t_compact, (size_t)take_r * sizeof(sk_tally_rec), hipMemcpyDeviceToHost));
+    *n = cnt[1];
+    // the raw log holds one entry per hit, the caller gets one per hit AND strain: if the raw log itself ran over, entries are
+    // missing from the count below -- report at least one more than the room there was
+    unsigned long long nh = cnt[2];
+    if (cnt[0] > c->t_inflight_cap && nh <= c->t_inflight_cap) nh = cnt[0] > nh ? cnt[0] : c->t_inflight_cap + 1;
+    const unsigned long long take = nh < c->t_inflight_cap ? nh : c->t_inflight_cap;
+    if (take && !out_hits) return SK_E_ARG;
+    if (take) SK_HIP(c, hipMemcpy(out_hits, c->t_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost));
+    *out_nhits = nh;
+    return SK_OK;
 }
 
+extern "C" int sk_union_scan_timing(sk_union *u, double *total_ms, uint64_t *launches, int reset)
+{
+    return u ? sk_scan_timing(u->uc, total_ms, launches, reset) : SK_E_ARG;
+}
 extern "C" const char *sk_union_last_error(const sk_union *u) { return u ? u->uc->err : "no union"; }
 extern "C" uint32_t sk_union_members(const sk_union *u) { return u ? u->n : 0u; }
 extern "C" uint32_t sk_union_rows(const sk_union *u) { return u ? u->uc->nrows : 0u; }

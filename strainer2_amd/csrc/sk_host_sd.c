@@ -784,7 +784,7 @@ static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c
         }
         memset(cnt, 0, sizeof cnt); memset(hcnt, 0, sizeof hcnt);
         for (e = 0; e < nsp; e++) cnt[sd_un.recs[e].rec % n]++;
-        for (e = 0; e < nh; e++) hcnt[sd_un.hits[e].pos >> 26]++;
+        for (e = 0; e < nh; e++) hcnt[sd_un.hits[e].row >> SK_UNION_ROW_BITS]++;
         for (s = 0; s < n; s++) {
             sd_prog *q = &p[a + s];
             if (q->tallycap < cnt[s] || !q->tallybuf) {
@@ -802,9 +802,9 @@ static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c
             out->rec = sd_un.recs[e].rec / n; out->all = sd_un.recs[e].all; out->inf = sd_un.recs[e].inf;
         }
         for (e = 0; e < nh; e++) {
-            sd_prog *q = &p[a + (sd_un.hits[e].pos >> 26)];
+            sd_prog *q = &p[a + (sd_un.hits[e].row >> SK_UNION_ROW_BITS)];
             sk_hit *out = q->hitbuf + q->u_nh++;
-            out->pos = sd_un.hits[e].pos & ((1u << 26) - 1u); out->row = sd_un.hits[e].row;
+            out->pos = sd_un.hits[e].pos; out->row = sd_un.hits[e].row & ((1u << SK_UNION_ROW_BITS) - 1u);
         }
     }
     return SK_OK;
@@ -816,7 +816,7 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *poo
     uint32_t s;
     int rc;
     double t0 = now_s(), t1;
-    const int use_union = sd_un.n && c->blen < (1u << 26);
+    const int use_union = sd_un.n != 0;
     c->nstrains = ns;
     c->sp = (sd_sp *)calloc(ns, sizeof *c->sp);
     if (c->np) {

@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
     "sk_distinct_count", "sk_first_seen_count", "skh_coverage_depth_main",
     "sk_batch_create", "sk_batch_destroy", "sk_batch_fill", "sk_tally_launch", "sk_tally_collect", "sk_tally_collect_sparse",
-    "sk_union_create", "sk_union_destroy", "sk_union_tally_launch", "sk_union_tally_collect", "sk_union_last_error",
+    "sk_union_create", "sk_union_destroy", "sk_union_tally_launch", "sk_union_tally_collect", "sk_union_last_error", "sk_union_scan_timing",
     "sk_union_members", "sk_union_rows",
 ]
 
@@ -150,6 +150,7 @@ lib.sk_tally_collect_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.PO
 lib.sk_union_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
 lib.sk_union_destroy.argtypes = [C.c_void_p]
 lib.sk_union_destroy.restype = None
+lib.sk_union_scan_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
 lib.sk_union_tally_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
 lib.sk_union_tally_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]
 lib.sk_union_last_error.argtypes = [C.c_void_p]
@@ -463,7 +464,7 @@ class KmerUnion:
         recs = recs[: nr.value]
         tally[recs[:, 0]] = recs[:, 1:]
         hits = hits[: nh.value]
-        out = np.stack([hits[:, 0] >> 26, hits[:, 0] & ((1 << 26) - 1), hits[:, 1]], axis=1) if len(hits) else np.zeros((0, 3), dtype=np.uint32)
+        out = np.stack([hits[:, 1] >> 27, hits[:, 0], hits[:, 1] & ((1 << 27) - 1)], axis=1) if len(hits) else np.zeros((0, 3), dtype=np.uint32)
         order = np.lexsort((out[:, 2], out[:, 1], out[:, 0]))
         return tally.reshape(nrec, n, 2), out[order]
 

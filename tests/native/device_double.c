@@ -153,7 +153,6 @@ uint32_t sk_union_rows(const sk_union *u) { uint32_t i, r = 0; for (i = 0; i < u
 const char *sk_union_last_error(const sk_union *u) { (void)u; return "stub"; }
 int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t cap)
 {
-    if (b->nbytes >= (1u << 26)) return SK_E_ARG;
     u->b = b; u->cap = cap;
     return SK_OK;
 }
@@ -168,7 +167,7 @@ int sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t cap, uint64_
         sk_tally_launch(u->m[s], u->b, u->type_col, u->inf_value, u->cap);
         sk_tally_collect_sparse(u->m[s], one, nrec, &got, oh, &goth);
         for (i = 0; i < got; i++) { if (k < cap) { out[k].rec = one[i].rec * u->n + s; out[k].all = one[i].all; out[k].inf = one[i].inf; } k++; }
-        for (i = 0; i < goth; i++) { if (nh < u->cap && i < u->cap) { hits[nh].pos = oh[i].pos | (s << 26); hits[nh].row = oh[i].row; } nh++; }
+        for (i = 0; i < goth; i++) { if (nh < u->cap && i < u->cap) { hits[nh].pos = oh[i].pos; hits[nh].row = oh[i].row | (s << SK_UNION_ROW_BITS); } nh++; }
     }
     free(one); free(oh);
     *n = k; *nhits = nh;

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""tools/sd_cfg5_share.py -- one GPU's share of BASELINE configs[4] at size: `strain_detect -S` with 32 strains of 5 Mbp resident
+against a 100 Gbase SE metagenome (the 10 Gbase reads file of strainer2_amd/cfg5.py listed ten times in -B), on the GPU box.
+
+  1. writes the inputs under WORK (default /dev/shm/sk_cfg5: 10.3 GB of FASTA + 32 strains + their -a lists)
+  2. PIN: runs bin/strain_detect -S (all 32 strains, one union table) on the 1 Gbase PREFIX of the metagenome and compares the -o files of
+     the two pinned strains (decompressed md5, lines, bytes, stdout, stderr) with tests/golden/cfg5_share_facts.json -- what the UNMODIFIED
+     reference program wrote for exactly these inputs in the build container (tests/golden/make_cfg5_share_facts.py)
+  3. SIZE: runs bin/strain_detect -S on the whole -B list (100 Gbase scanned), wall clock and the program's own timing lines; the
+     size-independent checks: every strain's file must be LIST_REPEAT identical parts (one per list line: hit lines + the four
+     trailer lines, src/strain_detect.c:263-384,633-636), and every part must BEGIN with the hit lines of that strain's prefix run
+     (same reads in the same order; only the file name in column 1 differs)
+Prints one JSON object (kept as profiles/r03_cfg5_share.json); exit status 1 on any difference.
+
+  python3 tools/sd_cfg5_share.py        (env: WORK, PROCS, KEEP=1, SKIP_FULL=1)
+"""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from strainer2_amd import cfg5  # noqa: E402
+
+WORK = os.environ.get("WORK", "/dev/shm/sk_cfg5")
+FACTS = os.path.join(REPO, "tests", "golden", "cfg5_share_facts.json")
+
+
+def run(exe, argv, **env):
+    t = time.time()
+    p = subprocess.run([exe] + argv, cwd=WORK, capture_output=True, env=dict(os.environ, SK_SD_TIMING="1", **env))
+    return p, time.time() - t
+
+
+def split_timing(err):
+    lines = err.decode(errors="replace").split("\n")
+    timing = [ln for ln in lines if ln.startswith("strain_detect timing") or ln.startswith("strain_detect: no union table")]
+    rest = "".join(ln + "\n" for ln in lines if ln and ln not in timing)
+    return timing, rest
+
+
+def main():
+    facts = json.load(open(FACTS))
+    assert facts["prefix_reads"] == cfg5.PREFIX_READS
+    exe = os.path.join(REPO, "strainer2_amd", "bin", "strain_detect")
+    t0 = time.time()
+    paths = cfg5.write_all(WORK, procs=int(os.environ.get("PROCS", "16")),
+                           progress=lambda n, m: print(f"  inputs {n}/{m} {time.time() - t0:.0f} s", file=sys.stderr, flush=True))
+    t_write = time.time() - t0
+    report = {"job": "strain_detect -S, %d strains x %d bp resident; SE FASTA of %d x %d bp reads (%.2f Gbase) listed %d times = %.1f Gbase scanned"
+                     % (cfg5.NSTRAINS, cfg5.STRAIN_BP, cfg5.READS, cfg5.READ_LEN, cfg5.READS * cfg5.READ_LEN / 1e9, cfg5.LIST_REPEAT,
+                        cfg5.LIST_REPEAT * cfg5.READS * cfg5.READ_LEN / 1e9),
+              "inputs_written_in_s": round(t_write, 1)}
+    ok = True
+    # ---- 2. the prefix, pinned to the reference
+    p, wall = run(exe, ["-S", paths["strains_prefix"], "-b", paths["prefix"], "-t", "SE"])
+    timing, rest = split_timing(p.stderr)
+    pin = {"wall_s": round(wall, 2), "returncode": p.returncode, "timing": timing, "strains": {}}
+    for s, want in facts["strains"].items():
+        hits = gzip.open(os.path.join(WORK, f"prefix{s}.gz"), "rb").read()
+        got = {"hits_md5": hashlib.md5(hits).hexdigest(), "hits_bytes": len(hits), "hits_lines": hits.count(b"\n")}
+        same = all(got[k] == want[k] for k in got) and p.returncode == want["returncode"] and p.stdout.decode() == want["stdout"] and rest == want["stderr"]
+        pin["strains"][s] = dict(got, identical_to_the_reference=same)
+        ok = ok and same
+    report["prefix_%.1f_gbase_pinned" % (cfg5.PREFIX_READS * cfg5.READ_LEN / 1e9)] = pin
+    report["facts"] = "tests/golden/cfg5_share_facts.json (" + facts["producer"] + ")"
+    # ---- 3. the whole list
+    if not os.environ.get("SKIP_FULL"):
+        p, wall = run(exe, ["-S", paths["strains"], "-B", paths["B"]])
+        timing, rest = split_timing(p.stderr)
+        bases = cfg5.LIST_REPEAT * cfg5.READS * cfg5.READ_LEN
+        full = {"wall_s": round(wall, 2), "returncode": p.returncode, "bases_scanned": bases, "strain_x_bases_per_s": round(cfg5.NSTRAINS * bases / wall),
+                "metagenome_bases_per_s": round(bases / wall), "timing": timing, "stderr_other": rest[-500:]}
+        # size-independent check: a list line is scanned as often as it is listed, so every strain's file is LIST_REPEAT equal parts, and
+        # a part begins with the hit lines of the prefix run (same reads, same order; the file name in column 1 differs)
+        parts_ok, prefix_ok, lines = True, True, 0
+        for s in range(cfg5.NSTRAINS):
+            data = gzip.open(os.path.join(WORK, f"multi{s}.gz"), "rb").read()
+            lines += data.count(b"\n")
+            n = len(data) // cfg5.LIST_REPEAT
+            part = data[:n]
+            parts_ok = parts_ok and len(data) == n * cfg5.LIST_REPEAT and all(data[i * n:(i + 1) * n] == part for i in range(cfg5.LIST_REPEAT))
+            pre = [ln.split(b"\t", 1)[1] for ln in gzip.open(os.path.join(WORK, f"prefix{s}.gz"), "rb").read().split(b"\n") if ln and not ln.startswith(b"#")]
+            head = [ln.split(b"\t", 1)[1] for ln in part.split(b"\n")[:len(pre)]]
+            prefix_ok = prefix_ok and head == pre
+        full["every_file_is_%d_equal_parts" % cfg5.LIST_REPEAT] = parts_ok
+        full["every_part_begins_with_the_prefix_runs_hit_lines"] = prefix_ok
+        full["output_lines"] = lines
+        ok = ok and parts_ok and prefix_ok and p.returncode == 0
+        report["full_pass"] = full
+    report["ok"] = ok
+    print(json.dumps(report, indent=1))
+    if not os.environ.get("KEEP"):
+        shutil.rmtree(WORK, ignore_errors=True)
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
