@@ -1475,6 +1475,55 @@ __global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint
     }
 }
 
+// the same set from the table's slots (a table loaded without a text stage: built when the first scan needs it)
+__global__ void sk_grid_insert_slots(const sk_u4 *__restrict__ slots, uint64_t nslots, uint32_t *__restrict__ w1, uint32_t nblocks1,
+                                     uint32_t *__restrict__ w2, uint32_t shift2)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += stride) {
+        const uint64_t k = sk_slot_key(slots[i]);
+        if (k == SK_EMPTY64) continue;
+        for (int off = 0; off < 16; off++) {
+            const uint32_t f = (uint32_t)(k >> (2 * (15 - off)));
+            const uint32_t r = sk_revcomp16(f);
+            const uint32_t g = sk_gmix(f < r ? f : r);
+            const uint32_t a = sk_grid1_bits(g), b = sk_grid2_bits(g);
+            uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
+            uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
+            if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
+            if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
+            blk = w2 + 2u * (size_t)sk_grid2_block(g, shift2);
+            m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)); m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
+            if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
+            if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
+        }
+    }
+}
+
+// ... and from the strain's TEXT, when every key is a window of it: a key's sixteen 16-mers are the text's 16-mers at its
+// place and the fifteen places behind it, and consecutive keys share fifteen of them -- inserting every 16-mer of the text ONCE
+// does in nbases steps what the key-wise kernels do in 16 x nrows (5.5 ms -> 0.3 ms for a 5 Mbp strain; 167 ms -> 10 ms for the
+// union of 32).  16-mers that no key holds (across an N, across two records) only add a few false positives.
+__global__ void sk_grid_insert_text(const uint32_t *__restrict__ text2, uint32_t nbases, uint32_t *__restrict__ w1, uint32_t nblocks1,
+                                    uint32_t *__restrict__ w2, uint32_t shift2)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q + 16u > nbases) return;
+    const uint32_t w = q >> 4, o2 = 2u * (q & 15u);
+    const uint32_t f = (uint32_t)(((((uint64_t)text2[w] << 32) | text2[w + 1u]) << o2) >> 32);
+    const uint32_t r = sk_revcomp16(f);
+    const uint32_t g = sk_gmix(f < r ? f : r);
+    const uint32_t a = sk_grid1_bits(g), b = sk_grid2_bits(g);
+    uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
+    uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
+    if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
+    if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
+    blk = w2 + 2u * (size_t)sk_grid2_block(g, shift2);
+    m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)); m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
+    if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
+    if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
@@ -1497,6 +1546,8 @@ struct sk_ctx {
     uint2       *d_grid1, *d_grid2;       // grid kernel's two filter levels
     uint32_t     grid1_blocks, grid2_blocks_log2;
     long         grid_kib;                // option: size of level 1 in KiB (-1 = automatic)
+    bool         grid_pending;            // the two levels are allocated and zeroed, not filled yet (sk_grid_ensure)
+    bool         all_rows_in_text;        // every key is a window of the text stage (sk_table_load_text)
     long         odd_cap;                 // option (tests): usable length of the odd-chunk list, 0 = all of it
     uint32_t     nrows, ncols;
     uint32_t    *d_counts;
@@ -1637,6 +1688,7 @@ static void sk_table_release(sk_ctx *c)
     hipFree(c->d_grid1); c->d_grid1 = NULL;
     hipFree(c->d_grid2); c->d_grid2 = NULL;
     hipFree(c->d_grid3); c->d_grid3 = NULL;
+    c->grid_pending = false; c->all_rows_in_text = false;
     hipFree(c->d_counts); c->d_counts = NULL;
     hipFree(c->d_perm); c->d_perm = NULL;
     c->h_perm.clear();
@@ -1768,8 +1820,10 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
             SK_HIP(c, hipMalloc((void **)&c->d_grid2, b2));
             SK_HIP(c, hipMemsetAsync(c->d_grid1, 0, b1, c->stream));
             SK_HIP(c, hipMemsetAsync(c->d_grid2, 0, b2, c->stream));
-            hipLaunchKernelGGL(sk_grid_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, d_in, nrows,
-                               (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+            // filled when it is known from what: by sk_table_load_text from the strain's text (one insert per base instead of
+            // sixteen per key), or -- no text stage -- from the slots when the first scan asks (sk_grid_ensure)
+            c->grid_pending = true;
+            c->all_rows_in_text = false;
         }
         uint32_t flags[2] = {0, 0};
         SK_HIP(c, hipMemcpyAsync(flags, c->d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
@@ -1858,9 +1912,26 @@ extern "C" int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nba
     SK_HIP(c, hipMemcpyAsync(c->d_rank, rank.data(), nblk * sizeof(sk_u4), hipMemcpyHostToDevice, c->stream));
     SK_HIP(c, hipMemcpyAsync(c->d_tmp, pos_by_idx.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(sk_table_setpos, dim3(4096), dim3(256), 0, c->stream, c->d_keys, (uint64_t)1 << c->slots_log2, c->d_tmp);
+    c->all_rows_in_text = m == nrows;
+    if (c->grid_pending && c->all_rows_in_text) {          // (rows without a place in the text -- a U in the strain -- : from the slots, sk_grid_ensure)
+        hipLaunchKernelGGL(sk_grid_insert_text, dim3((nbases + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)c->d_text2, nbases,
+                           (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+        c->grid_pending = false;
+    }
     SK_HIP(c, hipStreamSynchronize(c->stream));
     SK_HIP(c, hipGetLastError());
     c->text_bases = nbases;
+    return SK_OK;
+}
+
+// the filter levels of a table that has no text stage (or keys outside it): from the slots, once, before the first scan
+static int sk_grid_ensure(sk_ctx *c)
+{
+    if (!c->grid_pending) return SK_OK;
+    hipLaunchKernelGGL(sk_grid_insert_slots, dim3(4096), dim3(256), 0, c->stream, (const sk_u4 *)c->d_keys, (uint64_t)1 << c->slots_log2,
+                       (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+    SK_HIP(c, hipGetLastError());
+    c->grid_pending = false;
     return SK_OK;
 }
 
@@ -1913,6 +1984,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     }
     const dim3 grid((uint32_t)ntiles), block(SK_THREADS);
     if (!c->d_grid1) return sk_fail(c, SK_E_STATE, "no table loaded");
+    { int grc = sk_grid_ensure(c); if (grc) return grc; }
 
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(uint32_t), c->stream));     // [0] odd bytes seen, [2] listed chunks
     // timing: a begin/end event pair per launch from a small ring -- the oldest pair is added to the totals (its launch is
@@ -2465,8 +2537,14 @@ extern "C" int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type
         SK_U(hipMalloc((void **)&c->d_grid2, b2));
         SK_U(hipMemsetAsync(c->d_grid1, 0, b1, c->stream));
         SK_U(hipMemsetAsync(c->d_grid2, 0, b2, c->stream));
-        hipLaunchKernelGGL(sk_grid_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)u->d_ukeys, nrows,
-                           (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+        bool from_text = true;                              // (every member's keys are windows of its text: one insert per base of the union's text)
+        for (uint32_t s2 = 0; s2 < n; s2++) from_text = from_text && members[s2]->all_rows_in_text;
+        if (from_text)
+            hipLaunchKernelGGL(sk_grid_insert_text, dim3((text_bases + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)c->d_text2, text_bases,
+                               (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+        else
+            hipLaunchKernelGGL(sk_grid_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)u->d_ukeys, nrows,
+                               (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
     }
     SK_U(hipMalloc((void **)&u->d_members, n * sizeof(sk_union_member)));
     SK_U(hipMemcpyAsync(u->d_members, hm.data(), n * sizeof(sk_union_member), hipMemcpyHostToDevice, c->stream));
@@ -2634,12 +2712,13 @@ extern "C" int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t nbytes)
     void *m = NULL;
     bool registered = true;
     if (posix_memalign(&m, 4096, want) != 0) return SK_E_NOMEM;
-    if (hipHostRegister(m, want, hipHostRegisterDefault) != hipSuccess) {      // (a limit on registered memory, say): the slower way
+    // (portable: every device of the process may DMA from it -- one decoded chunk goes up to several GPUs, sk_host_sd.c)
+    if (hipHostRegister(m, want, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {      // (a limit on registered memory, say): the slower way
         free(m);
         m = NULL;
         registered = false;
         (void)hipGetLastError();
-        if (hipHostMalloc(&m, want, hipHostMallocDefault) != hipSuccess) return sk_fail(c, SK_E_NOMEM, "no page-locked memory (%zu bytes)", want);
+        if (hipHostMalloc(&m, want, hipHostMallocPortable) != hipSuccess) return sk_fail(c, SK_E_NOMEM, "no page-locked memory (%zu bytes)", want);
     }
     pthread_mutex_lock(&c->pin_mu);
     c->pins.push_back((sk_pin){m, want, true, registered});

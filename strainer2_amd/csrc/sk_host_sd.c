@@ -40,6 +40,19 @@
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
 enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
 #define SD_BATCH_BYTES (32u << 20)
+/* ONE process, ONE decode pipeline, several devices (strain_detect -S with SK_DEVICES=n; BASELINE configs[4]: 256 strains on the 8
+ * GPUs of a node).  The strains are dealt to the devices in groups of SK_UNION_MAX (one union table per group: group g lives on
+ * logical device g mod n); a decoded chunk of the metagenome is uploaded ONCE PER DEVICE from the same page-locked buffer (every
+ * GPU has its own PCIe link: the copies run side by side), every device scans it against its own strains, and the results come
+ * back to the one host that replays each strain's bookkeeping.  Against `torchrun`-style one-process-per-GPU with the strains
+ * dealt to ranks (which still works: RANK/WORLD_SIZE) the metagenome is inflated and parsed once instead of once per GPU.
+ * New relative to the reference, which is one process, one strain (src/strain_detect.c:263-384).
+ * phys[d] = the HIP device behind logical device d: SK_DEVICES=n -> SK_DEVICE + 0..n-1; SK_DEVICES=0,0,0 -> as listed (several
+ * logical devices on one card: how the path is tested on a one-GPU box). */
+#define SD_MAX_DEV 8
+static struct { int n; int phys[SD_MAX_DEV]; sk_ctx *ctx[SD_MAX_DEV]; } sd_dev = { 1, {0}, {NULL} };
+static uint32_t sd_group = SK_UNION_MAX;                  /* strains per union table (SK_SD_GROUP: smaller groups, for tests of the dealing) */
+static int sd_dev_of_strain(uint32_t s) { return (int)((s / sd_group) % (uint32_t)sd_dev.n); }
 /* SK_SD_CHUNK_BYTES: smaller chunks (tests: chunk boundaries between mates, carried state across chunks) */
 /* strain_detect never shows the order of the table's rows (hits are printed read by read with the k-mer's text; the
  * trailer counts rows), so the 0.2 s replay of BIO_hash's slot order (sk_host.c) is left out: rows in strain order.
@@ -113,8 +126,9 @@ typedef struct {
     /* consumer */
     sd_chunk   *c; uint32_t ci;
     int         eof, end_kind; size_t end_len;
-    /* two device batches in turn: while the chunk in one is scanned, the next chunk of the queue is uploaded into the other */
-    sk_batch   *bat[2]; int bcur;
+    /* two device batches in turn: while the chunk in one is scanned, the next chunk of the queue is uploaded into the other;
+     * with several devices (sd_dev) every device has its own pair -- one decoded chunk goes up to all of them */
+    sk_batch   *bat[2][SD_MAX_DEV]; int bcur;
     sd_chunk   *pre;                         /* the queued chunk whose bytes are already in bat[bcur ^ 1] */
 } sd_stream;
 
@@ -521,8 +535,10 @@ static void stream_close(sd_stream *st)
         pthread_mutex_destroy(&st->pmu);
         pthread_cond_destroy(&st->pcv);
     }
-    sk_batch_destroy(st->bat[0]);                       /* (waits for an upload in flight before the chunks go) */
-    sk_batch_destroy(st->bat[1]);
+    for (i = 0; i < SD_MAX_DEV; i++) {
+        sk_batch_destroy(st->bat[0][i]);                /* (waits for an upload in flight before the chunks go) */
+        sk_batch_destroy(st->bat[1][i]);
+    }
     for (i = 0; i < st->qn; i++) chunk_free(st->q[i]);
     chunk_free(st->c);
     chunk_free(st->cur);
@@ -546,18 +562,26 @@ typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
     unsigned long gen; int quit;
     sd_job_fn fn; void *arg; uint32_t ns;
-    uint32_t next, done;
+    uint64_t ticket;                 /* (job number << 32) | next item: an item is claimed by a CAS that also proves the job is still the same */
+    uint32_t done;
 } sd_pool;
 
-static void pool_drain(sd_pool *pl)
+/* Items of job `job` are claimed through ONE word that holds the job's number beside the item counter: a worker that comes late
+ * out of the previous job cannot take an item of the next one (nor read that job's fn/arg/ns half written) -- its CAS fails on
+ * the job number.  fn, arg and ns are written before the release store that opens the job and read after an acquire load of the
+ * ticket that shows the job's number.  (ThreadSanitizer found the old form -- a bare counter, ns read without order -- with five
+ * strains on four threads.) */
+static void pool_drain(sd_pool *pl, uint32_t job, uint32_t ns, sd_job_fn fn, void *arg)     /* (the job's own ns/fn/arg, read under the mutex) */
 {
     uint32_t mine = 0;
     for (;;) {
-        const uint32_t s = __atomic_fetch_add(&pl->next, 1u, __ATOMIC_ACQ_REL);   /* pairs with the release store that opens a job */
-        if (s >= pl->ns) break;
-        pl->fn(pl->arg, s);
+        uint64_t t = __atomic_load_n(&pl->ticket, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(t >> 32) != job || (uint32_t)t >= ns) break;
+        if (!__atomic_compare_exchange_n(&pl->ticket, &t, t + 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) continue;
+        fn(arg, (uint32_t)t);
         mine++;
     }
+    if (!mine) return;
     pthread_mutex_lock(&pl->mu);
     pl->done += mine;
     if (pl->done == pl->ns) pthread_cond_broadcast(&pl->cv_done);
@@ -573,8 +597,13 @@ static void *pool_worker_sd(void *arg)
         while (pl->gen == seen && !pl->quit) pthread_cond_wait(&pl->cv_work, &pl->mu);
         if (pl->quit) { pthread_mutex_unlock(&pl->mu); return NULL; }
         seen = pl->gen;
-        pthread_mutex_unlock(&pl->mu);
-        pool_drain(pl);
+        {
+            const uint32_t ns = pl->ns;
+            const sd_job_fn fn = pl->fn;
+            void *const arg = pl->arg;
+            pthread_mutex_unlock(&pl->mu);
+            pool_drain(pl, (uint32_t)seen, ns, fn, arg);
+        }
     }
 }
 
@@ -611,14 +640,16 @@ static void pool_run(sd_pool *pl, uint32_t ns, sd_job_fn fn, void *arg)
         for (s = 0; s < ns; s++) fn(arg, s);
         return;
     }
-    pthread_mutex_lock(&pl->mu);
+    uint32_t job;
+    pthread_mutex_lock(&pl->mu);                         /* (every item of the previous job is done: nobody reads fn/arg/ns now) */
     pl->fn = fn; pl->arg = arg; pl->ns = ns;
     pl->done = 0;
-    __atomic_store_n(&pl->next, 0u, __ATOMIC_RELEASE);   /* a worker still leaving the previous job may pick up this one's items */
     pl->gen++;
+    job = (uint32_t)pl->gen;
+    __atomic_store_n(&pl->ticket, (uint64_t)job << 32, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&pl->cv_work);
     pthread_mutex_unlock(&pl->mu);
-    pool_drain(pl);
+    pool_drain(pl, job, ns, fn, arg);
     pthread_mutex_lock(&pl->mu);
     while (pl->done != pl->ns) pthread_cond_wait(&pl->cv_done, &pl->mu);
     pthread_mutex_unlock(&pl->mu);
@@ -639,7 +670,7 @@ static int hit_cmp(const void *a, const void *b)
 /* tally one chunk against every strain: one upload, one launch per strain (they overlap on the device),
  * then -- strain by strain on the pool -- the per-record tallies and per-record lists of informative rows, in
  * window order */
-typedef struct { sd_prog *p; sk_batch *batch; sd_chunk *c; int from_union; } sd_tally_job;
+typedef struct { sd_prog *p; sk_batch **batches; sd_chunk *c; int from_union; } sd_tally_job;
 
 static void tally_one(void *arg, uint32_t s)
 {
@@ -667,7 +698,7 @@ static void tally_one(void *arg, uint32_t s)
     if (nh > p->hitcap) {                                 /* the log overflowed: once more with room */
         p->hitcap = nh + nh / 4;
         p->hitbuf = (sk_hit *)realloc(p->hitbuf, (size_t)p->hitcap * sizeof(sk_hit));
-        if ((rc = sk_tally_launch(p->ctx, j->batch, SD_TYPE, SD_INFORMATIVE, p->hitcap)) != SK_OK ||
+        if ((rc = sk_tally_launch(p->ctx, j->batches[sd_dev_of_strain(s)], SD_TYPE, SD_INFORMATIVE, p->hitcap)) != SK_OK ||
             (rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
     }
     }
@@ -713,7 +744,7 @@ static void sd_unions_close(void)
 
 static void sd_unions_open(sd_prog *p, uint32_t ns)
 {
-    uint32_t g, ng = (ns + SK_UNION_MAX - 1) / SK_UNION_MAX;
+    uint32_t g, ng = (ns + sd_group - 1) / sd_group;
     const double t0 = now_s();
     memset(&sd_un, 0, sizeof sd_un);
     if (ns < 2 || getenv("SK_SD_NO_UNION")) return;
@@ -721,7 +752,7 @@ static void sd_unions_open(sd_prog *p, uint32_t ns)
     sd_un.hcap = (uint64_t *)calloc(ng, sizeof *sd_un.hcap);
     for (g = 0; g < ng; g++) {
         sk_ctx *m[SK_UNION_MAX];
-        const uint32_t a = g * SK_UNION_MAX, n = ns - a < SK_UNION_MAX ? ns - a : SK_UNION_MAX;
+        const uint32_t a = g * sd_group, n = ns - a < sd_group ? ns - a : sd_group;
         uint32_t k;
         int rc;
         for (k = 0; k < n; k++) m[k] = p[a + k].ctx;
@@ -740,33 +771,36 @@ static void sd_unions_open(sd_prog *p, uint32_t ns)
 
 /* while the device scans the current chunk: the next chunk of the stream's queue (if the reader is ahead) goes up into the
  * stream's other batch -- the upload of a 32 MiB chunk takes about twice as long as its scan against a union table */
-static void sd_prefetch(sd_stream *st, sk_ctx *ctx)
+static void sd_prefetch(sd_stream *st)
 {
     sd_chunk *n = NULL;
-    sk_batch **b;
     const double t0 = now_s();
+    int d, ok = 1;
     if (!st) return;
     pthread_mutex_lock(&st->mu);
     if (st->qn > 0) n = st->q[0];                          /* (only this thread takes chunks off the queue: n stays) */
     pthread_mutex_unlock(&st->mu);
     if (!n || n == st->pre || !n->np) return;
-    b = &st->bat[st->bcur ^ 1];
-    if (!*b && sk_batch_create(ctx, b) != SK_OK) { *b = NULL; return; }
-    if (sk_batch_fill(*b, n->buf, n->blen, n->pstart, n->np) == SK_OK) st->pre = n;
+    for (d = 0; d < sd_dev.n && ok; d++) {
+        sk_batch **b = &st->bat[st->bcur ^ 1][d];
+        if (!*b && sk_batch_create(sd_dev.ctx[d], b) != SK_OK) { *b = NULL; ok = 0; break; }
+        ok = sk_batch_fill(*b, n->buf, n->blen, n->pstart, n->np) == SK_OK;
+    }
+    if (ok) st->pre = n;                                   /* (all devices or none: a chunk that is not everywhere goes up again) */
     t_fill += now_s() - t0;
 }
 
 /* one batch against the unions; the results are dealt to the strains' tallybuf/hitbuf (u_nsp, u_nh entries) */
-static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c, sd_stream *st)
+static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chunk *c, sd_stream *st)
 {
     uint32_t g, s;
     int rc;
     for (g = 0; g < sd_un.n; g++)
-        if ((rc = sk_union_tally_launch(sd_un.u[g], batch, sd_un.hcap[g])) != SK_OK) return rc;
-    sd_prefetch(st, p[0].ctx);
+        if ((rc = sk_union_tally_launch(sd_un.u[g], batches[sd_dev_of_strain(g * sd_group)], sd_un.hcap[g])) != SK_OK) return rc;
+    sd_prefetch(st);
     for (s = 0; s < ns; s++) p[s].u_nsp = p[s].u_nh = 0;
     for (g = 0; g < sd_un.n; g++) {
-        const uint32_t a = g * SK_UNION_MAX, n = sk_union_members(sd_un.u[g]);
+        const uint32_t a = g * sd_group, n = sk_union_members(sd_un.u[g]);
         const uint64_t worst = (uint64_t)c->np * n;
         uint64_t nsp = 0, nh = 0, e;
         uint64_t cnt[SK_UNION_MAX], hcnt[SK_UNION_MAX];
@@ -780,7 +814,7 @@ static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c
             if ((rc = sk_union_tally_collect(sd_un.u[g], sd_un.recs, sd_un.recs_cap, &nsp, sd_un.hits, &nh)) != SK_OK) return rc;
             if (nh <= sd_un.hcap[g]) break;
             sd_un.hcap[g] = nh + nh / 4;                    /* the log overflowed: once more with room */
-            if ((rc = sk_union_tally_launch(sd_un.u[g], batch, sd_un.hcap[g])) != SK_OK) return rc;
+            if ((rc = sk_union_tally_launch(sd_un.u[g], batches[sd_dev_of_strain(a)], sd_un.hcap[g])) != SK_OK) return rc;
         }
         memset(cnt, 0, sizeof cnt); memset(hcnt, 0, sizeof hcnt);
         for (e = 0; e < nsp; e++) cnt[sd_un.recs[e].rec % n]++;
@@ -810,7 +844,7 @@ static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch *batch, sd_chunk *c
     return SK_OK;
 }
 
-static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, sd_chunk *c, int uploaded, sd_stream *st)
+static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch **batches, sd_pool *pool, sd_chunk *c, int uploaded, sd_stream *st)
 {
     sd_tally_job job;
     uint32_t s;
@@ -820,20 +854,22 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *poo
     c->nstrains = ns;
     c->sp = (sd_sp *)calloc(ns, sizeof *c->sp);
     if (c->np) {
-        if (!uploaded && (rc = sk_batch_fill(batch, c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
+        int d;
+        for (d = 0; d < sd_dev.n && !uploaded; d++)              /* (asynchronous copies from page-locked memory: the devices' uploads overlap) */
+            if ((rc = sk_batch_fill(batches[d], c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
         t1 = now_s(); t_fill += t1 - t0; t0 = t1;
         if (use_union) {
-            if ((rc = sd_tally_unions(p, ns, batch, c, st)) != SK_OK) return rc;
+            if ((rc = sd_tally_unions(p, ns, batches, c, st)) != SK_OK) return rc;
         } else {
             for (s = 0; s < ns; s++) {
                 if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
-                if ((rc = sk_tally_launch(p[s].ctx, batch, SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
+                if ((rc = sk_tally_launch(p[s].ctx, batches[sd_dev_of_strain(s)], SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
             }
-            sd_prefetch(st, p[0].ctx);
+            sd_prefetch(st);
         }
         t1 = now_s(); t_launch += t1 - t0; t0 = t1;
     }
-    job.p = p; job.batch = batch; job.c = c; job.from_union = use_union;
+    job.p = p; job.batches = batches; job.c = c; job.from_union = use_union;
     pool_run(pool, ns, tally_one, &job);
     t_post += now_s() - t0;
     for (s = 0; s < ns; s++) if (p[s].job_rc != SK_OK) return p[s].job_rc;
@@ -874,7 +910,8 @@ static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, 
             (void)batch;
             if (uploaded) st->bcur ^= 1;
             st->pre = NULL;
-            if (!st->bat[st->bcur] && (rc = sk_batch_create(p[0].ctx, &st->bat[st->bcur])) != SK_OK) { st->bat[st->bcur] = NULL; chunk_free(c); return rc; }
+            for (i = 0; i < sd_dev.n; i++)
+                if (!st->bat[st->bcur][i] && (rc = sk_batch_create(sd_dev.ctx[i], &st->bat[st->bcur][i])) != SK_OK) { st->bat[st->bcur][i] = NULL; chunk_free(c); return rc; }
             rc = sd_tally_chunk(p, ns, st->bat[st->bcur], pool, c, uploaded, st);
             t_tally += now_s() - t0;
         }
@@ -1535,6 +1572,10 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
         usage(err); return 1;
     }
     if ((env = getenv("SK_DEVICE")) != NULL) device = atoi(env);
+    sd_dev.n = 1; sd_dev.phys[0] = device;
+    sd_group = SK_UNION_MAX;
+    if ((env = getenv("SK_SD_GROUP")) != NULL && atoi(env) >= 1 && atoi(env) <= SK_UNION_MAX) sd_group = (uint32_t)atoi(env);
+    memset(sd_dev.ctx, 0, sizeof sd_dev.ctx);
     t_begin = now_s();
     {
         const long ncpu = sk_cpu_budget();
@@ -1551,6 +1592,24 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
         unsigned lineno = 0;
         if (!fp) { fprintf(err, "strain_detect: could not read the strain list %s\n", S); goto done; }
         if (!getenv("SK_DEVICE") && (env = getenv("SK_LOCAL_RANK") ? getenv("SK_LOCAL_RANK") : getenv("LOCAL_RANK")) != NULL) device = atoi(env);
+        sd_dev.phys[0] = device;
+        if ((env = getenv("SK_DEVICES")) != NULL && *env) {      /* one process, several devices: see sd_dev */
+            if (world > 1) { fprintf(err, "strain_detect: SK_DEVICES is for ONE process that drives several devices (WORLD_SIZE is %d)\n", world); fclose(fp); goto done; }
+            if (strchr(env, ',')) {                               /* the devices as listed (several logical devices may share a card) */
+                const char *q = env;
+                sd_dev.n = 0;
+                while (*q && sd_dev.n < SD_MAX_DEV) {
+                    sd_dev.phys[sd_dev.n++] = atoi(q);
+                    while (*q && *q != ',') q++;
+                    if (*q == ',') q++;
+                }
+            } else {
+                int k;
+                sd_dev.n = atoi(env);
+                if (sd_dev.n < 1 || sd_dev.n > SD_MAX_DEV) { fprintf(err, "strain_detect: SK_DEVICES must be 1..%d or a list of devices\n", SD_MAX_DEV); fclose(fp); goto done; }
+                for (k = 0; k < sd_dev.n; k++) sd_dev.phys[k] = device + k;
+            }
+        }
         while (getline(&line, &cap, fp) != -1) {
             char *nl, *fr, *fa, *fo, *fg;
             if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
@@ -1578,7 +1637,11 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
             sk_ctxjob cj;
             /* the HIP runtime comes up (0.25-3 s) while the first key sets are built: the context opened here becomes the first
              * strain's -- every other sk_ctx_create then finds the runtime ready instead of all workers queueing up behind it */
-            if (ns) sk_ctxjob_start(&cj, device);
+            {   /* no more devices than there are groups of strains */
+                const uint32_t ng = (ns + sd_group - 1) / sd_group;
+                if ((uint32_t)sd_dev.n > ng) sd_dev.n = ng ? (int)ng : 1;
+            }
+            if (ns) sk_ctxjob_start(&cj, sd_dev.phys[0]);
             memset(&kp, 0, sizeof kp);
             kp.jobs = (ks_job *)calloc(ns ? ns : 1, sizeof *kp.jobs);
             kp.njobs = ns;
@@ -1587,7 +1650,7 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
             for (k = 0; k < ns; k++) {
                 ks_job *j = &kp.jobs[k];
                 j->p = &p[k]; j->r = paths[4 * k]; j->a = paths[4 * k + 1]; j->o = paths[4 * k + 2]; j->g = paths[4 * k + 3];
-                j->device = device;
+                j->device = sd_dev.phys[sd_dev_of_strain(k)];
                 j->cj = k == 0 ? &cj : NULL;
             }
             if (nth > 16) nth = 16;
@@ -1621,6 +1684,8 @@ static int sd_main_impl(int argc, char **argv, FILE *out, FILE *err, sk_ctx *ado
         if (adopt_ctx ? sd_strain_adopt(&p[0], adopt_ctx, adopt_ks, a, g, o, out, err) : sd_strain_open(&p[0], r, a, g, o, device, out, err)) goto done;
     }
     t_setup = now_s() - t_begin;
+    for (s = ns; s-- > 0; ) sd_dev.ctx[sd_dev_of_strain(s)] = p[s].ctx;       /* a context on every device (its first strain's): owner of the device's batches */
+    if (getenv("SK_SD_TIMING") && sd_dev.n > 1) fprintf(err, "strain_detect timing: %u strains on %d devices, one decode pipeline\n", ns, sd_dev.n);
     for (s = 0; want_cov && s < ns; s++)
         if (sd_coverage_open(&p[s], S ? NULL : cov_file, cov_min)) goto done;
     if (sd_run(p, ns, B, b, b2, mode, out, err)) goto done;

@@ -14,6 +14,10 @@ job (same rows in the same order in every slice; reference_count identical) and 
 sum / non-zero rows / max / md5 of the u32 vector in the reference's row order, process 0's stderr (the skip message) and the
 md5 of the progress file without its time stamps.
 
+(The assembly was checked against the real thing at a size one process finishes: `--genomes 12 --b-files 3 --reads-per-file 20000`
+gives stdout md5 b2488527...; the reference run ONCE on that whole job, its -B list naming the three files ten times over,
+printed a table with the same md5 and the same progress file -- round 3, build container.)
+
 tools/cfg3_full.py writes the same inputs on the GPU box, runs bin/kmer_scrub_count ONCE on the whole job and compares.
 Only data is committed (tests/golden/cfg3_full_facts.json).  Runs in the build container only (about 15 minutes on 8 cores,
 26 GB under --work).

@@ -185,6 +185,34 @@ def test_strain_detect_many_strains_host_logic_under_sanitizers(san, union, tmp_
         assert gzip.open(tmp_path / f"o{s}.gz", "rb").read() == want
 
 
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_strain_detect_one_decoder_several_devices_under_sanitizers(san, tmp_path):
+    """SK_DEVICES: ONE process and ONE decode pipeline drive several devices -- the strains are dealt to the devices in groups
+    (one union table per group; SK_SD_GROUP=2 makes groups of two so that five strains are three groups on three logical
+    devices), every decoded chunk goes up to every device, each device tallies it against its own strains.  Every strain's
+    file must be the single-strain golden.  (CPU double for the device calls: the host logic is what runs here -- per-device
+    batches, the prefetch of the next chunk to all devices, results dealt back to the strains.)"""
+    import gzip
+    exe = str(tmp_path / "sd_multi")
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=" + san, "-fno-omit-frame-pointer"] + SD_SOURCES + ["-lz", "-lpthread", "-o", exe], check=True)
+    d = os.path.join(SD_DIR, "batch")
+    with open(tmp_path / "strains.txt", "w") as f:
+        for s in range(5):
+            f.write(f"strain.fa\tinf.txt.gz\t{tmp_path}/o{s}.gz\n")
+    want = open(os.path.join(d, "expected.hits"), "rb").read()
+    for devices, chunk in (("3", "700"), ("0,0", "4000")):
+        env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_SD_TIMING="1", SK_DEVICES=devices, SK_SD_GROUP="2", SK_SD_CHUNK_BYTES=chunk)
+        p = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", "B.txt"], cwd=d, env=env, capture_output=True)
+        for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
+            assert bad not in p.stderr, p.stderr.decode()[-3000:]
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert b"3 union table(s) for 5 strains" in p.stderr
+        assert (b"5 strains on %d devices, one decode pipeline" % (3 if devices == "3" else 2)) in p.stderr
+        for s in range(5):
+            assert gzip.open(tmp_path / f"o{s}.gz", "rb").read() == want
+            os.remove(tmp_path / f"o{s}.gz")
+
+
 @pytest.fixture(scope="module", params=["address,undefined", "thread"])
 def ks_host_exe(request, tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("ks") / ("ks_" + request.param.split(",")[0]))

@@ -256,6 +256,31 @@ def test_sd_many_strains_golden_strain_plus_another(golden, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("union", [True, False])
+def test_sd_one_decoder_several_devices(golden, tmp_path, union):
+    """SK_DEVICES=0,0,0: ONE process, ONE decode pipeline, three logical devices (all of them this box's one card -- on a node
+    they are three GPUs): the strains go to the devices in groups (SK_SD_GROUP=2: five strains = three groups = three union
+    tables, one per device), every decoded chunk is uploaded to every device, each device tallies it against its own strains.
+    Every strain's file equals the reference's output for the single strain (golden `batch`), through the union tables and
+    strain by strain; small chunks so that the next chunk's prefetch to all devices is in play."""
+    d = os.path.join(golden, "sd_cases", "batch")
+    exe = sk.cli_path("strain_detect")
+    with open(tmp_path / "strains.txt", "w") as f:
+        for s in range(5):
+            f.write(f"strain.fa\tinf.txt.gz\t{tmp_path}/m{s}.gz\n")
+    want = open(os.path.join(d, "expected.hits"), "rb").read()
+    env = dict(os.environ, SK_DEVICES="0,0,0", SK_SD_GROUP="2", SK_SD_TIMING="1", SK_SD_CHUNK_BYTES="3000")
+    if not union:
+        env["SK_SD_NO_UNION"] = "1"
+    p = subprocess.run([exe, "-S", str(tmp_path / "strains.txt"), "-B", "B.txt"], cwd=d, env=env, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert b"5 strains on 3 devices, one decode pipeline" in p.stderr
+    assert (b"3 union table(s) for 5 strains" in p.stderr) == union
+    for s in range(5):
+        assert gzip.open(tmp_path / f"m{s}.gz", "rb").read() == want, s
+
+
+@pytest.mark.gpu
 def test_sd_strain_list_is_dealt_to_ranks(golden, tmp_path):
     """-S with RANK/WORLD_SIZE: strain i of the list belongs to rank i % world (no collective); each rank writes
     only its own outfiles, and they equal the single-process ones"""
