@@ -44,6 +44,9 @@ SURVEY_MODEL_BYTES_PER_BASE = 7.4     # 1 B base + 8 B key probe x 
                                       # algorithm; reported as a side field only)
 HIT_BYTES = 8.0                       # u32 counter read-modify-write per hit
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_REQ_CEILING = 270e9            # requests/s the L2 takes for random 8-byte loads from an L2-resident table, measured on this chip
+                                  # (profiles/r01_gather_microbench.txt): one request per channel clock over 8 XCDs x 16 channels
+VALU_CYCLES_PER_WAVE_INSTR = 4    # a wave64 vector instruction occupies its 16-lane SIMD for four cycles (CDNA)
 
 
 # ----------------------------------------------------------------------------- CPU baseline
@@ -636,7 +639,18 @@ def main():
                          "survey_model_bytes_per_base": SURVEY_MODEL_BYTES_PER_BASE,
                          "survey_model_gbs": SURVEY_MODEL_BYTES_PER_BASE * nbases / (avg_ms * 1e-3) / 1e9,
                          "note": "frac = compulsory bytes / kernel time / 8 TB/s.  survey_model_* is SURVEY 8(d)'s 7.4 B/base "
-                                 "(one 8 B probe per window), a model of a different algorithm kept for continuity only"},
+                                 "(one 8 B probe per window), a model of a different algorithm kept for continuity only",
+                         # What holds the kernel below the HBM roofline: the design asks ONE membership question
+                         # per aligned 16-base chunk -- a random 8-byte load from the L2-resident filter -- and reads the stream in
+                         # 64-byte requests; no exact scheme asks fewer (a 31-base window is guaranteed to hold only one aligned
+                         # 16-mer, and the chunks of unrelated reads are independent random keys).  Requests per launch / kernel time
+                         # against the L2's measured request ceiling is the kernel's second stated roofline.
+                         "l2_requests": {"per_launch": nbytes / 16.0 + nbytes / 64.0,
+                                         "what": "one level-1 filter block per 16-byte chunk + one 64-byte request per 64 stream bytes (algorithmic; "
+                                                 "measured TCC_REQ in profiles/)",
+                                         "achieved_per_s": (nbytes / 16.0 + nbytes / 64.0) / (avg_ms * 1e-3), "ceiling_per_s": L2_REQ_CEILING,
+                                         "frac": (nbytes / 16.0 + nbytes / 64.0) / (avg_ms * 1e-3) / L2_REQ_CEILING,
+                                         "ceiling_source": "random 8-byte loads from a <= 4 MiB table, profiles/r01_gather_microbench.txt"}},
             "cpu_baseline": cpu,
             "strain_detect": sd_leg,
         }

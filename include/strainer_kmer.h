@@ -179,6 +179,7 @@ int  sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type_col, uint
 void sk_union_destroy(sk_union *u);
 int  sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hits_cap);
 int  sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t cap, uint64_t *n, sk_hit *out_hits /* hits_cap */, uint64_t *out_nhits);
+int  sk_union_sync(sk_union *u);                               /* wait for a launch whose results will not be collected */
 int  sk_union_scan_timing(sk_union *u, double *total_ms, uint64_t *launches, int reset);   /* sk_scan_timing of the union's scans */
 const char *sk_union_last_error(const sk_union *u);          /* of launch/collect */
 uint32_t sk_union_members(const sk_union *u);

@@ -56,7 +56,14 @@ def write_strain(d, s):
 
 
 def reads_block(b, m, genome):
-    """FASTA bytes of block b (m reads); genome = the 32 strains end to end"""
+    """FASTA bytes of the first m reads of block b; genome = the 32 strains end to end.  A block is always DRAWN whole (BLOCK
+    reads) and then cut: what read i of block b is must not depend on how many reads of the block are wanted (the prefix file
+    ends inside a block)."""
+    return _whole_block(b, genome)[:m]
+
+
+def _whole_block(b, genome):
+    m = BLOCK
     rng = np.random.default_rng(SEED_R + b)
     blk = synth._rand_bases(rng, m * READ_LEN).reshape(m, READ_LEN)
     h = np.flatnonzero(rng.random(m) < 0.02)

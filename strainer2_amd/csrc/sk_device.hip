@@ -2638,6 +2638,17 @@ extern "C" int sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t c
     return SK_OK;
 }
 
+// wait for a launch whose results nobody will collect (the batch it reads is about to be freed)
+extern "C" int sk_union_sync(sk_union *u)
+{
+    if (!u) return SK_E_ARG;
+    sk_ctx *c = u->uc;
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    c->t_inflight_nrec = 0;
+    return SK_OK;
+}
+
 extern "C" int sk_union_scan_timing(sk_union *u, double *total_ms, uint64_t *launches, int reset)
 {
     return u ? sk_scan_timing(u->uc, total_ms, launches, reset) : SK_E_ARG;

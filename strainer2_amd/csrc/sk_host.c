@@ -755,7 +755,9 @@ static int worker_init(scan_worker *w, scan_pool *p)
 
 static void worker_done(scan_worker *w)
 {
+#ifdef SK_EXPERIMENTS
     if (w->inf) sk_inflater_destroy(w->inf);
+#endif
     if (w->text) sk_pinned_free(w->pool->ctx, w->text);
     pthread_mutex_lock(&w->pool->submit_mu);
     if (w->pinned[0]) sk_pinned_free(w->pool->ctx, w->pinned[0]);      /* (synchronises the stream first) */
@@ -956,6 +958,7 @@ static int64_t parse_gz_split(scan_worker *w, const scan_item *it, uint64_t *bas
     return g.rc ? (int64_t)g.rc : g.nrec;
 }
 
+#ifdef SK_EXPERIMENTS        /* (make EXPERIMENTS=1; the library that ships has no device-side inflate: DESIGN.md section 7) */
 /* SK_GPU_INFLATE=1 (experimental): a .gz item of one member and dynamic blocks only is inflated ON THE DEVICE (sk_inflate.hip: the speculative
  * scheme of sk_gzpar.h, a lane per 16 KiB segment; every guess checked, the chain checked here in the library, the CRC-32 here) and its text
  * parsed by this thread.  -100: not such a file, or a check failed -- the caller decodes it on the host as before, so the bytes are zlib's
@@ -1020,16 +1023,20 @@ static int64_t parse_gz_on_device(scan_worker *w, const scan_item *it, uint64_t 
     }
 }
 
+#endif
+
 /* decode one item into the worker's pinned buffers; returns records or a negative SK_E_* */
 static int64_t worker_item(scan_worker *w, const scan_item *it, uint64_t *bases)
 {
     stream_writer sw;
     int64_t nrec = 0;
     int rc;
+#ifdef SK_EXPERIMENTS
     if (!it->ranged) {
         const int64_t r = parse_gz_on_device(w, it, bases);
         if (r != -100) return r;
     }
+#endif
     if (!it->ranged && w->pool->pipe > 1 && !getenv("SK_NO_SPLIT") && !getenv("SK_ZLIB")) {
         const int64_t r = parse_gz_split(w, it, bases);
         if (r != -100) return r;
@@ -1275,7 +1282,9 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
         if (pool.pipe && pool.nitem && nthreads / (int)pool.nitem >= 3) pool.pipe = nthreads / (int)pool.nitem;
         if (gzt && nthreads > 1) pool.pipe = atoi(gzt) < 1 ? 1 : atoi(gzt);
         if (pool.pipe > 16) pool.pipe = 16;
+#ifdef SK_EXPERIMENTS
         pool.gpu_inflate = getenv("SK_GPU_INFLATE") ? atoi(getenv("SK_GPU_INFLATE")) : 0;
+#endif
     }
     if (plan_only) {
         /* nothing is scanned */

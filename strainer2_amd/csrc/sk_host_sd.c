@@ -53,7 +53,7 @@ enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
 static struct { int n; int phys[SD_MAX_DEV]; sk_ctx *ctx[SD_MAX_DEV]; } sd_dev = { 1, {0}, {NULL} };
 static uint32_t sd_group = SK_UNION_MAX;                  /* strains per union table (SK_SD_GROUP: smaller groups, for tests of the dealing) */
 static int sd_dev_of_strain(uint32_t s) { return (int)((s / sd_group) % (uint32_t)sd_dev.n); }
-/* SK_SD_CHUNK_BYTES: smaller chunks (tests: chunk boundaries between mates, carried state across chunks) */
+/* SK_SD_CHUNK_BYTES: smaller chunks (tests: chunk boundaries between mates, carried state across chunks) or bigger ones (up to 1 GiB) */
 /* strain_detect never shows the order of the table's rows (hits are printed read by read with the k-mer's text; the
  * trailer counts rows), so the 0.2 s replay of BIO_hash's slot order (sk_host.c) is left out: rows in strain order.
  * SK_SD_REF_ROW_ORDER=1 replays it all the same (tests compare the two). */
@@ -63,7 +63,7 @@ static size_t sd_chunk_bytes(void)
 {
     const char *e = getenv("SK_SD_CHUNK_BYTES");
     const long v = e ? atol(e) : 0;
-    return v >= 64 && (unsigned long)v < SD_BATCH_BYTES ? (size_t)v : SD_BATCH_BYTES;
+    return v >= 64 && v <= (1l << 30) ? (size_t)v : SD_BATCH_BYTES;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -130,6 +130,8 @@ typedef struct {
      * with several devices (sd_dev) every device has its own pair -- one decoded chunk goes up to all of them */
     sk_batch   *bat[2][SD_MAX_DEV]; int bcur;
     sd_chunk   *pre;                         /* the queued chunk whose bytes are already in bat[bcur ^ 1] */
+    sd_chunk   *ahead;                       /* ... and whose scan has been launched as well (solo streams: see sd_launch_ahead) */
+    int         solo;                        /* the only stream that uses the tables now (SE, PEI): its next chunk may be scanned while this one is replayed */
 } sd_stream;
 
 /* Page-locked chunk buffers, recycled.  The upload of a chunk from ordinary memory goes through the runtime's
@@ -517,10 +519,13 @@ static int stream_open(sd_stream *st, const char *path, int gz_threads)
     return SK_OK;
 }
 
+static void sd_drain_scans(void);
+
 static void stream_close(sd_stream *st)
 {
     int i;
     if (!st->g) return;
+    if (st->ahead) sd_drain_scans();                       /* scans started ahead on a batch that is about to go */
     if (st->started) {
         pthread_mutex_lock(&st->mu);
         st->cancel = 1;
@@ -734,6 +739,15 @@ static void tally_one(void *arg, uint32_t s)
  * batch of 64 MiB or more (one huge record) leave the member-by-member way below, which gives the same results. */
 static struct { sk_union **u; uint32_t n; sk_tally_rec *recs; uint64_t recs_cap; sk_hit *hits; uint64_t *hcap; } sd_un;
 
+/* every scan that may still be in flight (a stream closed early with a chunk launched ahead): wait before its batch is freed */
+static sd_prog *sd_all_p; static uint32_t sd_all_ns;
+static void sd_drain_scans(void)
+{
+    uint32_t g, s;
+    for (g = 0; g < sd_un.n; g++) sk_union_sync(sd_un.u[g]);
+    for (s = 0; !sd_un.n && s < sd_all_ns; s++) if (sd_all_p[s].ctx) sk_sync(sd_all_p[s].ctx);
+}
+
 static void sd_unions_close(void)
 {
     uint32_t g;
@@ -790,14 +804,28 @@ static void sd_prefetch(sd_stream *st)
     t_fill += now_s() - t0;
 }
 
-/* one batch against the unions; the results are dealt to the strains' tallybuf/hitbuf (u_nsp, u_nh entries) */
-static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chunk *c, sd_stream *st)
+/* start the scans of one uploaded chunk: against every union table, or strain by strain (they overlap on the devices) */
+static int sd_launch(sd_prog *p, uint32_t ns, sk_batch **batches)
 {
     uint32_t g, s;
     int rc;
-    for (g = 0; g < sd_un.n; g++)
-        if ((rc = sk_union_tally_launch(sd_un.u[g], batches[sd_dev_of_strain(g * sd_group)], sd_un.hcap[g])) != SK_OK) return rc;
-    sd_prefetch(st);
+    if (sd_un.n) {
+        for (g = 0; g < sd_un.n; g++)
+            if ((rc = sk_union_tally_launch(sd_un.u[g], batches[sd_dev_of_strain(g * sd_group)], sd_un.hcap[g])) != SK_OK) return rc;
+        return SK_OK;
+    }
+    for (s = 0; s < ns; s++) {
+        if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
+        if ((rc = sk_tally_launch(p[s].ctx, batches[sd_dev_of_strain(s)], SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
+    }
+    return SK_OK;
+}
+
+/* the unions' results of the chunk whose scans are in flight, dealt to the strains' tallybuf/hitbuf (u_nsp, u_nh entries) */
+static int sd_collect_unions(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chunk *c)
+{
+    uint32_t g, s;
+    int rc;
     for (s = 0; s < ns; s++) p[s].u_nsp = p[s].u_nh = 0;
     for (g = 0; g < sd_un.n; g++) {
         const uint32_t a = g * sd_group, n = sk_union_members(sd_un.u[g]);
@@ -844,7 +872,9 @@ static int sd_tally_unions(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chunk
     return SK_OK;
 }
 
-static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch **batches, sd_pool *pool, sd_chunk *c, int uploaded, sd_stream *st)
+/* One chunk against every strain.  uploaded: its bytes are in `batches` already (prefetched while the chunk before it was scanned);
+ * launched: its scans are in flight as well (started while the chunk before it was being replayed: sd_launch_ahead). */
+static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch **batches, sd_pool *pool, sd_chunk *c, int uploaded, int launched, sd_stream *st)
 {
     sd_tally_job job;
     uint32_t s;
@@ -858,15 +888,9 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch **batches, sd_pool *
         for (d = 0; d < sd_dev.n && !uploaded; d++)              /* (asynchronous copies from page-locked memory: the devices' uploads overlap) */
             if ((rc = sk_batch_fill(batches[d], c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
         t1 = now_s(); t_fill += t1 - t0; t0 = t1;
-        if (use_union) {
-            if ((rc = sd_tally_unions(p, ns, batches, c, st)) != SK_OK) return rc;
-        } else {
-            for (s = 0; s < ns; s++) {
-                if (p[s].hitcap == 0) { p[s].hitcap = 1u << 16; p[s].hitbuf = (sk_hit *)malloc((size_t)p[s].hitcap * sizeof(sk_hit)); }
-                if ((rc = sk_tally_launch(p[s].ctx, batches[sd_dev_of_strain(s)], SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK) return rc;
-            }
-            sd_prefetch(st);
-        }
+        if (!launched && (rc = sd_launch(p, ns, batches)) != SK_OK) return rc;
+        sd_prefetch(st);                                         /* the next chunk goes up while this one is scanned */
+        if (use_union && (rc = sd_collect_unions(p, ns, batches, c)) != SK_OK) return rc;
         t1 = now_s(); t_launch += t1 - t0; t0 = t1;
     }
     job.p = p; job.batches = batches; job.c = c; job.from_union = use_union;
@@ -874,6 +898,20 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch **batches, sd_pool *
     t_post += now_s() - t0;
     for (s = 0; s < ns; s++) if (p[s].job_rc != SK_OK) return p[s].job_rc;
     return SK_OK;
+}
+
+/* The chunk that follows is uploaded already (st->pre) and this stream is the only user of the tables: start its scans NOW, so
+ * that the devices work on it while the host replays the reference's read-after-read bookkeeping over the chunk just collected
+ * (and compresses the strains' output) -- the two used to take turns.  Every result buffer of the current chunk has been copied
+ * out by now (collect + spread), so the launches may overwrite the device side. */
+static void sd_launch_ahead(sd_stream *st, sd_prog *p, uint32_t ns)
+{
+    const double t0 = now_s();
+    if (!st->solo || !st->pre || st->ahead || getenv("SK_SD_NO_AHEAD")) return;
+    if (sd_launch(p, ns, st->bat[st->bcur ^ 1]) == SK_OK) st->ahead = st->pre;
+    /* (a failed launch is not an error here: the chunk is launched again, and the error reported, when its turn comes --
+     * but scans that did start must be collected first: see stream_fill) */
+    t_launch += now_s() - t0;
 }
 
 /* make sure the stream's current chunk has an unread record: 1 = st->c->...[st->ci] is it, 0 = end of
@@ -907,12 +945,15 @@ static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, 
         {
             const double t0 = now_s();
             const int uploaded = st->pre == c;             /* its bytes went up while the chunk before it was scanned */
+            const int launched = uploaded && st->ahead == c;   /* ... and its scans were started while that chunk was replayed */
             (void)batch;
             if (uploaded) st->bcur ^= 1;
             st->pre = NULL;
+            st->ahead = NULL;
             for (i = 0; i < sd_dev.n; i++)
                 if (!st->bat[st->bcur][i] && (rc = sk_batch_create(sd_dev.ctx[i], &st->bat[st->bcur][i])) != SK_OK) { st->bat[st->bcur][i] = NULL; chunk_free(c); return rc; }
-            rc = sd_tally_chunk(p, ns, st->bat[st->bcur], pool, c, uploaded, st);
+            rc = sd_tally_chunk(p, ns, st->bat[st->bcur], pool, c, uploaded, launched, st);
+            if (rc == SK_OK) sd_launch_ahead(st, p, ns);
             t_tally += now_s() - t0;
         }
         if (rc != SK_OK) { chunk_free(c); return rc; }
@@ -1084,6 +1125,7 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
         if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f2); stream_close(&A); return 1; }
     }
     for (s = 0; s < ns; s++) { p[s].h1 = p[s].i1 = p[s].h2 = p[s].i2 = 0; p[s].copy_n = 0; }
+    A.solo = mode != SD_PE;                              /* (two streams take turns at the tables: no scan ahead of the replay) */
 
     while ((got = stream_fill(&A, p, ns, batch, pool)) == 1) {
         sd_chunk *ca = A.c, *cb = NULL, *held = NULL;
@@ -1458,6 +1500,7 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
     sd_pool pool;
     int bad = 0;
     sd_pin_open(p[0].ctx, sd_chunk_bytes());
+    sd_all_p = p; sd_all_ns = ns;
     sd_unions_open(p, ns);
     pool_start(&pool, ns);
     if (B) {

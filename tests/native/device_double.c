@@ -148,6 +148,7 @@ int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type_col, uint3
     return SK_OK;
 }
 void sk_union_destroy(sk_union *u) { free(u); }
+int sk_union_sync(sk_union *u) { (void)u; return SK_OK; }
 uint32_t sk_union_members(const sk_union *u) { return u->n; }
 uint32_t sk_union_rows(const sk_union *u) { uint32_t i, r = 0; for (i = 0; i < u->n; i++) r += u->m[i]->n; return r; }
 const char *sk_union_last_error(const sk_union *u) { (void)u; return "stub"; }

@@ -45,8 +45,9 @@ def main():
     with open(out_path, "wb") as out:
         p = subprocess.run([exe] + argv, cwd=WORK, stdout=out, stderr=subprocess.PIPE, env=dict(os.environ, SK_TIMING="1"))
     wall = time.time() - t1
-    timing = [ln for ln in p.stderr.decode().split("\n") if ln.startswith("kmer_scrub_count timing")]
-    stderr = "".join(ln + "\n" for ln in p.stderr.decode().split("\n") if ln and not ln.startswith("kmer_scrub_count timing"))
+    is_timing = lambda ln: ln.startswith("kmer_scrub_count timing") or ln.startswith("key set of ")      # (SK_TIMING=1 lines) # noqa: E731
+    timing = [ln for ln in p.stderr.decode().split("\n") if is_timing(ln)]
+    stderr = "".join(ln + "\n" for ln in p.stderr.decode().split("\n") if ln and not is_timing(ln))
     h = hashlib.md5()
     nbytes = 0
     with open(out_path, "rb") as f:
