@@ -93,6 +93,19 @@ def main():
         full["output_lines"] = lines
         ok = ok and parts_ok and prefix_ok and p.returncode == 0
         report["full_pass"] = full
+        # A/B of the same pass (VARIANTS=1): without the scan-ahead of the next chunk, with bigger chunks, on several logical devices
+        if os.environ.get("VARIANTS"):
+            def two_md5():                                   # (decompressed: the gz members differ with the block boundaries)
+                return [hashlib.md5(gzip.open(os.path.join(WORK, f"multi{s}.gz"), "rb").read()).hexdigest() for s in cfg5.PINNED_STRAINS]
+            sizes = two_md5()
+            report["variants"] = {}
+            for name, env in (("no_scan_ahead", {"SK_SD_NO_AHEAD": "1"}), ("chunks_of_128_mib", {"SK_SD_CHUNK_BYTES": str(128 << 20)}),
+                              ("two_logical_devices_one_card", {"SK_DEVICES": "0,0", "SK_SD_GROUP": "16"})):
+                p2, wall2 = run(exe, ["-S", paths["strains"], "-B", paths["B"]], **env)
+                timing2, _ = split_timing(p2.stderr)
+                same = p2.returncode == 0 and sizes == two_md5()
+                report["variants"][name] = {"env": env, "wall_s": round(wall2, 2), "same_output_for_the_two_pinned_strains": same, "timing": timing2}
+                ok = ok and same
     report["ok"] = ok
     print(json.dumps(report, indent=1))
     if not os.environ.get("KEEP"):
