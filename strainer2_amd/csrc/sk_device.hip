@@ -349,6 +349,63 @@ __device__ __forceinline__ uint32_t sk_chunk_has_odd_byte(const sk_u4 v, uint32_
     return odd;
 }
 
+// ---- phase 1, the cheap form (SK_LAZY_MASKS = 1; an EXPERIMENT of round 3, off: it removes a third of the kernel's vector
+// instructions and changes the launch time by less than 1 % without strain reads, and costs 10-17 % with many of them -- the
+// kernel is not bound by vector issue): codes for every byte, but of the validity only what EVERY chunk needs ----
+// Phase 2 asks of a chunk only "is every byte A/C/G/T?", and the byte-string kernel's work list only "is there a byte that is
+// neither A/C/G/T nor N/n nor the separator?".  Both are ONE comparison per chunk on the OR of four words that are zero where a
+// byte is as wanted: d = expected letter (by the byte's low three bits) ^ the byte with its case folded, and x = the same with
+// 'N' and the separator expected as well.  The exact 16-bit "not ACGT" mask -- 5 operations per word to squeeze out of d, and
+// before round 3 a loop over its set bits to tell N and the separator from the rest -- is wanted only by stage 2, and only
+// for the two neighbours of a SURVIVING chunk (the strain's reads: 2 % of the chunks at cfg 2): those few are worked out there,
+// from the stream's bytes (sk_exact_inv16), when the record says "not clean" (mask field 0xFFFF).
+// Case folding touches letters only (bit 6 set): '*' (0x2A) must not turn into the separator (0x0A).
+__device__ __forceinline__ void sk_decode4_lazy(uint32_t w, uint32_t &codes8, uint32_t &d, uint32_t &x)
+{
+    const uint32_t sel = w & 0x07070707u;
+    const uint32_t cd  = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, sel);   // A0 C1 G2 T3
+    codes8 = (cd * 0x40100401u) >> 24;
+    const uint32_t u   = w & ~((w >> 1) & 0x20202020u);                           // lower-case letters -> upper case
+    d = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, sel) ^ u;                 // 0 <=> A/C/G/T (0xFF: no folded byte is that)
+    x = __builtin_amdgcn_perm(0x474EFF54u, 0x430A41FFu, sel) ^ u;                 // 0 <=> A/C/G/T, N/n or '\n'
+}
+// the exact "not ACGT" mask of a chunk's 16 bytes (bit i <=> byte i), the same bits sk_decode4 gives
+__device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
+{
+    uint32_t c, i0, i1, i2, i3;
+    sk_decode4(v.x, c, i0);
+    sk_decode4(v.y, c, i1);
+    sk_decode4(v.z, c, i2);
+    sk_decode4(v.w, c, i3);
+    return i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+}
+#ifndef SK_LAZY_MASKS
+#define SK_LAZY_MASKS 0                      // measured (profiles/r03_kernel_experiments.txt): a third fewer vector instructions and NO gain
+#endif
+#ifndef SK_L2_BATCH
+#define SK_L2_BATCH 2                      // phase 2: 0 = one level-2 question per loop iteration, 1 = a thread's questions together, 2 = and two more level-1 questions first
+#endif
+#ifndef SK_L2_K
+#define SK_L2_K 2                          // ... chunks per round (4: -3 %, 2: -4.7 % with no strain reads)
+#endif
+// ... of the chunk at stream offset off; a chunk that sticks out of the batch (its first and last tiles only) is put together
+// byte by byte, '\n' where there is nothing -- out of line, so that the rare case costs the scan kernel no registers
+__device__ __noinline__ uint32_t sk_exact_inv16_edge(const uint8_t *__restrict__ stream, uint64_t nbytes, int64_t off)
+{
+    uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+#pragma nounroll
+    for (int i = 0; i < 16; i++) {
+        const int64_t p = off + i;
+        if (p >= 0 && (uint64_t)p < nbytes) w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
+    }
+    return sk_exact_inv16((sk_u4){w[0], w[1], w[2], w[3]});
+}
+__device__ __forceinline__ uint32_t sk_exact_inv16_at(const uint8_t *__restrict__ stream, uint64_t nbytes, int64_t off)
+{
+    if (off >= 0 && (uint64_t)off + 16u <= nbytes) return sk_exact_inv16(*(const sk_u4 *)(stream + off));
+    return sk_exact_inv16_edge(stream, nbytes, off);
+}
+
 __device__ __forceinline__ uint32_t sk_revcomp32(uint32_t x)              // 16 packed bases
 {
     uint32_t y = __builtin_bitreverse32(x);
@@ -482,6 +539,8 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+    // the cheap phase 1 (sk_decode4_lazy): in COUNT mode; the TALLY kernels, short of scalar registers, keep the exact masks
+    constexpr bool LAZY = SK_LAZY_MASKS && !CAND && !TALLY;
     __shared__ uint32_t hl_n[2];                                  // TALLY: the hit log's LDS share (agg is free in that mode)
     if (!TALLY)
         for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) agg[i] = make_uint2(0xFFFFFFFFu, 0u);   // (visible after phase 1's barrier)
@@ -527,14 +586,27 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             const uint32_t c = tid + (uint32_t)it * SK_THREADS;
             if (c < SK_NCHUNK_GRID) {
                 const sk_u4 v = vv[it];
-                uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
-                sk_decode4(v.x, c0, i0);
-                sk_decode4(v.y, c1, i1);
-                sk_decode4(v.z, c2, i2);
-                sk_decode4(v.w, c3, i3);
-                const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+                uint32_t c0, c1, c2, c3, inv16;
+                bool odd;
+                if (LAZY) {
+                    uint32_t d0, d1, d2, d3, x0, x1, x2, x3;
+                    sk_decode4_lazy(v.x, c0, d0, x0);
+                    sk_decode4_lazy(v.y, c1, d1, x1);
+                    sk_decode4_lazy(v.z, c2, d2, x2);
+                    sk_decode4_lazy(v.w, c3, d3, x3);
+                    inv16 = (d0 | d1 | d2 | d3) ? 0xFFFFu : 0u;                  // 0xFFFF: "not clean; the exact mask on demand" (sk_exact_inv16)
+                    odd = (x0 | x1 | x2 | x3) != 0u;
+                } else {
+                    uint32_t i0, i1, i2, i3;
+                    sk_decode4(v.x, c0, i0);
+                    sk_decode4(v.y, c1, i1);
+                    sk_decode4(v.z, c2, i2);
+                    sk_decode4(v.w, c3, i3);
+                    inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+                    odd = sk_chunk_has_odd_byte(v, inv16) != 0u;
+                }
                 // bytes of the chunk after the tile belong to the next tile, which reports them itself
-                if (c < SK_NCHUNK && sk_chunk_has_odd_byte(v, inv16)) {
+                if (c < SK_NCHUNK && odd) {
                     bad = 1;
                     if (c >= SK_SPAN_CH) {                                   // (the chunks before the tile are the previous tile's)
                         const uint32_t at = atomicAdd(&flags[2], 1u);
@@ -624,13 +696,14 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         b1[i] = make_uint2(0u, 0u);
         if (ABLATE == 4) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks) & 131071u]; }  // timing: all lookups in 1 MiB (L2 hits)
         else if (ABLATE == 6) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks) & 2047u]; } // timing: all lookups in 16 KiB (L1 hits)
+        else if (ABLATE == 10) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)]; }         // timing: the real level-1 lookups, verdicts dropped (no level 2, no stage 2)
         else if (ABLATE != 1 && ((okm >> i) & 1u)) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)];
     }
     uint32_t m = 0;                                               // chunks that may be in the strain
 #pragma unroll
     for (int i = 0; i < SK_SPAN_CH; i++)
         m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) &&
-                        ((ABLATE != 4 && ABLATE != 6) || g[i] == 0x9E3779B9u)) << i;     // (ablations: loads kept alive, verdicts dropped)
+                        ((ABLATE != 4 && ABLATE != 6 && ABLATE != 10) || g[i] == 0x9E3779B9u)) << i;     // (ablations: loads kept alive, verdicts dropped)
     if (m && SK_SHIFTED_TEST && !CAND) {                          // (CAND: the LDS slice and the L2 block have both said maybe -- 0.3 % false positives left)
         // Second question to the same L2-resident filter: every window of a chunk also holds the 16-mer that starts
         // 8 bases before the chunk (the windows that begin 8..15 bases before it) or the one that starts 8 bases into
@@ -666,6 +739,96 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         // exact: stage 2 verifies every window.
         // (a loop over the set bits, not over the eight chunks: a thread rarely has more than one survivor of level 1,
         // and the unrolled form cost every wave all eight bodies)
+#if SK_L2_BATCH == 2
+        // Round 3.  What the false positives of level 1 cost is not the latency of their level-2 questions (asking them together
+        // changed nothing, SK_L2_BATCH 1) but their NUMBER: 7 % of all chunks, each a random 64-byte line from a 32 MiB array that
+        // never stays in the L2 -- 2.4 M line fetches per 0.6 Gbase competing with the stream for the fabric: 0.082 ms of a
+        // 0.293 ms launch (ablation: the same kernel with level 1's verdicts dropped takes 0.211 ms).  Level 1 itself has room --
+        // its lookups are L2 hits and the L2 serves 60 % of the requests it could --, so a false positive is first asked two
+        // more L2 questions: every window of a chunk also holds the 16-mer that starts 8 bases before the chunk (the windows that
+        // begin 8..15 bases before it) or the one that starts 8 bases into it (the others); a chunk both of whose half-shifted
+        // 16-mers are strangers to the strain (or hold a non-ACGT byte) has no window left.  7 % -> ~1 % go on to level 2.
+        // (Round 2 tried the same question as eight unrolled bodies with their lookups one after the other: no gain.  Here: a
+        // round takes the first chunk of every run of survivors, at most SK_L2_K of them, all their lookups in flight together;
+        // the rest of a run follows its first chunk's verdict, as in the plain loop.)
+        uint32_t m2 = 0, pend = m;
+        while (pend) {
+            uint32_t ap = pend & (m2 << 1);                       // right behind a chunk that passed: passes, and so on down the run
+            while (ap) { m2 |= ap; pend &= ~ap; ap = pend & (ap << 1); }
+            if (!pend) break;
+            uint32_t starts = pend & ~(pend << 1), st = starts, taken = 0u;
+            uint32_t ix[SK_L2_K], gl[SK_L2_K], gr[SK_L2_K], g2[SK_L2_K], oks[SK_L2_K];
+            uint2 bl[SK_L2_K], br[SK_L2_K], b2[SK_L2_K];
+#pragma unroll
+            for (int k = 0; k < SK_L2_K; k++) {
+                ix[k] = 8u; gl[k] = gr[k] = g2[k] = oks[k] = 0u;
+                bl[k] = br[k] = make_uint2(0u, 0u);
+                if (st) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(st);
+                    st &= st - 1u;
+                    taken |= 1u << i;
+                    const uint32_t cid = tid * SK_SPAN_CH + SK_SPAN_CH + i;                 // record 0 = the 8 chunks before the tile
+                    const uint32_t cw  = rec[(cid >> 3) * SK_REC_DW + (cid & 7u)];
+                    const uint32_t cwp = rec[((cid - 1u) >> 3) * SK_REC_DW + ((cid - 1u) & 7u)];
+                    const uint32_t cwn = rec[((cid + 1u) >> 3) * SK_REC_DW + ((cid + 1u) & 7u)];
+                    const bool lv_ok = (sk_chunk_inv(rec, cid - 1u) >> 8) == 0u, rv_ok = (sk_chunk_inv(rec, cid + 1u) & 0xFFu) == 0u;
+                    const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
+                    const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr), rc = sk_revcomp32(cw);
+                    ix[k] = i;
+                    gl[k] = sk_gmix(wl < rl ? wl : rl); gr[k] = sk_gmix(wr < rr ? wr : rr); g2[k] = sk_gmix(cw < rc ? cw : rc);
+                    oks[k] = (lv_ok ? 1u : 0u) | (rv_ok ? 2u : 0u);
+                    if (lv_ok) bl[k] = table.grid1[sk_grid1_block(gl[k], table.grid1_blocks)];
+                    if (rv_ok) br[k] = table.grid1[sk_grid1_block(gr[k], table.grid1_blocks)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SK_L2_K; k++) {
+                const bool keep = ix[k] < 8u && (((oks[k] & 1u) && sk_grid_test(bl[k], sk_grid1_bits(gl[k]))) ||
+                                                 ((oks[k] & 2u) && sk_grid_test(br[k], sk_grid1_bits(gr[k]))));
+                b2[k] = make_uint2(0u, 0u);
+                if (keep) b2[k] = table.grid2[sk_grid2_block(g2[k], table.grid2_shift)];
+                else ix[k] = 8u;
+            }
+#pragma unroll
+            for (int k = 0; k < SK_L2_K; k++)
+                if (ix[k] < 8u) m2 |= (uint32_t)sk_grid_test(b2[k], sk_grid2_bits(g2[k])) << ix[k];
+            pend &= ~taken;
+        }
+#elif SK_L2_BATCH
+        // Round 3: the level-2 questions of a thread go out TOGETHER.  The loop used to ask one chunk per iteration, each answer an
+        // L2 miss (the 32 MiB level never stays in the L2): a wave ran as many dependent misses in a row as its busiest lane had
+        // survivors of level 1 (three, typically) -- 4-6 us of a workgroup's ~30 us life spent waiting, with every wave slot of the
+        // CU taken.  Now a round asks about the FIRST chunk of every run of survivors that is left (at most four runs in eight
+        // chunks; their loads are independent), the rest of a run follows its first chunk's verdict as before (pass: the run passes
+        // on its level-1 verdicts; fail: the next round asks about the run's next chunk).  One round settles all but the rare run
+        // of two false positives.  Same pruning as the loop it replaces, bit for bit.
+        uint32_t m2 = 0, pend = m;
+        while (pend) {
+            uint32_t ap = pend & (m2 << 1);                       // right behind a chunk that passed: passes, and so on down the run
+            while (ap) { m2 |= ap; pend &= ~ap; ap = pend & (ap << 1); }
+            if (!pend) break;
+            const uint32_t starts = pend & ~(pend << 1);          // the first chunk of every run that is left
+            uint32_t st = starts, gi[4], ix[4];
+            uint2 b2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ix[k] = 8u; gi[k] = 0u; b2[k] = make_uint2(0u, 0u);
+                if (st) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(st);
+                    st &= st - 1u;
+                    const uint32_t cw = my[i];
+                    const uint32_t rc = sk_revcomp32(cw);
+                    ix[k] = i;
+                    gi[k] = sk_gmix(cw < rc ? cw : rc);
+                    b2[k] = table.grid2[sk_grid2_block(gi[k], table.grid2_shift)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (ix[k] < 8u) m2 |= (uint32_t)sk_grid_test(b2[k], sk_grid2_bits(gi[k])) << ix[k];
+            pend &= ~starts;
+        }
+#else
         uint32_t m2 = 0, left = m;
         while (left) {
             const uint32_t i = (uint32_t)__builtin_ctz(left);
@@ -677,6 +840,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             const uint2 b2 = table.grid2[sk_grid2_block(gi, table.grid2_shift)];   // (nontemporal loads here: 7 % slower)
             m2 |= (uint32_t)sk_grid_test(b2, sk_grid2_bits(gi)) << i;
         }
+#endif
         m = m2;
     }
 
@@ -777,6 +941,12 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         if (act) {
             inv_prev = sk_chunk_inv(rec, ch + SK_SPAN_CH - 1u);
             inv_next = sk_chunk_inv(rec, ch + SK_SPAN_CH + 1u);
+            // a neighbour that is not clean: its exact mask, from the stream's bytes (phase 1 only noted THAT it is not clean;
+            // chunk index c of the records = bytes tile0 - SK_SPAN + 16 c ..., '\n' beyond the batch's ends as in phase 1)
+            if (LAZY) {
+                if (inv_prev == 0xFFFFu) inv_prev = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(ch + SK_SPAN_CH - 1u));
+                if (inv_next == 0xFFFFu) inv_next = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(ch + SK_SPAN_CH + 1u));
+            }
             const uint64_t v = ~((uint64_t)inv_prev | ((uint64_t)inv_next << 32)) & 0x0000FFFFFFFFFFFFull;
             uint64_t rr = v & (v << 1);
             rr &= rr << 2;
@@ -2065,6 +2235,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     else if (c->ablate == 4) SK_LAUNCH_GRID(false, 4, false);
     else if (c->ablate == 5) SK_LAUNCH_GRID(false, 5, false);
     else if (c->ablate == 6) SK_LAUNCH_GRID(false, 6, false);
+    else if (c->ablate == 10) SK_LAUNCH_GRID(false, 10, false);
 #endif
     else                     SK_LAUNCH_GRID(false, 0, false);
 #undef SK_LAUNCH_GRID

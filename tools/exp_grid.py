@@ -26,6 +26,8 @@ VARIANTS = {
     "l2hit_h2":     (0.02, {"ablate": 4}, False),
     "l1hit_h2":     (0.02, {"ablate": 6}, False),
     "nofilt_h2":    (0.02, {"ablate": 1}, False),
+    "l1only_h0":    (0.0,  {"ablate": 10}, False),
+    "l1only_h2":    (0.02, {"ablate": 10}, False),
     "g2048_h0":     (0.0,  {"grid_kib": 2048}, False),
     "g2048_h2":     (0.02, {"grid_kib": 2048}, False),
     "g1536_h2":     (0.02, {"grid_kib": 1536}, False),

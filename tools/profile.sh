@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu --no-host-rate --file-reads 0 $@"   # (only the resident launches: per-launch averages must be of one size)
+ARGS="--steps 5 --warmup 1 --no-cpu --no-sd --no-host-rate --file-reads 0 $@"   # (only the resident launches: per-launch averages must be of one size)
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 grep '^{' $OUT/trace.log > $OUT/bench_line.json
 i=0
