@@ -3,7 +3,8 @@
 ahead, several parser threads) against the oracle program run strain by strain.  Per seed: 2-6 RELATED strains (diverged and
 exact copies of ancestors, the other strand), informative lists that overlap only in part, a -B list with SE / PE / PEI files
 (plain and .gz, FASTA and FASTQ), a third of the reads cut below k (they re-emit the tallies of the read before), N's, tiny
-chunks (SK_SD_CHUNK_BYTES) so that mates, short-read runs and hits straddle chunk borders, several parser threads.
+chunks (SK_SD_CHUNK_BYTES) so that mates, short-read runs and hits straddle chunk borders, several parser threads; every third seed with the
+strains dealt to several logical devices (SK_DEVICES), every fifth without the scan-ahead of the next chunk.
 SEEDS=a..b (default 0..19).  Test tool: prints one line per seed and exits non-zero on the first difference."""
 import gzip
 import os
@@ -102,6 +103,11 @@ def one_seed(seed, d):
                SK_GZ_THREADS=str(r.choice([1, 3])), SK_GZ_SEG="4000")
     if r.random() < 0.25:
         env["SK_SD_NO_UNION"] = "1"
+    if seed % 3 == 1:                                   # one process, several (logical) devices on the one card: groups of 1-2 strains dealt to them
+        env["SK_DEVICES"] = r.choice(["0,0", "0,0,0"])
+        env["SK_SD_GROUP"] = str(r.choice([1, 2]))
+    if seed % 5 == 2:
+        env["SK_SD_NO_AHEAD"] = "1"
     p = subprocess.run([EXE, "-S", f"{d}/strains.txt", "-B", f"{d}/B.txt"], capture_output=True, env=env)
 
     def ora(s):
