@@ -1137,8 +1137,17 @@ static uint64_t plan_digest(const scan_item *items, const uint32_t *owner, uint3
 
 typedef struct { uint64_t *hash; uint32_t *owner; uint32_t cap, *nlines; } plan_report;
 
-static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
-                          FILE *err, uint32_t rank, uint32_t world, uint64_t *bases, int plan_only, const plan_report *report)
+/* What a cut that does not hold costs (single process): nothing but time.  Before a list with pieces is scanned the column is
+ * copied; if a piece fails its check (SK_E_SPLIT: a record that ends the FILE for the reference in the middle of it, a layout
+ * the guess misjudges) the column and the progress file are put back and the list is scanned again UNCUT -- the reference's
+ * strict record sequence per file, which reports what the reference reports (src/kseq.h:205-209, src/genome_compare.c:203).
+ * The cut is an optimisation that is checked, not a new way to fail.  With several ranks the run still fails (other ranks
+ * have counted their pieces already): SK_NO_SPLIT=1 is the way round there. */
+typedef struct { uint32_t *snap; long prog_at; int armed; } split_guard;
+
+static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
+                          FILE *err, uint32_t rank, uint32_t world, uint64_t *bases, int plan_only, const plan_report *report,
+                          int no_split, split_guard *guard)
 {
     FILE *fp = fopen(list_path, "r");
     char *line = NULL, *nl;
@@ -1214,7 +1223,7 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
             size_t total_items = 0;
             for (i = 0; i < n0; i++) {
                 uint64_t np = 1;
-                if (lanes > 1 && !gz[i] && !getenv("SK_NO_SPLIT") && all[i].size >= 2 * target) np = (all[i].size + target - 1) / target;
+                if (lanes > 1 && !gz[i] && !no_split && !getenv("SK_NO_SPLIT") && all[i].size >= 2 * target) np = (all[i].size + target - 1) / target;
                 total_items += np > 256 ? 256 : (size_t)np;
             }
             cut = (scan_item *)malloc((total_items + 1) * sizeof *cut);
@@ -1222,7 +1231,7 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
         }
         for (i = 0; i < n0; i++) {
             uint32_t np = 1, k;
-            if (lanes > 1 && !gz[i] && !getenv("SK_NO_SPLIT") && all[i].size >= 2 * target) {
+            if (lanes > 1 && !gz[i] && !no_split && !getenv("SK_NO_SPLIT") && all[i].size >= 2 * target) {
                 np = (uint32_t)((all[i].size + target - 1) / target > 256 ? 256 : (all[i].size + target - 1) / target);
             }
             for (k = 0; k < np; k++) {
@@ -1273,6 +1282,17 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
     }
     free(all); free(est); free(owner);
 
+    if (guard && !plan_only && world <= 1 && !no_split) {      /* pieces ahead: keep what a failed cut would spoil */
+        int ranged = 0;
+        for (i = 0; i < pool.nitem; i++) ranged |= pool.item[i].ranged;
+        if (ranged && sk_table_rows(ctx)) {
+            guard->snap = (uint32_t *)malloc((size_t)sk_table_rows(ctx) * sizeof(uint32_t));
+            if (guard->snap && sk_counts_fetch(ctx, col, guard->snap) == SK_OK) {
+                guard->prog_at = progress ? (fflush(progress), ftell(progress)) : -1;
+                guard->armed = 1;
+            }
+        }
+    }
     {   /* with fewer files than half the cores, a file's inflate and its record parsing take a core each; with
          * fewer still, the threads left over inflate inside the files (a speculative segment costs about twice a
          * serial one, so it takes three threads per file to be worth it).  SK_GZ_THREADS sets the number per file. */
@@ -1322,7 +1342,7 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
                 ftruncate(fileno(pool.progress), (off_t)pool.ll[upto - 1].end) == 0)
                 fseek(pool.progress, pool.ll[upto - 1].end, SEEK_SET);
         }
-        if (err && rank == 0)
+        if (err && rank == 0 && !(pool.rc == SK_E_SPLIT && guard && guard->armed))
             for (i = 0; i < upto; i++)
                 if (pool.ll[i].skipped) fprintf(err, "skipping %s (identical match)\n", pool.ll[i].text);
     }
@@ -1330,6 +1350,8 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
         /* (said above, or nothing to say) */
     } else if (pool.rc == SK_E_OPEN) {
         if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", pool.item[pool.rc_index].path);
+    } else if (pool.rc == SK_E_SPLIT && guard && guard->armed) {
+        /* (said nothing: the caller scans the list again, uncut) */
     } else if (pool.rc == SK_E_SPLIT) {
         if (err) fprintf(err, "kmer_scrub_count: %s could not be cut at record boundaries (bytes %llu-%llu): nothing is reported; "
                               "run again with SK_NO_SPLIT=1\n", pool.item[pool.rc_index].path,
@@ -1344,8 +1366,26 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
     free(pool.ll);
     pthread_mutex_destroy(&pool.submit_mu);
     pthread_mutex_destroy(&pool.queue_mu);
-    if (bases) *bases += pool.bases;
+    if (bases && !(pool.rc == SK_E_SPLIT && guard && guard->armed)) *bases += pool.bases;
     return pool.rc;
+}
+
+static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
+                          FILE *err, uint32_t rank, uint32_t world, uint64_t *bases, int plan_only, const plan_report *report)
+{
+    split_guard guard = {NULL, -1, 0};
+    int rc = scan_list_once(ctx, list_path, skip, col, progress, err, rank, world, bases, plan_only, report, 0, &guard);
+    if (rc == SK_E_SPLIT && guard.armed) {
+        rc = sk_counts_set(ctx, col, guard.snap);
+        if (rc == SK_OK && progress && guard.prog_at >= 0 && fflush(progress) == 0 && ftruncate(fileno(progress), (off_t)guard.prog_at) == 0)
+            fseek(progress, guard.prog_at, SEEK_SET);
+        if (rc == SK_OK) {
+            if (getenv("SK_TIMING") && err) fprintf(err, "kmer_scrub_count timing: a cut of %s did not hold; the list is scanned again uncut\n", list_path);
+            rc = scan_list_once(ctx, list_path, skip, col, progress, err, rank, world, bases, plan_only, report, 1, NULL);
+        }
+    }
+    free(guard.snap);
+    return rc;
 }
 
 int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,

@@ -166,3 +166,35 @@ def test_a_record_that_ends_the_file_for_the_reference_is_not_read_past(exe, tmp
     q = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list_head.txt"), "2"], env=env, capture_output=True, timeout=300)
     assert p.returncode == 0 and q.returncode == 0
     assert p.stdout.split()[:2] == q.stdout.split()[:2] and p.stdout.startswith(b"OK")
+
+
+def test_one_process_scans_again_uncut_when_a_cut_does_not_hold(exe, tmp_path):
+    """with ONE process a cut that fails its check must not fail the run -- the reference accepts these files.  The
+    column and the progress file are put back and the list is scanned again uncut (sk_host.c: split_guard): the adversarial
+    wrapped FASTQ and the file with a record that ends it for the reference both give, with three decode threads and tiny
+    pieces, exactly what SK_NO_SPLIT=1 gives, and nothing on stderr."""
+    rng = random.Random(17)
+    strain = _synth.rand_dna(rng, 20000)
+    open(tmp_path / "strain.fa", "wb").write(b">s\n" + strain + b"\n")
+    recs = []
+    for i in range(400):
+        a = rng.randrange(0, len(strain) - 150)
+        s = strain[a:a + 150]
+        q = b"@" + b"I" * 49 + b"\n" + b"I" * 50 + b"\n" + b"+" + b"I" * 49
+        recs.append(b"@r%d\n%s\n%s\n%s\n+\n%s\n" % (i, s[:50], s[50:100], s[100:], q))
+    open(tmp_path / "wrapped.fq", "wb").write(b"".join(recs))
+    head = _fastq(rng, strain, 300)
+    bad = b"@bad\n" + strain[100:250] + b"\n+\n" + b"I" * 170 + b"\n"
+    open(tmp_path / "whole.fq", "wb").write(head + bad + _fastq(rng, strain, 300))
+    open(tmp_path / "ok.fq", "wb").write(_fastq(rng, strain, 500))
+    open(tmp_path / "list.txt", "w").write("".join(str(tmp_path / n) + "\n" for n in ("ok.fq", "wrapped.fq", "whole.fq", "ok.fq")))
+    base = dict(os.environ, SK_THREADS="3", ASAN_OPTIONS="detect_leaks=0")
+    cut = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "1"], env=dict(base, SK_SPLIT_BYTES="5000"),
+                         capture_output=True, timeout=300)
+    uncut = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "1"], env=dict(base, SK_NO_SPLIT="1"),
+                           capture_output=True, timeout=300)
+    assert cut.returncode == 0 and uncut.returncode == 0, (cut.stdout, cut.stderr[-1500:])
+    assert cut.stdout == uncut.stdout and cut.stdout.startswith(b"OK") and cut.stderr == b""
+    said = subprocess.run([exe, str(tmp_path / "strain.fa"), str(tmp_path / "list.txt"), "1"], env=dict(base, SK_SPLIT_BYTES="5000", SK_TIMING="1"),
+                          capture_output=True, timeout=300)
+    assert said.stdout == uncut.stdout and b"did not hold; the list is scanned again uncut" in said.stderr      # (the fall-back did run)
