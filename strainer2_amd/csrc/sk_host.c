@@ -1260,7 +1260,7 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
                 *o = *o == SKH_PLAN_SKIPPED || *o == owner[i] ? owner[i] : SKH_PLAN_SHARED;
             }
     }
-    if (world > 1 && !plan_only) {
+    if (ctx && !plan_only) {                            /* (a world of one with a communicator -- SK_FORCE_COMM -- takes the same road: tests) */
         /* local settings that change the plan (SK_SPLIT_BYTES, SK_NO_SPLIT) or a file whose size another rank sees
          * differently would have byte ranges scanned twice or never and the summed table silently wrong: every rank
          * leaves instead.  (Without an in-library communicator -- a caller that reduces the counters itself -- the
