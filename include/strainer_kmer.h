@@ -107,6 +107,15 @@ int sk_table_load_ex(sk_ctx *ctx, const uint64_t *keys, uint32_t nrows, uint32_t
  * expected places (a 62-bit compare each, as exact as a table probe) instead of being probed one by one.
  * Replaces nothing in the reference: BIO_searchHash per window (src/BIO_hash.c:161-172) stays the meaning. */
 int sk_table_load_text(sk_ctx *ctx, const uint32_t *text2, uint32_t nbases, const uint32_t *first_pos);
+/* The whole table made ON THE DEVICE from the strain's text (new; strain_detect's opening): text2 = the bases, 2 bits each, records end
+ * to end (as for sk_table_load_text); startok = one bit per position, set where a window of 31 A/C/G/T bases of one record starts
+ * (nstarts of them) -- the windows src/genome_compare.c:1000-1019 makes keys of.  Rows are numbered by first occurrence along the
+ * text; column 0 of every row = col0_value (src/strain_detect.c:139: default 1, increment 0); *nrows = distinct keys.  No byte-string
+ * keys: a strain with U/IUPAC letters goes through skh_keyset_from_file + skh_keyset_load.  sk_table_export_keys: the keys in
+ * row order, once.  Replaces GEN_hash_sequences_set_count_vec (src/genome_compare.c:967-1030) for strain_detect. */
+int sk_table_build_from_text(sk_ctx *ctx, const uint32_t *text2, const uint32_t *startok, uint32_t nbases, uint32_t nstarts,
+                             uint32_t ncols, uint32_t col0_value, uint32_t *nrows);
+int sk_table_export_keys(sk_ctx *ctx, uint64_t *keys_out /* nrows */);
 
 /* Wide keys: rows whose 31-byte upper-cased oriented key contains bytes other than ACGT
  * (IUPAC letters in the strain: SURVEY 8(a) a3/a6).  keys31 = nwide * 32 bytes, each key

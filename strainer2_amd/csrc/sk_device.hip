@@ -1645,6 +1645,89 @@ __global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint
     }
 }
 
+// ---- the table built ON THE DEVICE from the strain's 2-bit text (sk_table_build_from_text; strain_detect's opening) -----------------
+// The host hands over the text (records end to end) and one bit per position "a window of 31 A/C/G/T bases of one record starts
+// here" (src/genome_compare.c:1000-1019: every such window's oriented form is a key).  Rows are numbered by first occurrence along
+// the text, which makes the counter index of a text position its RANK -- the layout the scan's verify stage wants anyway.
+__device__ __forceinline__ bool sk_bit(const uint32_t *__restrict__ bits, uint32_t p) { return (bits[p >> 5] >> (p & 31u)) & 1u; }
+__device__ __forceinline__ uint64_t sk_text_canon(const uint32_t *__restrict__ text2, uint32_t p, uint32_t *is_fwd)
+{
+    const uint64_t fwd = sk_text_key(text2, p);
+    uint64_t r = ((uint64_t)__builtin_bitreverse32((uint32_t)fwd) << 32) | __builtin_bitreverse32((uint32_t)(fwd >> 32));
+    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+    const uint64_t rc = (~r) >> 2;
+    *is_fwd = fwd > rc;
+    return fwd > rc ? fwd : rc;
+}
+// every window's key into the slots; the slot keeps the LOWEST position of its key (with the orientation it has there)
+__global__ void sk_build_insert(const uint32_t *__restrict__ text2, const uint32_t *__restrict__ startok, uint32_t nbases, sk_u4 *slots, uint32_t mask)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p + SK_K > nbases || !sk_bit(startok, p)) return;
+    uint32_t fw;
+    const uint64_t k = sk_text_canon(text2, p, &fw);
+    uint32_t slot = sk_slot0(sk_khash(k), mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long *)&slots[slot], (unsigned long long)SK_EMPTY64, (unsigned long long)k);
+        if (old == SK_EMPTY64 || old == k) { atomicMin(&((uint32_t *)&slots[slot])[3], (p << 1) | fw); return; }
+        slot = (slot + 1u) & mask;
+    }
+}
+__device__ __forceinline__ uint32_t sk_build_find(const sk_u4 *slots, uint32_t mask, uint64_t k)
+{
+    uint32_t slot = sk_slot0(sk_khash(k), mask);
+    while (sk_slot_key(slots[slot]) != k) slot = (slot + 1u) & mask;       // (the key is there: sk_build_insert put it)
+    return slot;
+}
+// the positions at which a key occurs for the first time: the rank map's bits
+__global__ void sk_build_first(const uint32_t *__restrict__ text2, const uint32_t *__restrict__ startok, uint32_t nbases, const sk_u4 *slots, uint32_t mask, sk_u4 *rank)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p + SK_K > nbases || !sk_bit(startok, p)) return;
+    uint32_t fw;
+    const uint64_t k = sk_text_canon(text2, p, &fw);
+    if ((slots[sk_build_find(slots, mask, k)].w >> 1) != p) return;
+    atomicOr((uint32_t *)&rank[p >> 6] + ((p & 32u) ? 2 : 1), 1u << (p & 31u));          // (.y: bits 0..31 of the block, .z: 32..63)
+}
+// rank[b].x = first-occurrence positions before block b (one workgroup walks the blocks in slices; *total = all of them)
+__global__ __launch_bounds__(1024) void sk_build_rank_scan(sk_u4 *rank, uint32_t nblk, uint32_t *total)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nblk + 1023u) / 1024u, lo = threadIdx.x * per;
+    uint32_t t = 0;
+    for (uint32_t i = lo; i < lo + per && i < nblk; i++) t += (uint32_t)__popc(rank[i].y) + (uint32_t)__popc(rank[i].z);
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t d = 1u; d < 1024u; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - t;
+    for (uint32_t i = lo; i < lo + per && i < nblk; i++) { const uint32_t v = (uint32_t)__popc(rank[i].y) + (uint32_t)__popc(rank[i].z); rank[i].x = run; run += v; }
+    if (threadIdx.x == 1023u) *total = part[1023];
+}
+// every row's counter index (= the rank of its first position) into its slot, and its key into the row-ordered key list
+__global__ void sk_build_index(const uint32_t *__restrict__ text2, uint32_t nbases, sk_u4 *slots, uint32_t mask, const sk_u4 *__restrict__ rank, uint64_t *__restrict__ keys_by_row)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p + SK_K > nbases) return;
+    const sk_u4 r = rank[p >> 6];
+    const uint64_t bits = ((uint64_t)r.z << 32) | r.y;
+    if (!((bits >> (p & 63u)) & 1ull)) return;
+    const uint32_t idx = r.x + (uint32_t)__popcll(bits & ((1ull << (p & 63u)) - 1ull));
+    uint32_t fw;
+    const uint64_t k = sk_text_canon(text2, p, &fw);
+    ((uint32_t *)&slots[sk_build_find(slots, mask, k)])[2] = idx;
+    keys_by_row[idx] = k;
+}
+__global__ void sk_fill32(uint32_t *p, uint32_t n, uint32_t v)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // the same set from the table's slots (a table loaded without a text stage: built when the first scan needs it)
 __global__ void sk_grid_insert_slots(const sk_u4 *__restrict__ slots, uint64_t nslots, uint32_t *__restrict__ w1, uint32_t nblocks1,
                                      uint32_t *__restrict__ w2, uint32_t shift2)
@@ -1716,6 +1799,7 @@ struct sk_ctx {
     uint2       *d_grid1, *d_grid2;       // grid kernel's two filter levels
     uint32_t     grid1_blocks, grid2_blocks_log2;
     long         grid_kib;                // option: size of level 1 in KiB (-1 = automatic)
+    uint64_t    *d_keys_by_row;           // sk_table_build_from_text: the keys in row order, until sk_table_export_keys fetched them
     bool         grid_pending;            // the two levels are allocated and zeroed, not filled yet (sk_grid_ensure)
     bool         all_rows_in_text;        // every key is a window of the text stage (sk_table_load_text)
     long         odd_cap;                 // option (tests): usable length of the odd-chunk list, 0 = all of it
@@ -1858,6 +1942,7 @@ static void sk_table_release(sk_ctx *c)
     hipFree(c->d_grid1); c->d_grid1 = NULL;
     hipFree(c->d_grid2); c->d_grid2 = NULL;
     hipFree(c->d_grid3); c->d_grid3 = NULL;
+    hipFree(c->d_keys_by_row); c->d_keys_by_row = NULL;
     c->grid_pending = false; c->all_rows_in_text = false;
     hipFree(c->d_counts); c->d_counts = NULL;
     hipFree(c->d_perm); c->d_perm = NULL;
@@ -2091,6 +2176,100 @@ extern "C" int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nba
     SK_HIP(c, hipStreamSynchronize(c->stream));
     SK_HIP(c, hipGetLastError());
     c->text_bases = nbases;
+    return SK_OK;
+}
+
+// The whole table from the strain's text, on the device (round 3; strain_detect's opening: src/strain_detect.c:137-139 builds it with
+// GEN_hash_sequences_set_count_vec(r, 31, h, 1, 0, 0, 6), src/genome_compare.c:967-1030).  The host parses the file and hands over the
+// bases (2 bits each, records end to end) and, per position, whether a window of 31 A/C/G/T bases of one record starts there; keys,
+// first occurrences, row numbers (by first occurrence: "strain order"), rank map, both filter levels and column 0 are made here --
+// no 40 MB of keys, no permutations and no column 0 over PCIe, no hash table on the host.  *nrows_out = distinct keys.
+extern "C" int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const uint32_t *startok, uint32_t nbases, uint32_t nstarts,
+                                        uint32_t ncols, uint32_t col0_value, uint32_t *nrows_out)
+{
+    if (!c || !text2 || !startok || !nrows_out || ncols == 0 || ncols > 16) return SK_E_ARG;
+    if (nbases < SK_K || nbases > 0x7FFFFF00u) return sk_fail(c, SK_E_ARG, "text of %u bases (a table slot holds 31 bits of position)", nbases);
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    sk_table_release(c);
+    uint32_t lg = 10;
+    while (((uint64_t)1 << lg) * (uint64_t)c->table_load_pct < (uint64_t)nstarts * 100ull && lg < 31) lg++;
+    const uint64_t slots = (uint64_t)1 << lg;
+    const uint32_t mask = (uint32_t)(slots - 1);
+    c->slots_log2 = lg;
+    const size_t words = (size_t)nbases / 16 + 4, have = ((size_t)nbases + 15) / 16, nblk = (size_t)nbases / 64 + 2, bwords = ((size_t)nbases + 31) / 32;
+    uint32_t *d_ok = NULL, *d_total = NULL;
+    SK_HIP(c, hipMalloc((void **)&c->d_keys, slots * sizeof(sk_u4)));
+    SK_HIP(c, hipMalloc((void **)&c->d_text2, words * 4));
+    SK_HIP(c, hipMalloc((void **)&c->d_rank, nblk * sizeof(sk_u4)));
+    SK_HIP(c, hipMalloc((void **)&d_ok, bwords * 4 + 4));
+    d_total = d_ok + bwords;
+    hipLaunchKernelGGL(sk_fill64, dim3(2048), dim3(256), 0, c->stream, (uint64_t *)c->d_keys, 2 * slots, SK_EMPTY64);
+    SK_HIP(c, hipMemsetAsync(c->d_text2, 0, words * 4, c->stream));
+    SK_HIP(c, hipMemsetAsync(c->d_rank, 0, nblk * sizeof(sk_u4), c->stream));
+    SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 16 * sizeof(uint32_t), c->stream));
+    SK_HIP(c, hipMemcpyAsync(c->d_text2, text2, have * 4, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(c, hipMemcpyAsync(d_ok, startok, bwords * 4, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((nbases + 255) / 256), block(256);
+    hipLaunchKernelGGL(sk_build_insert, grid, block, 0, c->stream, (const uint32_t *)c->d_text2, (const uint32_t *)d_ok, nbases, c->d_keys, mask);
+    hipLaunchKernelGGL(sk_build_first, grid, block, 0, c->stream, (const uint32_t *)c->d_text2, (const uint32_t *)d_ok, nbases, (const sk_u4 *)c->d_keys, mask, c->d_rank);
+    hipLaunchKernelGGL(sk_build_rank_scan, dim3(1), dim3(1024), 0, c->stream, c->d_rank, (uint32_t)nblk, d_total);
+    uint32_t nrows = 0;
+    SK_HIP(c, hipMemcpyAsync(&nrows, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_ok);
+    *nrows_out = nrows;
+    c->nrows = nrows; c->ncols = ncols;
+    c->text_bases = nbases;
+    c->all_rows_in_text = true;
+    const size_t cbytes = (size_t)(nrows ? nrows : 1) * ncols * sizeof(uint32_t);
+    SK_HIP(c, hipMalloc((void **)&c->d_counts, cbytes));
+    SK_HIP(c, hipMemsetAsync(c->d_counts, 0, cbytes, c->stream));
+    if (nrows) {
+        SK_HIP(c, hipMalloc((void **)&c->d_keys_by_row, (size_t)nrows * 8));
+        hipLaunchKernelGGL(sk_build_index, grid, block, 0, c->stream, (const uint32_t *)c->d_text2, nbases, c->d_keys, mask, (const sk_u4 *)c->d_rank, c->d_keys_by_row);
+        if (col0_value) hipLaunchKernelGGL(sk_fill32, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, c->d_counts, nrows, col0_value);
+        // the filter levels, sized as sk_table_load_ex sizes them, filled from the text
+        uint64_t kib = c->grid_kib > 0 ? (uint64_t)c->grid_kib : ((uint64_t)nrows * 5ull / 8ull + 1023ull) / 1024ull;
+        if (kib > (1ull << 22)) kib = 1ull << 22;
+        if (kib < 4ull) kib = 4ull;
+        c->grid1_blocks = (uint32_t)(kib * 1024ull / sizeof(uint2));
+        uint32_t g2 = 12;
+        while (g2 < 34 && ((uint64_t)1 << g2) < (uint64_t)nrows * 32ull) g2++;
+        c->grid2_blocks_log2 = g2 - 6u;
+        const size_t b1 = (size_t)c->grid1_blocks * sizeof(uint2), b2 = ((size_t)1 << c->grid2_blocks_log2) * sizeof(uint2);
+        SK_HIP(c, hipMalloc((void **)&c->d_grid1, b1));
+        SK_HIP(c, hipMalloc((void **)&c->d_grid2, b2));
+        SK_HIP(c, hipMemsetAsync(c->d_grid1, 0, b1, c->stream));
+        SK_HIP(c, hipMemsetAsync(c->d_grid2, 0, b2, c->stream));
+        hipLaunchKernelGGL(sk_grid_insert_text, grid, block, 0, c->stream, (const uint32_t *)c->d_text2, nbases,
+                           (uint32_t *)c->d_grid1, c->grid1_blocks, (uint32_t *)c->d_grid2, 32u - c->grid2_blocks_log2);
+        c->grid_pending = false;
+        c->diff_col = -1;
+        SK_HIP(c, hipMalloc((void **)&c->d_diff, ((size_t)nrows + 2) * 4));
+        SK_HIP(c, hipMalloc((void **)&c->d_diff_sums, ((size_t)nrows / SK_DIFF_PER_BLOCK + 2) * 4));
+        SK_HIP(c, hipMemsetAsync(c->d_diff, 0, ((size_t)nrows + 2) * 4, c->stream));
+    } else {                                             // (no key at all: an empty table the scans skip)
+        c->grid1_blocks = 512; c->grid2_blocks_log2 = 6;
+        SK_HIP(c, hipMalloc((void **)&c->d_grid1, 512 * sizeof(uint2)));
+        SK_HIP(c, hipMalloc((void **)&c->d_grid2, 64 * sizeof(uint2)));
+        SK_HIP(c, hipMemsetAsync(c->d_grid1, 0, 512 * sizeof(uint2), c->stream));
+        SK_HIP(c, hipMemsetAsync(c->d_grid2, 0, 64 * sizeof(uint2), c->stream));
+    }
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    SK_HIP(c, hipGetLastError());
+    return SK_OK;
+}
+
+// the keys of a table built by sk_table_build_from_text, in row order (once: the device copy is released)
+extern "C" int sk_table_export_keys(sk_ctx *c, uint64_t *keys_out)
+{
+    if (!c || (!keys_out && c->nrows)) return SK_E_ARG;
+    if (!c->d_keys_by_row && c->nrows) return sk_fail(c, SK_E_STATE, "no key list to export (sk_table_build_from_text first, once)");
+    SK_HIP(c, hipSetDevice(c->device));
+    if (c->nrows) SK_HIP(c, hipMemcpy(keys_out, c->d_keys_by_row, (size_t)c->nrows * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(c->d_keys_by_row);
+    c->d_keys_by_row = NULL;
     return SK_OK;
 }
 

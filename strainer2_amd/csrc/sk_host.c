@@ -604,6 +604,66 @@ int skh_keyset_from_stream(skh_keyset *ks, const char *stream, size_t nbytes, ui
     return rc;
 }
 
+/* ---- the key set built on the DEVICE (strain_detect's opening, round 3) ----------------------------------------------------
+ * The host's part shrinks to what needs the file: the reference's record grammar (src/kseq.h:166-211), the strain's bases packed
+ * 2 bits each, records end to end, and one bit per position "a window of 31 A/C/G/T bases of ONE record starts here" -- the
+ * windows src/genome_compare.c:1000-1019 turns into keys (N breaks a window, :1007; records shorter than k - 1 are skipped and
+ * counted as the host builder does).  sk_table_build_from_text makes keys, first occurrences, row numbers, rank map, filters and
+ * column 0 from that; the keys come back once, in row order, for the hit lines' k-mer text.  A strain with any other letter (U,
+ * IUPAC: byte-string keys) is not for this path: SK_E_UNSUPPORTED, and the caller builds the key set on the host as before. */
+typedef struct { uint32_t *text2, *ok; uint64_t n, cap_words, ok_words; uint64_t nstarts, short_records; int soft; } dk_state;
+
+static int dk_record(void *user, char *seq, size_t len)
+{
+    dk_state *d = (dk_state *)user;
+    uint32_t run = 0;
+    size_t i;
+    if (len + 1 < SK_K) { d->short_records++; return 0; }
+    if ((d->n + len + 64) / 16 + 1 > d->cap_words) {
+        uint64_t want = d->cap_words ? d->cap_words * 2 : 1u << 16;
+        while (want < (d->n + len + 64) / 16 + 1) want *= 2;
+        d->text2 = (uint32_t *)realloc(d->text2, want * sizeof(uint32_t));
+        d->ok = (uint32_t *)realloc(d->ok, (want / 2 + 2) * sizeof(uint32_t));          /* (one bit per base: 16 bases per text word) */
+        memset(d->text2 + d->cap_words, 0, (want - d->cap_words) * sizeof(uint32_t));
+        memset(d->ok + d->ok_words, 0, (want / 2 + 2 - d->ok_words) * sizeof(uint32_t));
+        d->cap_words = want;
+        d->ok_words = want / 2 + 2;
+    }
+    for (i = 0; i < len; i++) {
+        const uint32_t c = (uint8_t)seq[i];
+        const uint64_t at = d->n + i;
+        if (sk_is_acgt(c)) {
+            d->text2[at >> 4] |= (sk_code(c) & 3u) << (2u * (15u - (uint32_t)(at & 15u)));
+            if (++run >= SK_K) { const uint64_t p = at - (SK_K - 1); d->ok[p >> 5] |= 1u << (p & 31u); d->nstarts++; }
+        } else {
+            run = 0;
+            if (!sk_is_hard_break(c)) d->soft = 1;          /* a letter the packed table cannot hold: the host's builder decides */
+        }
+    }
+    d->n += len;
+    return 0;
+}
+
+int skh_keyset_build_on_device(skh_keyset *ks, sk_ctx *ctx, const char *path, uint32_t ncols, uint32_t col0_value)
+{
+    dk_state d;
+    uint32_t nrows = 0;
+    int rc;
+    if (!ks || !ctx || !path) return SK_E_ARG;
+    memset(ks, 0, sizeof *ks);
+    memset(&d, 0, sizeof d);
+    rc = parse_file(path, dk_record, &d, NULL, NULL, 0);
+    if (rc == SK_OK && (d.soft || d.nstarts == 0 || d.n >= 0x7FFFFF00u)) rc = SK_E_UNSUPPORTED;
+    if (rc == SK_OK) rc = sk_table_build_from_text(ctx, d.text2, d.ok, (uint32_t)d.n, (uint32_t)d.nstarts, ncols, col0_value, &nrows);
+    free(d.text2); free(d.ok);
+    if (rc != SK_OK) return rc;
+    ks->nrows = nrows;
+    ks->short_records = d.short_records;
+    ks->packed = (uint64_t *)malloc((size_t)(nrows ? nrows : 1) * sizeof(uint64_t));
+    if (!ks->packed) return SK_E_NOMEM;
+    return sk_table_export_keys(ctx, ks->packed);
+}
+
 void skh_keyset_free(skh_keyset *ks)
 {
     if (!ks) return;

@@ -72,6 +72,7 @@ static size_t sd_chunk_bytes(void)
 typedef struct {
     sk_ctx     *ctx;
     int         ctx_rc;        /* status of a context opened in the background (0 = fine or not tried) */
+    int         table_on_device;/* the key set was built on the device (skh_keyset_build_on_device): the table is loaded already */
     skh_keyset  ks;
     uint32_t   *type;          /* host copy of the type column */
     FILE       *out, *err;
@@ -1347,6 +1348,25 @@ typedef struct { ks_job *jobs; uint32_t njobs, next; pthread_mutex_t mu; pthread
 
 static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a, const char *g, const char *o, int device);
 
+/* A strain's key set.  Round 3: built ON THE DEVICE from the strain's text (skh_keyset_build_on_device: the host only parses the
+ * file and packs the bases; no hash table of 5 M keys on the host, no 140 MB of keys, permutations and columns over PCIe) -- the
+ * context must be there first.  A strain with byte-string keys (U, IUPAC), a context that could not be opened (the caller reports it)
+ * or SK_SD_HOST_KEYSET=1 (tests compare the two ways) take the host's builder as before; strain_detect never shows the order of
+ * the rows, so either numbering serves. */
+static int sd_keyset(sd_prog *p, const char *r, int device)
+{
+    if (!getenv("SK_SD_HOST_KEYSET")) {
+        if (!p->ctx && !p->ctx_rc) p->ctx_rc = sk_ctx_create(&p->ctx, device);
+        if (p->ctx) {
+            const int rc = skh_keyset_build_on_device(&p->ks, p->ctx, r, SD_NCOLS, SD_PLAIN);
+            if (rc == SK_OK) { p->table_on_device = 1; return SK_OK; }
+            skh_keyset_free(&p->ks);
+            if (rc != SK_E_UNSUPPORTED && rc != SK_E_OPEN) return rc;      /* (an unreadable file: the host's builder says so in the reference's words) */
+        }
+    }
+    return skh_keyset_from_file(&p->ks, r, SD_ROW_ORDER, SD_PLAIN, 0);
+}
+
 static void *sd_keyset_pool_thread(void *arg)
 {
     ks_pool *kp = (ks_pool *)arg;
@@ -1357,8 +1377,8 @@ static void *sd_keyset_pool_thread(void *arg)
         int rc;
         if (k >= kp->njobs) return NULL;
         j = &kp->jobs[k];
-        rc = skh_keyset_from_file(&j->p->ks, j->r, SD_ROW_ORDER, SD_PLAIN, 0);
         if (j->cj) j->p->ctx_rc = sk_ctxjob_join(j->cj, &j->p->ctx);
+        rc = sd_keyset(j->p, j->r, j->device);
         real_out = j->p->out; real_err = j->p->err;
         mo = open_memstream(&j->out_buf, &j->out_len);
         me = open_memstream(&j->err_buf, &j->err_len);
@@ -1405,7 +1425,7 @@ static int sd_strain_finish(sd_prog *p, int ks_rc, const char *r, const char *a,
         rc = p->ctx ? SK_OK : (p->ctx_rc ? p->ctx_rc : sk_ctx_create(&p->ctx, device));
         if (rc != SK_OK) { fprintf(err, "strain_detect: cannot use HIP device %d: %s\n", device, sk_strerror(rc)); return 1; }
         t1 = now_s();
-        rc = skh_keyset_load(p->ctx, &p->ks, SD_NCOLS);
+        rc = p->table_on_device ? SK_OK : skh_keyset_load(p->ctx, &p->ks, SD_NCOLS);
         if (rc != SK_OK) { fprintf(err, "strain_detect: table load failed: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
         t2 = now_s();
         frc = sd_strain_flags(p, a, g, o);
@@ -1472,9 +1492,9 @@ static int sd_strain_open(sd_prog *p, const char *r, const char *a, const char *
     memset(p, 0, sizeof *p);
     p->out = out;
     p->err = err;
-    sk_ctxjob_start(&cj, device);                        /* the HIP runtime comes up while the key set is built */
-    ks_rc = skh_keyset_from_file(&p->ks, r, SD_ROW_ORDER, SD_PLAIN, 0);
+    sk_ctxjob_start(&cj, device);                        /* (the HIP runtime comes up on a helper thread) */
     p->ctx_rc = sk_ctxjob_join(&cj, &p->ctx);
+    ks_rc = sd_keyset(p, r, device);
     return sd_strain_finish(p, ks_rc, r, a, g, o, device);
 }
 

@@ -8,6 +8,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#define SK_E_UNSUPPORTED -100
 /* record a message for sk_last_error and hand back `code` */
 int sk_fail_(sk_ctx *ctx, int code, const char *fmt, ...);
 int sk_ctx_device_(const sk_ctx *ctx);
@@ -21,9 +22,11 @@ void skc_destroy(skc_acc *a);
 int skc_add_hit(skc_acc *a, const char *metagenome, int64_t hits_pe1, int64_t hits_pe2, uint32_t row);
 int skc_add_trailer(skc_acc *a, const char *metagenome, const char *name, int64_t value);
 int skc_report(skc_acc *a, sk_ctx *ctx, const char *hits_file_name, FILE *out, FILE *err);
+/* strain_detect's key set built on the device (sk_host.c): SK_OK, the ctx holds the table and *ks the keys in row order; SK_E_UNSUPPORTED: a
+ * strain with letters other than A/C/G/T/N (byte-string keys) or without a key -- the caller builds it on the host */
+int skh_keyset_build_on_device(skh_keyset *ks, sk_ctx *ctx, const char *path, uint32_t ncols, uint32_t col0_value);
 /* gzip on the device (sk_inflate.hip; experimental, SK_GPU_INFLATE=1).  SK_E_UNSUPPORTED: not a file this path takes, or a check failed --
  * the caller decodes it on the host as before. */
-#define SK_E_UNSUPPORTED -100
 typedef struct sk_inflater sk_inflater;
 int  sk_inflater_create(int device, sk_inflater **out);
 void sk_inflater_destroy(sk_inflater *f);

@@ -68,6 +68,46 @@ int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nbases, const 
     free(pos_by_loc);
     return SK_OK;
 }
+/* the device-built table of strain_detect's opening, restated for the double: keys of the marked windows, rows by first occurrence */
+typedef struct { uint64_t k; uint32_t p; } kp;
+static int kp_cmp(const void *a, const void *b) { const kp *x = a, *y = b; return x->k < y->k ? -1 : x->k > y->k ? 1 : x->p < y->p ? -1 : x->p > y->p; }
+static int u32_cmp(const void *a, const void *b) { const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const uint32_t *ok, uint32_t nbases, uint32_t nstarts, uint32_t ncols, uint32_t col0, uint32_t *nrows)
+{
+    kp *w = malloc(((size_t)nstarts + 1) * sizeof *w);
+    uint32_t *first = malloc(((size_t)nstarts + 1) * 4), nw = 0, nf = 0, p, i;
+    uint64_t *keys;
+    for (p = 0; p + 31 <= nbases; p++) {
+        uint64_t k = 0, rc;
+        uint32_t j;
+        if (!((ok[p >> 5] >> (p & 31)) & 1u)) continue;
+        for (j = 0; j < 31; j++) { const uint32_t q = p + j; k = (k << 2) | ((text2[q >> 4] >> (2 * (15 - (q & 15)))) & 3u); }
+        rc = sk_revcomp62(k);
+        if (nw >= nstarts) return die("sk_table_build_from_text: more marked windows than nstarts");
+        w[nw].k = k > rc ? k : rc; w[nw].p = p; nw++;
+    }
+    if (nw != nstarts) return die("sk_table_build_from_text: nstarts does not count the marked windows");
+    qsort(w, nw, sizeof *w, kp_cmp);
+    for (i = 0; i < nw; i++) if (i == 0 || w[i].k != w[i - 1].k) first[nf++] = w[i].p;      /* a key's lowest position */
+    qsort(first, nf, 4, u32_cmp);
+    keys = malloc(((size_t)nf + 1) * 8);
+    for (i = 0; i < nf; i++) {
+        uint64_t k = 0, rc;
+        uint32_t j;
+        for (j = 0; j < 31; j++) { const uint32_t q = first[i] + j; k = (k << 2) | ((text2[q >> 4] >> (2 * (15 - (q & 15)))) & 3u); }
+        rc = sk_revcomp62(k);
+        keys[i] = k > rc ? k : rc;
+    }
+    free(w); free(first);
+    free(c->key); free(c->row); free(c->cols); free(c->loc); free(c->rawkey);
+    c->key = NULL; c->row = NULL; c->cols = NULL; c->loc = NULL; c->rawkey = NULL;
+    sk_table_load_ex(c, keys, nf, ncols, NULL);
+    for (i = 0; i < nf; i++) c->cols[i] = col0;
+    free(keys);
+    *nrows = nf;
+    return SK_OK;
+}
+int sk_table_export_keys(sk_ctx *c, uint64_t *out) { memcpy(out, c->rawkey, (size_t)c->n * 8); return SK_OK; }
 int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in) { memcpy(c->cols + (size_t)col * c->n, in, (size_t)c->n * 4); return SK_OK; }
 int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out) { memcpy(out, c->cols + (size_t)col * c->n, (size_t)c->n * 4); return SK_OK; }
 

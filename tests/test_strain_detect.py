@@ -83,6 +83,62 @@ def test_sd_program_matches_reference_golden(golden, name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["batch", "cli_pe", "background", "err_no_inf"])
+def test_sd_program_with_the_key_set_built_on_the_host(golden, name, tmp_path, monkeypatch):
+    """Round 3: by default the key set of a strain is built ON THE DEVICE from its text (sk_table_build_from_text: keys, first
+    occurrences, rows numbered along the text, rank map, filters, column 0) -- the goldens above run that way.  SK_SD_HOST_KEYSET=1
+    keeps the host's builder (skh_keyset_from_file + skh_keyset_load), which strains with byte-string keys still take: same output."""
+    monkeypatch.setenv("SK_SD_HOST_KEYSET", "1")
+    d, meta, out, err, hits = _case(golden, name)
+    p, got = _run(_gpu_runner, d, meta, tmp_path)
+    assert p.returncode == meta["returncode"] and p.stdout == out and p.stderr == err
+    if meta["returncode"] == 0:
+        assert got == hits
+
+
+@pytest.mark.gpu
+def test_table_built_on_the_device_equals_the_hosts(tmp_path):
+    """sk_table_build_from_text against the host's key set on a strain with repeats, both strands of a segment, N runs, lower
+    case, a record of 30 bases (no window) and one of 31: the same SET of keys (the numbering is by first occurrence along the
+    text in both, so the same order too), column 0 all 1, and a scan counts every row alike through either table."""
+    import ctypes as C
+    from strainer2_amd.native import lib
+    rng = random.Random(314)
+    a = _synth.rand_dna(rng, 3000)
+    recs = [a[:1200] + b"NN" + a[1200:2000].lower() + b"N" + a[100:400], _synth.revcomp(a[500:900]) + a[2000:], a[:30], a[7:38], _synth.rand_dna(rng, 500)]
+    fa = tmp_path / "s.fa"
+    fa.write_bytes(b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(recs)))
+    host = sk.Keyset.from_stream(b"\n".join(recs) + b"\n", default_val=1, incr=0)
+    reads = _synth.fuzz_stream(rng, a, 400, junk=b"Nn", p_junk=0.003, min_len=31, max_len=160)
+    with sk.KmerContext(0) as ch, sk.KmerContext(0) as cd:
+        ch.load_keyset(host, 6)
+        ch.scan_stream(reads, 2)
+        # the device's way, through the program's own host step (the record parser + packing) via the C entry point
+        dks = sk.native._KeysetStruct()
+        lib.skh_keyset_build_on_device.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
+        rc = lib.skh_keyset_build_on_device(C.byref(dks), cd._h, os.fsencode(str(fa)), 6, 1)
+        assert rc == 0
+        n = dks.nrows
+        dev_keys = [lib_key(dks, r) for r in range(n)]
+        assert sorted(dev_keys) == sorted(host.keys()) and n == host.nrows
+        cd.scan_stream(reads, 2)
+        hc, dc = ch.counts(2), cd.counts(2)
+        by_key_h = dict(zip(host.keys(), hc.tolist()))
+        by_key_d = dict(zip(dev_keys, dc.tolist()))
+        assert by_key_h == by_key_d and sum(by_key_h.values()) > 1000
+        assert cd.counts(0).tolist() == [1] * n
+        lib.skh_keyset_free(C.byref(dks))
+
+
+def lib_key(dks, row):
+    import ctypes as C
+    from strainer2_amd.native import lib
+    buf = C.create_string_buffer(32)
+    lib.skh_keyset_key(C.byref(dks), row, buf)
+    return buf.value
+
+
+@pytest.mark.gpu
 def test_sd_program_bundled_step3_md5(golden, tmp_path):
     b = os.path.join(golden, "bundled")
     facts = json.load(open(os.path.join(b, "step3_facts.json")))
