@@ -116,6 +116,7 @@ int sk_table_load_text(sk_ctx *ctx, const uint32_t *text2, uint32_t nbases, cons
 int sk_table_build_from_text(sk_ctx *ctx, const uint32_t *text2, const uint32_t *startok, uint32_t nbases, uint32_t nstarts,
                              uint32_t ncols, uint32_t col0_value, uint32_t *nrows);
 int sk_table_export_keys(sk_ctx *ctx, uint64_t *keys_out /* nrows */);
+int sk_table_export_keys_of(sk_ctx *ctx, const uint32_t *rows, uint32_t n, uint64_t *keys_out /* n */);   /* ... of n chosen rows */
 
 /* Wide keys: rows whose 31-byte upper-cased oriented key contains bytes other than ACGT
  * (IUPAC letters in the strain: SURVEY 8(a) a3/a6).  keys31 = nwide * 32 bytes, each key
@@ -203,6 +204,8 @@ int sk_sync(sk_ctx *ctx);
  * (src/kmer_scrub_count.c:144-151; src/genome_compare.c:1011-1016). */
 int sk_counts_fetch(sk_ctx *ctx, uint32_t col, uint32_t *out /* nrows */);
 int sk_counts_set(sk_ctx *ctx, uint32_t col, const uint32_t *in /* nrows */);
+/* counts[col][rows[i]] = value, i < n: a sparse update (new; strain_detect's type column names 1 % of the rows informative) */
+int sk_counts_set_rows(sk_ctx *ctx, uint32_t col, const uint32_t *rows, uint32_t n, uint32_t value);
 int sk_counts_zero(sk_ctx *ctx, uint32_t col);
 /* Device address of the whole counter block (ncols * nrows u32) for a caller-run collective
  * (torch.distributed / RCCL all-reduce over xGMI).  New: the reference is single-process. */

@@ -1722,6 +1722,16 @@ __global__ void sk_build_index(const uint32_t *__restrict__ text2, uint32_t nbas
     ((uint32_t *)&slots[sk_build_find(slots, mask, k)])[2] = idx;
     keys_by_row[idx] = k;
 }
+__global__ void sk_set_rows_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ rows, uint32_t n, const uint32_t *__restrict__ perm, uint32_t v)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[perm ? perm[rows[i]] : rows[i]] = v;
+}
+__global__ void sk_gather_keys(uint64_t *__restrict__ out, const uint64_t *__restrict__ keys_by_row, const uint32_t *__restrict__ rows, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = keys_by_row[rows[i]];
+}
 __global__ void sk_fill32(uint32_t *p, uint32_t n, uint32_t v)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2261,15 +2271,36 @@ extern "C" int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const 
     return SK_OK;
 }
 
-// the keys of a table built by sk_table_build_from_text, in row order (once: the device copy is released)
+// the keys of a table built by sk_table_build_from_text, in row order (the device keeps its list: 8 bytes per row)
 extern "C" int sk_table_export_keys(sk_ctx *c, uint64_t *keys_out)
 {
     if (!c || (!keys_out && c->nrows)) return SK_E_ARG;
-    if (!c->d_keys_by_row && c->nrows) return sk_fail(c, SK_E_STATE, "no key list to export (sk_table_build_from_text first, once)");
+    if (!c->d_keys_by_row && c->nrows) return sk_fail(c, SK_E_STATE, "no key list to export (sk_table_build_from_text first)");
     SK_HIP(c, hipSetDevice(c->device));
     if (c->nrows) SK_HIP(c, hipMemcpy(keys_out, c->d_keys_by_row, (size_t)c->nrows * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(c->d_keys_by_row);
-    c->d_keys_by_row = NULL;
+    return SK_OK;
+}
+// ... of n chosen rows only (strain_detect prints the k-mers of informative rows -- 1 % of them -- and of no others: 40 MB per
+// strain stay where they are)
+extern "C" int sk_table_export_keys_of(sk_ctx *c, const uint32_t *rows, uint32_t n, uint64_t *keys_out)
+{
+    if (!c || (n && (!rows || !keys_out))) return SK_E_ARG;
+    if (!n) return SK_OK;
+    if (!c->d_keys_by_row) return sk_fail(c, SK_E_STATE, "no key list to export (sk_table_build_from_text first)");
+    for (uint32_t i = 0; i < n; i++) if (rows[i] >= c->nrows) return sk_fail(c, SK_E_ARG, "row %u out of range", rows[i]);
+    SK_HIP(c, hipSetDevice(c->device));
+    void *d = NULL;
+    SK_HIP(c, hipMalloc(&d, (size_t)n * 12));
+    uint64_t *d_out = (uint64_t *)d;
+    uint32_t *d_rows = (uint32_t *)(d_out + n);
+    hipError_t e = hipMemcpyAsync(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sk_gather_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_out, (const uint64_t *)c->d_keys_by_row, (const uint32_t *)d_rows, n);
+        e = hipMemcpyAsync(keys_out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    SK_HIP(c, e);
     return SK_OK;
 }
 
@@ -3175,6 +3206,30 @@ extern "C" int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in)
         SK_HIP(c, hipMemcpyAsync(dst, in, (size_t)c->nrows * 4, hipMemcpyHostToDevice, c->stream));
     }
     SK_HIP(c, hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+// counts[col][rows[i]] = value for n rows (caller's row numbers): what a column of mostly one value needs instead of 4 bytes per row
+// over PCIe (strain_detect's type column: "informative" for the 1 % of rows the -a list names; src/strain_detect.c:668-726)
+extern "C" int sk_counts_set_rows(sk_ctx *c, uint32_t col, const uint32_t *rows, uint32_t n, uint32_t value)
+{
+    if (!c || (n && !rows)) return SK_E_ARG;
+    c->infbits_ok = false;
+    if (!c->d_counts || col >= c->ncols) return sk_fail(c, SK_E_ARG, "bad column");
+    for (uint32_t i = 0; i < n; i++) if (rows[i] >= c->nrows) return sk_fail(c, SK_E_ARG, "row %u out of range", rows[i]);
+    SK_HIP(c, hipSetDevice(c->device));
+    { int rc_ = sk_diff_flush(c); if (rc_) return rc_; }
+    if (!n) return SK_OK;
+    uint32_t *d_rows = NULL;
+    SK_HIP(c, hipMalloc((void **)&d_rows, (size_t)n * 4));
+    hipError_t e = hipMemcpyAsync(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sk_set_rows_u32, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_counts + (size_t)col * c->nrows, (const uint32_t *)d_rows, n,
+                           (const uint32_t *)c->d_perm, value);
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(d_rows);
+    SK_HIP(c, e);
     return SK_OK;
 }
 

@@ -659,9 +659,26 @@ int skh_keyset_build_on_device(skh_keyset *ks, sk_ctx *ctx, const char *path, ui
     if (rc != SK_OK) return rc;
     ks->nrows = nrows;
     ks->short_records = d.short_records;
-    ks->packed = (uint64_t *)malloc((size_t)(nrows ? nrows : 1) * sizeof(uint64_t));
-    if (!ks->packed) return SK_E_NOMEM;
-    return sk_table_export_keys(ctx, ks->packed);
+    /* the keys stay on the device; the host's list is filled in for the rows somebody asks about (skh_keyset_fetch_keys: the
+     * informative rows, whose k-mers the hit lines print).  0 = not fetched: no canonical key is 0 (the reverse complement of
+     * thirty-one A's is thirty-one T's, the larger of the two).  calloc: pages nobody touches cost nothing */
+    ks->packed = (uint64_t *)calloc((size_t)(nrows ? nrows : 1), sizeof(uint64_t));
+    return ks->packed ? SK_OK : SK_E_NOMEM;
+}
+
+int skh_keyset_fetch_keys(skh_keyset *ks, sk_ctx *ctx, const uint32_t *rows, uint32_t n)
+{
+    uint64_t *k;
+    uint32_t i;
+    int rc;
+    if (!ks || !ctx || (n && !rows)) return SK_E_ARG;
+    if (!n) return SK_OK;
+    k = (uint64_t *)malloc((size_t)n * sizeof *k);
+    if (!k) return SK_E_NOMEM;
+    rc = sk_table_export_keys_of(ctx, rows, n, k);
+    for (i = 0; i < n && rc == SK_OK; i++) ks->packed[rows[i]] = k[i];
+    free(k);
+    return rc;
 }
 
 void skh_keyset_free(skh_keyset *ks)

@@ -991,6 +991,8 @@ static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *
     uint32_t j;
     char key[32];
     for (j = 0; j < n; j++) {
+        if (p->table_on_device && p->ks.packed[rows[j]] == 0 && skh_keyset_fetch_keys(&p->ks, p->ctx, &rows[j], 1) != SK_OK)
+            p->job_rc = SK_E_HIP;                            /* (a row whose key was not fetched with the informative ones: one at a time) */
         skh_keyset_key(&p->ks, rows[j], key);
         if (nl <= 3800) {
             unsigned char *w0 = skzo_reserve(p->zo, nl + 128), *w = w0;
@@ -1258,12 +1260,17 @@ static int sd_flag_informative(sd_prog *p, const char *path, unsigned *n_out)
         else if (kind[i] == 1 && tally[2 * slot[i]]) n++;
         else fprintf(p->out, "error could not find informative kmer %s in the total kmer list\n", piece[i]);
     }
-    for (i = 0; i < np; i++) free(piece[i]);
-    free(piece); free(kind); free(slot); free(stream); free(start); free(tally); free(hits);
     if (!rc && p->ks.nrows) {
-        rc = sk_counts_set(p->ctx, SD_TYPE, p->type);
+        /* every row's type is PLAIN on the device already (column 0 after the build: src/strain_detect.c:139): only the rows the
+         * list named go up -- 50 k row numbers instead of the 20 MB column */
+        uint32_t *rows = (uint32_t *)malloc(((size_t)nq + 1) * sizeof *rows), nr = 0;
+        for (i = 0; i < nh && i < nq && rows; i++) rows[nr++] = hits[i].row;      /* (a row named twice is set twice) */
+        rc = rows ? sk_counts_set_rows(p->ctx, SD_TYPE, rows, nr, SD_INFORMATIVE) : SK_E_NOMEM;
+        free(rows);
         if (rc) fprintf(p->err, "strain_detect: device error: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx));
     }
+    for (i = 0; i < np; i++) free(piece[i]);
+    free(piece); free(kind); free(slot); free(stream); free(start); free(tally); free(hits);
     *n_out = n;
     return rc ? 1 : 0;
 }
@@ -1403,6 +1410,14 @@ static int sd_strain_flags(sd_prog *p, const char *a, const char *g, const char 
     if (sd_flag_informative(p, a, &n_inform)) return 1;
     if (g && sd_background_filter(p, g, 0.5, n_inform)) return 1;
     for (i = 0; i < p->ks.nrows; i++) if (p->type[i] == SD_INFORMATIVE) p->genome_inf++;
+    if (p->table_on_device && p->genome_inf) {           /* the k-mers the hit lines will print: the informative rows' keys, and no others */
+        uint32_t *rows = (uint32_t *)malloc((size_t)p->genome_inf * sizeof *rows), nr = 0;
+        int rc;
+        for (i = 0; i < p->ks.nrows; i++) if (p->type[i] == SD_INFORMATIVE) rows[nr++] = i;
+        rc = skh_keyset_fetch_keys(&p->ks, p->ctx, rows, nr);
+        free(rows);
+        if (rc) { fprintf(p->err, "strain_detect: device error: %s (%s)\n", sk_strerror(rc), sk_last_error(p->ctx)); return 1; }
+    }
     p->zo = skzo_open(sd_zpool, o);
     if (!p->zo) { fprintf(p->err, "could not open *gzout file outfile %s in quantify_hits_all_files()\n", o); return 1; }
     p->o_path = strdup(o);

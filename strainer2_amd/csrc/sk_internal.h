@@ -25,6 +25,8 @@ int skc_report(skc_acc *a, sk_ctx *ctx, const char *hits_file_name, FILE *out, F
 /* strain_detect's key set built on the device (sk_host.c): SK_OK, the ctx holds the table and *ks the keys in row order; SK_E_UNSUPPORTED: a
  * strain with letters other than A/C/G/T/N (byte-string keys) or without a key -- the caller builds it on the host */
 int skh_keyset_build_on_device(skh_keyset *ks, sk_ctx *ctx, const char *path, uint32_t ncols, uint32_t col0_value);
+/* ... whose host list of keys (ks->packed) is filled in on demand: the keys of these rows now */
+int skh_keyset_fetch_keys(skh_keyset *ks, sk_ctx *ctx, const uint32_t *rows, uint32_t n);
 /* gzip on the device (sk_inflate.hip; experimental, SK_GPU_INFLATE=1).  SK_E_UNSUPPORTED: not a file this path takes, or a check failed --
  * the caller decodes it on the host as before. */
 typedef struct sk_inflater sk_inflater;

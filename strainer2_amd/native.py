@@ -40,9 +40,9 @@ SK_E_OPEN = -5
 # every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load", "sk_table_load_ex",
-    "sk_table_load_wide", "sk_table_load_text", "sk_table_build_from_text", "sk_table_export_keys", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
+    "sk_table_load_wide", "sk_table_load_text", "sk_table_build_from_text", "sk_table_export_keys", "sk_table_export_keys_of", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
     "sk_ticket_wait", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
-    "sk_counts_set", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
+    "sk_counts_set", "sk_counts_set_rows", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
     "sk_counts_allreduce", "sk_comm_init", "sk_comm_init_ex", "sk_rendezvous_exchange", "sk_comm_destroy", "sk_comm_sum_u32", "sk_comm_agree_u64", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",

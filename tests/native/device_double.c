@@ -108,6 +108,8 @@ int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const uint32_t *o
     return SK_OK;
 }
 int sk_table_export_keys(sk_ctx *c, uint64_t *out) { memcpy(out, c->rawkey, (size_t)c->n * 8); return SK_OK; }
+int sk_table_export_keys_of(sk_ctx *c, const uint32_t *rows, uint32_t n, uint64_t *out) { uint32_t i; for (i = 0; i < n; i++) { if (rows[i] >= c->n) return die("sk_table_export_keys_of: row out of range"); out[i] = c->rawkey[rows[i]]; } return SK_OK; }
+int sk_counts_set_rows(sk_ctx *c, uint32_t col, const uint32_t *rows, uint32_t n, uint32_t v) { uint32_t i; for (i = 0; i < n; i++) c->cols[(size_t)col * c->n + rows[i]] = v; return SK_OK; }
 int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in) { memcpy(c->cols + (size_t)col * c->n, in, (size_t)c->n * 4); return SK_OK; }
 int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out) { memcpy(out, c->cols + (size_t)col * c->n, (size_t)c->n * 4); return SK_OK; }
 

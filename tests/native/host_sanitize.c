@@ -16,6 +16,7 @@ int sk_table_load_wide(sk_ctx *c, const char *k, const uint32_t *r, uint32_t n) 
 int sk_table_load_text(sk_ctx *c, const uint32_t *t, uint32_t n, const uint32_t *f) { (void)c; (void)t; (void)n; (void)f; return unreachable("sk_table_load_text"); }
 int sk_table_build_from_text(sk_ctx *c, const uint32_t *t, const uint32_t *o, uint32_t n, uint32_t ns, uint32_t nc, uint32_t v, uint32_t *r) { (void)c; (void)t; (void)o; (void)n; (void)ns; (void)nc; (void)v; (void)r; return unreachable("sk_table_build_from_text"); }
 int sk_table_export_keys(sk_ctx *c, uint64_t *k) { (void)c; (void)k; return unreachable("sk_table_export_keys"); }
+int sk_table_export_keys_of(sk_ctx *c, const uint32_t *r, uint32_t n, uint64_t *k) { (void)c; (void)r; (void)n; (void)k; return unreachable("sk_table_export_keys_of"); }
 int sk_counts_set(sk_ctx *c, uint32_t col, const uint32_t *in) { (void)c; (void)col; (void)in; return unreachable("sk_counts_set"); }
 int sk_counts_fetch(sk_ctx *c, uint32_t col, uint32_t *out) { (void)c; (void)col; (void)out; return unreachable("sk_counts_fetch"); }
 int sk_scan_stream(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col) { (void)c; (void)s; (void)n; (void)col; return unreachable("sk_scan_stream"); }

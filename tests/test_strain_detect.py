@@ -119,6 +119,18 @@ def test_table_built_on_the_device_equals_the_hosts(tmp_path):
         rc = lib.skh_keyset_build_on_device(C.byref(dks), cd._h, os.fsencode(str(fa)), 6, 1)
         assert rc == 0
         n = dks.nrows
+        # the keys stay on the device until asked for: none fetched yet; a handful of rows first, then the rest, against the whole export
+        assert lib_key(dks, 0) == b"A" * 31
+        some = (C.c_uint32 * 5)(n - 1, 0, 17, 17, n // 2)
+        lib.skh_keyset_fetch_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        assert lib.skh_keyset_fetch_keys(C.byref(dks), cd._h, some, 5) == 0
+        whole = (C.c_uint64 * n)()
+        lib.sk_table_export_keys.argtypes = [C.c_void_p, C.c_void_p]
+        assert lib.sk_table_export_keys(cd._h, whole) == 0
+        assert [dks.packed[r] for r in (n - 1, 0, 17, n // 2)] == [whole[r] for r in (n - 1, 0, 17, n // 2)] and dks.packed[1] == 0
+        every = (C.c_uint32 * n)(*range(n))
+        assert lib.skh_keyset_fetch_keys(C.byref(dks), cd._h, every, n) == 0
+        assert list(dks.packed[:n]) == list(whole)
         dev_keys = [lib_key(dks, r) for r in range(n)]
         assert sorted(dev_keys) == sorted(host.keys()) and n == host.nrows
         cd.scan_stream(reads, 2)
@@ -127,6 +139,14 @@ def test_table_built_on_the_device_equals_the_hosts(tmp_path):
         by_key_d = dict(zip(dev_keys, dc.tolist()))
         assert by_key_h == by_key_d and sum(by_key_h.values()) > 1000
         assert cd.counts(0).tolist() == [1] * n
+        # a few rows of a column set to one value (strain_detect's informative rows): the others keep theirs
+        lib.sk_counts_set_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+        assert lib.sk_counts_set_rows(cd._h, 0, some, 5, 2) == 0
+        want = [1] * n
+        for r in (n - 1, 0, 17, n // 2):
+            want[r] = 2
+        assert cd.counts(0).tolist() == want and cd.counts(2).tolist() == dc.tolist()
+        assert lib.sk_counts_set_rows(cd._h, 0, (C.c_uint32 * 1)(n), 1, 2) != 0        # a row the table does not have
         lib.skh_keyset_free(C.byref(dks))
 
 
