@@ -13,13 +13,14 @@
 //                     ACGT (U / IUPAC / junk): the reference's signed-char orientation compare
 //                     through its COMPLEMENT map.  Early exit unless phase 1 saw such a byte.
 //   sk_table_insert   open-addressed key table (atomicCAS on the key word)
-//   sk_grid_insert    the two filter levels (canonical 16-mers of every key)
+//   sk_grid_insert    the two filter levels (canonical 16-mers / 24-mers of every key)
 //   sk_gather/scatter counters <-> caller row order
 //
 // Data layout in HBM:
 //   slots  [S]  16 B  {u64 key, u32 counter index, u32 text position << 1 | orientation}: open addressing,
 //                     linear probing, S = 2^s >= 2 nrows, empty = key all ones (one random line per hit)
-//   grid1/grid2 8 B   blocks of the Bloom sets of the strain's canonical 16-mers (level 1 sized for the L2)
+//   grid1       8 B   blocks of the Bloom set of the strain's canonical 16-mers (level 1, sized for the L2)
+//   grid2       8 B   blocks of the Bloom set of the strain's canonical 24-mers (level 2: the chunk + the 8 bases on either side)
 //   text2       u32   the strain's bases, 2 bits each, records end to end (1.25 MB for 5 Mbp)
 //   rank        16 B  per 64 text positions: {counter index of the first one, 64 "a row starts here" bits}
 //   counts [ncols][nrows] u32, in locality (first-occurrence) order: one read's hits are adjacent
@@ -47,8 +48,11 @@
 // ---------------------------------------------------------------------------------------------
 // scan kernel geometry
 // ---------------------------------------------------------------------------------------------
+#ifndef SK_THREADS
 #define SK_THREADS      256                 // 4 waves of 64
+#endif
 #define SK_WAVES        (SK_THREADS / 64)
+static_assert(SK_THREADS <= 256 && SK_THREADS % 64 == 0, "a tile's window numbers are kept in 16 bits (wq, cq): at most 256 threads x 128 positions");
 #define SK_SPAN         128                 // window-end positions per thread
 #define SK_SPAN_CH      8                   // 16-base chunks per span
 #define SK_TILE         (SK_THREADS * SK_SPAN)
@@ -382,9 +386,6 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
 #ifndef SK_LAZY_MASKS
 #define SK_LAZY_MASKS 0                      // measured (profiles/r03_kernel_experiments.txt): a third fewer vector instructions and NO gain
 #endif
-#ifndef SK_L2_BATCH
-#define SK_L2_BATCH 2                      // phase 2: 0 = one level-2 question per loop iteration, 1 = a thread's questions together, 2 = and two more level-1 questions first
-#endif
 #ifndef SK_L2_K
 #define SK_L2_K 2                          // ... chunks per round (4: -3 %, 2: -4.7 % with no strain reads)
 #endif
@@ -456,6 +457,39 @@ __device__ __forceinline__ bool sk_grid_test(const uint2 blk, uint32_t bits)
     const uint32_t t = (blk.x >> (bits >> 27)) & (blk.x >> ((bits >> 22) & 31u)) &
                        (blk.y >> ((bits >> 17) & 31u)) & (blk.y >> ((bits >> 12) & 31u));
     return (t & 1u) != 0u;
+}
+
+// Level 2 is keyed on 24-MERS (round 3).  Every window of a chunk holds, whole, either the chunk and the 8 bases before it or the
+// chunk and the 8 bases behind it (windows that begin 8..15 bases before the chunk: the first; the others: the second) -- so a
+// chunk neither of whose two 24-mers is a 24-mer of the strain has no window left.  A 16-mer stops being selective when the table
+// is a union of many strains (32 x 5 Mbp: 7.5 % of ALL canonical 16-mers are in it, every one of them a true positive of a filter
+// keyed on 16-mers, each then costing a table probe and sixteen windows one by one); a 24-mer of unrelated DNA is in no table.
+// f: 24 packed bases, the first in bits 47..46; canonical = the smaller of the two orientations; two hashes of the 48 bits, one for
+// the block and one for the bits in it (with a single 32-bit hash the union's 160 M entries would collide with 4 % of all questions).
+__device__ __forceinline__ uint64_t sk_canon24(uint64_t f)
+{
+    uint64_t y = __builtin_bitreverse64(f) >> 16;
+    y = ((y >> 1) & 0x555555555555ull) | ((y & 0x555555555555ull) << 1);
+    const uint64_t rc = ~y & 0xFFFFFFFFFFFFull;
+    return f < rc ? f : rc;
+}
+__device__ __forceinline__ uint32_t sk_h24_block(uint64_t c24) { return sk_gmix((uint32_t)c24 ^ ((uint32_t)(c24 >> 32) * 0x9E3779B1u)); }
+__device__ __forceinline__ uint32_t sk_h24_bits(uint64_t c24) { return sk_gmix((uint32_t)c24 * 0x7FEB352Du + (uint32_t)(c24 >> 32) * 0x846CA68Bu); }
+// the 24 bases of the text that start at position q (the text array has two spare words behind its last base)
+__device__ __forceinline__ uint64_t sk_text_24(const uint32_t *__restrict__ text2, uint32_t q)
+{
+    const uint32_t w = q >> 4, o2 = 2u * (q & 15u);
+    const uint64_t x = ((uint64_t)text2[w] << 32) | text2[w + 1u];
+    return ((x << o2) | ((uint64_t)text2[w + 2u] >> (32u - o2))) >> 16;
+}
+__device__ __forceinline__ void sk_grid2_insert24(uint32_t *__restrict__ w2, uint32_t shift2, uint64_t f24)
+{
+    const uint64_t c24 = sk_canon24(f24);
+    const uint32_t b = sk_grid2_bits(sk_h24_bits(c24));
+    uint32_t *blk = w2 + 2u * (size_t)sk_grid2_block(sk_h24_block(c24), shift2);
+    const uint32_t m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)), m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
+    if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
+    if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
 }
 
 // level-1 filter verdict on one packed 16-mer (either orientation): false = certainly not in the strain
@@ -739,9 +773,8 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         // exact: stage 2 verifies every window.
         // (a loop over the set bits, not over the eight chunks: a thread rarely has more than one survivor of level 1,
         // and the unrolled form cost every wave all eight bodies)
-#if SK_L2_BATCH == 2
         // Round 3.  What the false positives of level 1 cost is not the latency of their level-2 questions (asking them together
-        // changed nothing, SK_L2_BATCH 1) but their NUMBER: 7 % of all chunks, each a random 64-byte line from a 32 MiB array that
+        // changed nothing) but their NUMBER: 7 % of all chunks, each a random 64-byte line from a 32 MiB array that
         // never stays in the L2 -- 2.4 M line fetches per 0.6 Gbase competing with the stream for the fabric: 0.082 ms of a
         // 0.293 ms launch (ablation: the same kernel with level 1's verdicts dropped takes 0.211 ms).  Level 1 itself has room --
         // its lookups are L2 hits and the L2 serves 60 % of the requests it could --, so a false positive is first asked two
@@ -757,11 +790,12 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             while (ap) { m2 |= ap; pend &= ~ap; ap = pend & (ap << 1); }
             if (!pend) break;
             uint32_t starts = pend & ~(pend << 1), st = starts, taken = 0u;
-            uint32_t ix[SK_L2_K], gl[SK_L2_K], gr[SK_L2_K], g2[SK_L2_K], oks[SK_L2_K];
-            uint2 bl[SK_L2_K], br[SK_L2_K], b2[SK_L2_K];
+            uint32_t ix[SK_L2_K], gl[SK_L2_K], gr[SK_L2_K], oks[SK_L2_K], w3[SK_L2_K][3];
+            uint2 bl[SK_L2_K], br[SK_L2_K];
 #pragma unroll
             for (int k = 0; k < SK_L2_K; k++) {
-                ix[k] = 8u; gl[k] = gr[k] = g2[k] = oks[k] = 0u;
+                ix[k] = 8u; gl[k] = gr[k] = oks[k] = 0u;
+                w3[k][0] = w3[k][1] = w3[k][2] = 0u;
                 bl[k] = br[k] = make_uint2(0u, 0u);
                 if (st) {
                     const uint32_t i = (uint32_t)__builtin_ctz(st);
@@ -773,74 +807,45 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                     const uint32_t cwn = rec[((cid + 1u) >> 3) * SK_REC_DW + ((cid + 1u) & 7u)];
                     const bool lv_ok = (sk_chunk_inv(rec, cid - 1u) >> 8) == 0u, rv_ok = (sk_chunk_inv(rec, cid + 1u) & 0xFFu) == 0u;
                     const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
-                    const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr), rc = sk_revcomp32(cw);
+                    const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr);
                     ix[k] = i;
-                    gl[k] = sk_gmix(wl < rl ? wl : rl); gr[k] = sk_gmix(wr < rr ? wr : rr); g2[k] = sk_gmix(cw < rc ? cw : rc);
+                    gl[k] = sk_gmix(wl < rl ? wl : rl); gr[k] = sk_gmix(wr < rr ? wr : rr);
+                    w3[k][0] = cwp; w3[k][1] = cw; w3[k][2] = cwn;
                     oks[k] = (lv_ok ? 1u : 0u) | (rv_ok ? 2u : 0u);
                     if (lv_ok) bl[k] = table.grid1[sk_grid1_block(gl[k], table.grid1_blocks)];
                     if (rv_ok) br[k] = table.grid1[sk_grid1_block(gr[k], table.grid1_blocks)];
                 }
             }
+            // level 2, keyed on 24-mers: a side whose half-shifted 16-mer the strain has is asked about its 24-mer (the chunk and the
+            // 8 bases on that side); the chunk goes on if either side's 24-mer is the strain's.  One side first (inside a strain read
+            // it passes, and the other side's question -- always a miss in the L2 -- would buy nothing), the other only if that fails.
+            uint32_t hb[SK_L2_K];
+            uint2 q2[SK_L2_K];
 #pragma unroll
             for (int k = 0; k < SK_L2_K; k++) {
-                const bool keep = ix[k] < 8u && (((oks[k] & 1u) && sk_grid_test(bl[k], sk_grid1_bits(gl[k]))) ||
-                                                 ((oks[k] & 2u) && sk_grid_test(br[k], sk_grid1_bits(gr[k]))));
-                b2[k] = make_uint2(0u, 0u);
-                if (keep) b2[k] = table.grid2[sk_grid2_block(g2[k], table.grid2_shift)];
-                else ix[k] = 8u;
-            }
-#pragma unroll
-            for (int k = 0; k < SK_L2_K; k++)
-                if (ix[k] < 8u) m2 |= (uint32_t)sk_grid_test(b2[k], sk_grid2_bits(g2[k])) << ix[k];
-            pend &= ~taken;
-        }
-#elif SK_L2_BATCH
-        // Round 3: the level-2 questions of a thread go out TOGETHER.  The loop used to ask one chunk per iteration, each answer an
-        // L2 miss (the 32 MiB level never stays in the L2): a wave ran as many dependent misses in a row as its busiest lane had
-        // survivors of level 1 (three, typically) -- 4-6 us of a workgroup's ~30 us life spent waiting, with every wave slot of the
-        // CU taken.  Now a round asks about the FIRST chunk of every run of survivors that is left (at most four runs in eight
-        // chunks; their loads are independent), the rest of a run follows its first chunk's verdict as before (pass: the run passes
-        // on its level-1 verdicts; fail: the next round asks about the run's next chunk).  One round settles all but the rare run
-        // of two false positives.  Same pruning as the loop it replaces, bit for bit.
-        uint32_t m2 = 0, pend = m;
-        while (pend) {
-            uint32_t ap = pend & (m2 << 1);                       // right behind a chunk that passed: passes, and so on down the run
-            while (ap) { m2 |= ap; pend &= ~ap; ap = pend & (ap << 1); }
-            if (!pend) break;
-            const uint32_t starts = pend & ~(pend << 1);          // the first chunk of every run that is left
-            uint32_t st = starts, gi[4], ix[4];
-            uint2 b2[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                ix[k] = 8u; gi[k] = 0u; b2[k] = make_uint2(0u, 0u);
-                if (st) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(st);
-                    st &= st - 1u;
-                    const uint32_t cw = my[i];
-                    const uint32_t rc = sk_revcomp32(cw);
-                    ix[k] = i;
-                    gi[k] = sk_gmix(cw < rc ? cw : rc);
-                    b2[k] = table.grid2[sk_grid2_block(gi[k], table.grid2_shift)];
+                const bool al = ix[k] < 8u && (oks[k] & 1u) && sk_grid_test(bl[k], sk_grid1_bits(gl[k]));
+                const bool ar = ix[k] < 8u && (oks[k] & 2u) && sk_grid_test(br[k], sk_grid1_bits(gr[k]));
+                oks[k] = (al ? 1u : 0u) | (ar ? 2u : 0u);
+                q2[k] = make_uint2(0u, 0u);
+                hb[k] = 0u;
+                if (al | ar) {
+                    const uint64_t c24 = sk_canon24(al ? ((uint64_t)(w3[k][0] & 0xFFFFu) << 32) | w3[k][1] : ((uint64_t)w3[k][1] << 16) | (w3[k][2] >> 16));
+                    hb[k] = sk_h24_bits(c24);
+                    q2[k] = table.grid2[sk_grid2_block(sk_h24_block(c24), table.grid2_shift)];
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (ix[k] < 8u) m2 |= (uint32_t)sk_grid_test(b2[k], sk_grid2_bits(gi[k])) << ix[k];
-            pend &= ~starts;
+            for (int k = 0; k < SK_L2_K; k++) {
+                if (!oks[k]) continue;
+                bool pass = sk_grid_test(q2[k], sk_grid2_bits(hb[k]));
+                if (!pass && oks[k] == 3u) {                                   // (both sides were candidates and the first is not the strain's)
+                    const uint64_t c24 = sk_canon24(((uint64_t)w3[k][1] << 16) | (w3[k][2] >> 16));
+                    pass = sk_grid_test(table.grid2[sk_grid2_block(sk_h24_block(c24), table.grid2_shift)], sk_grid2_bits(sk_h24_bits(c24)));
+                }
+                if (pass) m2 |= 1u << ix[k];
+            }
+            pend &= ~taken;
         }
-#else
-        uint32_t m2 = 0, left = m;
-        while (left) {
-            const uint32_t i = (uint32_t)__builtin_ctz(left);
-            left &= left - 1u;
-            if (i > 0u && ((m2 >> (i - 1u)) & 1u)) { m2 |= 1u << i; continue; }
-            const uint32_t cw = my[i];
-            const uint32_t rc = sk_revcomp32(cw);
-            const uint32_t gi = sk_gmix(cw < rc ? cw : rc);
-            const uint2 b2 = table.grid2[sk_grid2_block(gi, table.grid2_shift)];   // (nontemporal loads here: 7 % slower)
-            m2 |= (uint32_t)sk_grid_test(b2, sk_grid2_bits(gi)) << i;
-        }
-#endif
         m = m2;
     }
 
@@ -1632,17 +1637,14 @@ __global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint
         const uint32_t f = (uint32_t)(k >> (2 * (15 - off)));
         const uint32_t r = sk_revcomp16(f);
         const uint32_t g = sk_gmix(f < r ? f : r);
-        const uint32_t a = sk_grid1_bits(g), b = sk_grid2_bits(g);
+        const uint32_t a = sk_grid1_bits(g);
         // consecutive keys share 15 of their 16 sub-words: most bits are set already, so look before the atomic
         uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
-        uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
-        if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
-        if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
-        blk = w2 + 2u * (size_t)sk_grid2_block(g, shift2);
-        m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)); m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
+        const uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
         if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
         if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
     }
+    for (int off = 0; off < 8; off++) sk_grid2_insert24(w2, shift2, (k >> (2 * (7 - off))) & 0xFFFFFFFFFFFFull);   // level 2: its eight 24-mers
 }
 
 // ---- the table built ON THE DEVICE from the strain's 2-bit text (sk_table_build_from_text; strain_detect's opening) -----------------
@@ -1750,16 +1752,13 @@ __global__ void sk_grid_insert_slots(const sk_u4 *__restrict__ slots, uint64_t n
             const uint32_t f = (uint32_t)(k >> (2 * (15 - off)));
             const uint32_t r = sk_revcomp16(f);
             const uint32_t g = sk_gmix(f < r ? f : r);
-            const uint32_t a = sk_grid1_bits(g), b = sk_grid2_bits(g);
+            const uint32_t a = sk_grid1_bits(g);
             uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
-            uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
-            if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
-            if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
-            blk = w2 + 2u * (size_t)sk_grid2_block(g, shift2);
-            m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)); m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
+            const uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
             if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
             if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
         }
+        for (int off = 0; off < 8; off++) sk_grid2_insert24(w2, shift2, (k >> (2 * (7 - off))) & 0xFFFFFFFFFFFFull);
     }
 }
 
@@ -1776,15 +1775,12 @@ __global__ void sk_grid_insert_text(const uint32_t *__restrict__ text2, uint32_t
     const uint32_t f = (uint32_t)(((((uint64_t)text2[w] << 32) | text2[w + 1u]) << o2) >> 32);
     const uint32_t r = sk_revcomp16(f);
     const uint32_t g = sk_gmix(f < r ? f : r);
-    const uint32_t a = sk_grid1_bits(g), b = sk_grid2_bits(g);
+    const uint32_t a = sk_grid1_bits(g);
     uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
-    uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
+    const uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
     if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
     if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
-    blk = w2 + 2u * (size_t)sk_grid2_block(g, shift2);
-    m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)); m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
-    if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
-    if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
+    if (q + 24u <= nbases) sk_grid2_insert24(w2, shift2, sk_text_24(text2, q));       // level 2: the text's 24-mer at this place
 }
 
 // ---------------------------------------------------------------------------------------------
