@@ -68,11 +68,6 @@ static_assert(SK_THREADS <= 256 && SK_THREADS % 64 == 0, "a tile's window number
 #define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
 #define SK_EV_PAIRS     64u                 // launches whose timing events are kept before they are added up
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
-#ifndef SK_SHIFTED_TEST
-#define SK_SHIFTED_TEST 0                   // phase 2: ask the level-1 filter about the half-shifted 16-mers before level 2.  Measured
-                                            // (profiles/r02_phase2_experiments.txt): it halves the kernel's L2 misses and changes nothing
-                                            // (+2 %): the kernel is bound by the L2's REQUEST rate, and the question costs two requests
-#endif
 #ifndef SK_CHUNK_REJECT
 #define SK_CHUNK_REJECT 1                   // stage 2: three filter questions per differing base before its ~31 windows go one by one
 #endif
@@ -738,34 +733,6 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     for (int i = 0; i < SK_SPAN_CH; i++)
         m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) &&
                         ((ABLATE != 4 && ABLATE != 6 && ABLATE != 10) || g[i] == 0x9E3779B9u)) << i;     // (ablations: loads kept alive, verdicts dropped)
-    if (m && SK_SHIFTED_TEST && !CAND) {                          // (CAND: the LDS slice and the L2 block have both said maybe -- 0.3 % false positives left)
-        // Second question to the same L2-resident filter: every window of a chunk also holds the 16-mer that starts
-        // 8 bases before the chunk (the windows that begin 8..15 bases before it) or the one that starts 8 bases into
-        // it (the others).  A chunk both of whose half-shifted 16-mers are strangers to the strain (or hold a
-        // non-ACGT byte) has no window left.  Cuts the false positives of one lookup (~7 %) to about 1 %, for two
-        // more lookups per pass -- which mostly hit the L2, where the level-2 lookup they save never does.
-        uint32_t keep = 0;
-        const uint32_t *pv = rec + tid * SK_REC_DW;               // the thread before this one
-        const uint32_t *nx = rec + (tid + 2u) * SK_REC_DW;        // and the one after
-#pragma unroll
-        for (int i = 0; i < SK_SPAN_CH; i++)
-            if ((m >> i) & 1u) {
-                const uint32_t cw = my[i];
-                const uint32_t cwp = i > 0 ? my[i - 1] : pv[7], cwn = i < SK_SPAN_CH - 1 ? my[i + 1] : nx[0];
-                const uint32_t ivp = i > 0 ? (((i - 1) & 1) ? my[8 + ((i - 1) >> 1)] >> 16 : my[8 + ((i - 1) >> 1)] & 0xFFFFu) : pv[11] >> 16;
-                const uint32_t ivn = i < SK_SPAN_CH - 1 ? (((i + 1) & 1) ? my[8 + ((i + 1) >> 1)] >> 16 : my[8 + ((i + 1) >> 1)] & 0xFFFFu) : nx[8] & 0xFFFFu;
-                const bool lv_ok = (ivp >> 8) == 0u, rv_ok = (ivn & 0xFFu) == 0u;   // the 8 bases they borrow from the neighbours are ACGT
-                const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
-                const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr);
-                const uint32_t gl = sk_gmix(wl < rl ? wl : rl), gr = sk_gmix(wr < rr ? wr : rr);
-                uint2 bl = make_uint2(0u, 0u), br = make_uint2(0u, 0u);                  // (both lookups in flight together)
-                if (lv_ok) bl = table.grid1[sk_grid1_block(gl, table.grid1_blocks)];
-                if (rv_ok) br = table.grid1[sk_grid1_block(gr, table.grid1_blocks)];
-                const bool any = (lv_ok && sk_grid_test(bl, sk_grid1_bits(gl))) || (rv_ok && sk_grid_test(br, sk_grid1_bits(gr)));
-                keep |= (uint32_t)any << i;
-            }
-        m = keep;
-    }
     if (m && ABLATE != 5 && !CAND) {                              // (ABLATE 5, exact: no level 2, stage 2 sorts it out)                                                      // level 2 (rare for unrelated reads)
         // A chunk right after one that passed level 2 is taken on its level-1 pass alone: inside a strain read
         // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
@@ -805,7 +772,12 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                     const uint32_t cw  = rec[(cid >> 3) * SK_REC_DW + (cid & 7u)];
                     const uint32_t cwp = rec[((cid - 1u) >> 3) * SK_REC_DW + ((cid - 1u) & 7u)];
                     const uint32_t cwn = rec[((cid + 1u) >> 3) * SK_REC_DW + ((cid + 1u) & 7u)];
-                    const bool lv_ok = (sk_chunk_inv(rec, cid - 1u) >> 8) == 0u, rv_ok = (sk_chunk_inv(rec, cid + 1u) & 0xFFu) == 0u;
+                    uint32_t ivp = sk_chunk_inv(rec, cid - 1u), ivn = sk_chunk_inv(rec, cid + 1u);
+                    if (LAZY) {                                                              // (phase 1 only noted THAT a neighbour is not clean)
+                        if (ivp == 0xFFFFu) ivp = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid - 1u));
+                        if (ivn == 0xFFFFu) ivn = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid + 1u));
+                    }
+                    const bool lv_ok = (ivp >> 8) == 0u, rv_ok = (ivn & 0xFFu) == 0u;        // the 8 bases borrowed from either neighbour are ACGT
                     const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
                     const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr);
                     ix[k] = i;
