@@ -161,6 +161,7 @@ int sk_tally_batch(sk_ctx *ctx, const uint8_t *stream, uint64_t nbytes, const ui
 typedef struct sk_batch sk_batch;
 int  sk_batch_create(sk_ctx *ctx, sk_batch **out);          /* on ctx's device; errors are reported through ctx */
 void sk_batch_destroy(sk_batch *b);
+int  sk_batch_sync(sk_batch *b);                               /* its uploads are done: the host memory it was filled from may be reused, the batch kept for the next file */
 int  sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec);
 int  sk_tally_launch(sk_ctx *ctx, const sk_batch *b, uint32_t type_col, uint32_t informative_value, uint64_t hits_cap);
 int  sk_tally_collect(sk_ctx *ctx, uint32_t *out_tally /* 2*nrec */, sk_hit *out_hits /* hits_cap */, uint64_t *out_nhits);

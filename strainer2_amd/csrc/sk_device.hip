@@ -2477,6 +2477,15 @@ extern "C" int sk_batch_create(sk_ctx *c, sk_batch **out)
     return SK_OK;
 }
 
+// waits until the batch's uploads are done: its device buffers may be refilled and the host memory it was filled from reused
+extern "C" int sk_batch_sync(sk_batch *b)
+{
+    if (!b) return SK_E_ARG;
+    SK_HIP(b->owner, hipSetDevice(b->owner->device));
+    SK_HIP(b->owner, hipStreamSynchronize(b->stream));
+    return SK_OK;
+}
+
 extern "C" void sk_batch_destroy(sk_batch *b)
 {
     if (!b) return;

@@ -168,6 +168,8 @@ static void sd_pin_close(void)
     sd_pin.ctx = NULL;
 }
 
+static void sd_unmap_later(void *p, size_t n);
+
 static void chunk_free(sd_chunk *c)
 {
     uint32_t s;
@@ -477,7 +479,7 @@ static void *sd_decode_thread(void *arg)
         parser_free(&ps);
     }
     if (own) skzp_close(&zp);
-    if (map) munmap((void *)map, mlen);
+    if (map) sd_unmap_later((void *)map, mlen);
     free(blk);
     return NULL;
 }
@@ -522,6 +524,48 @@ static int stream_open(sd_stream *st, const char *path, int gz_threads)
 
 static void sd_drain_scans(void);
 
+/* Device batches outlive the file they were made for: a `-B` list opens and closes a stream per line, and making and freeing a
+ * batch (two device buffers, a stream, an event) per file cost more than scanning a small file.  A closed stream's batches wait
+ * here, per device, for the next stream; sd_run frees them at its end. */
+static struct { sk_batch *b[SD_MAX_DEV][4]; int n[SD_MAX_DEV]; } sd_bcache;
+static int sd_batch_get(int d, sk_batch **out)
+{
+    if (sd_bcache.n[d] > 0) { *out = sd_bcache.b[d][--sd_bcache.n[d]]; return SK_OK; }
+    return sk_batch_create(sd_dev.ctx[d], out);
+}
+static void sd_batch_put(int d, sk_batch *b)
+{
+    if (!b) return;
+    if (sd_bcache.n[d] < 4 && sk_batch_sync(b) == SK_OK) sd_bcache.b[d][sd_bcache.n[d]++] = b;   /* (sync: an upload in flight must land before the chunks go) */
+    else sk_batch_destroy(b);
+}
+static void sd_batch_cache_close(void)
+{
+    int d;
+    for (d = 0; d < SD_MAX_DEV; d++) while (sd_bcache.n[d] > 0) sk_batch_destroy(sd_bcache.b[d][--sd_bcache.n[d]]);
+}
+
+/* Unmapping a plain file that was parsed out of its mapping (10 GB: 0.2 s of page-table work) happens behind the next file's scan,
+ * on a thread of its own; one at a time, the last one joined by sd_run. */
+static struct { pthread_t th; int live; void *p; size_t n; } sd_unmapper;
+static pthread_mutex_t sd_unmapper_mu = PTHREAD_MUTEX_INITIALIZER;
+static void *sd_unmap_thread(void *arg) { (void)arg; munmap(sd_unmapper.p, sd_unmapper.n); return NULL; }
+static void sd_unmap_wait(void)
+{
+    pthread_mutex_lock(&sd_unmapper_mu);
+    if (sd_unmapper.live) { pthread_join(sd_unmapper.th, NULL); sd_unmapper.live = 0; }
+    pthread_mutex_unlock(&sd_unmapper_mu);
+}
+static void sd_unmap_later(void *p, size_t n)
+{
+    sd_unmap_wait();
+    pthread_mutex_lock(&sd_unmapper_mu);
+    sd_unmapper.p = p; sd_unmapper.n = n;
+    if (pthread_create(&sd_unmapper.th, NULL, sd_unmap_thread, NULL) == 0) sd_unmapper.live = 1;
+    else munmap(p, n);
+    pthread_mutex_unlock(&sd_unmapper_mu);
+}
+
 static void stream_close(sd_stream *st)
 {
     int i;
@@ -542,8 +586,8 @@ static void stream_close(sd_stream *st)
         pthread_cond_destroy(&st->pcv);
     }
     for (i = 0; i < SD_MAX_DEV; i++) {
-        sk_batch_destroy(st->bat[0][i]);                /* (waits for an upload in flight before the chunks go) */
-        sk_batch_destroy(st->bat[1][i]);
+        sd_batch_put(i, st->bat[0][i]);                 /* (waits for an upload in flight before the chunks go) */
+        sd_batch_put(i, st->bat[1][i]);
     }
     for (i = 0; i < st->qn; i++) chunk_free(st->q[i]);
     chunk_free(st->c);
@@ -553,7 +597,7 @@ static void stream_close(sd_stream *st)
 }
 
 /* SK_SD_TIMING=1: where the wall clock went, on stderr at exit */
-static double t_wait, t_tally, t_setup, t_fill, t_launch, t_post, t_close;
+static double t_wait, t_tally, t_setup, t_fill, t_launch, t_post, t_close, t_lens, t_replay, t_sopen, t_sclose, t_uclose, t_cfree;
 static double t_open_ctx, t_open_load, t_open_flags;     /* thread time summed over the strains' worker threads (SK_SD_TIMING) */
 static pthread_mutex_t t_open_mu = PTHREAD_MUTEX_INITIALIZER;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -798,7 +842,7 @@ static void sd_prefetch(sd_stream *st)
     if (!n || n == st->pre || !n->np) return;
     for (d = 0; d < sd_dev.n && ok; d++) {
         sk_batch **b = &st->bat[st->bcur ^ 1][d];
-        if (!*b && sk_batch_create(sd_dev.ctx[d], b) != SK_OK) { *b = NULL; ok = 0; break; }
+        if (!*b && sd_batch_get(d, b) != SK_OK) { *b = NULL; ok = 0; break; }
         ok = sk_batch_fill(*b, n->buf, n->blen, n->pstart, n->np) == SK_OK;
     }
     if (ok) st->pre = n;                                   /* (all devices or none: a chunk that is not everywhere goes up again) */
@@ -929,7 +973,7 @@ static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, 
                 st->eof = 1; st->end_kind = st->c->end_kind; st->end_len = st->c->end_len; chunk_free(st->c); st->c = NULL;
                 return st->split_failed ? SK_E_SPLIT : 0;
             }
-            chunk_free(st->c);
+            { const double t0 = now_s(); chunk_free(st->c); t_cfree += now_s() - t0; }
             st->c = NULL;
         }
         {
@@ -952,7 +996,7 @@ static int stream_fill(sd_stream *st, sd_prog *p, uint32_t ns, sk_batch *batch, 
             st->pre = NULL;
             st->ahead = NULL;
             for (i = 0; i < sd_dev.n; i++)
-                if (!st->bat[st->bcur][i] && (rc = sk_batch_create(sd_dev.ctx[i], &st->bat[st->bcur][i])) != SK_OK) { st->bat[st->bcur][i] = NULL; chunk_free(c); return rc; }
+                if (!st->bat[st->bcur][i] && (rc = sd_batch_get(i, &st->bat[st->bcur][i])) != SK_OK) { st->bat[st->bcur][i] = NULL; chunk_free(c); return rc; }
             rc = sd_tally_chunk(p, ns, st->bat[st->bcur], pool, c, uploaded, launched, st);
             if (rc == SK_OK) sd_launch_ahead(st, p, ns);
             t_tally += now_s() - t0;
@@ -1115,10 +1159,12 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
     sd_stream A, B;
     uint32_t s, j;
     int have_copy = 0, rc, got, status = 1;
+    double t_mark;
     unsigned long long evaluated = 0, reads = 0;
     FILE *err = p[0].err;
 
     memset(&B, 0, sizeof B);
+    t_mark = now_s();
     rc = stream_open(&A, f1, sd_gz_threads(mode == SD_PE ? 2 : 1));
     if (rc == SK_E_OPEN) { fprintf(err, "could not read file (read1) %s in quantify_hits_PE() (error: %s)\n", f1, strerror(errno)); return 1; }
     if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f1); return 1; }
@@ -1128,6 +1174,7 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
         if (rc) { fprintf(err, "strain_detect: cannot start the reader of %s\n", f2); stream_close(&A); return 1; }
     }
     for (s = 0; s < ns; s++) { p[s].h1 = p[s].i1 = p[s].h2 = p[s].i2 = 0; p[s].copy_n = 0; }
+    t_sopen += now_s() - t_mark;
     A.solo = mode != SD_PE;                              /* (two streams take turns at the tables: no scan ahead of the replay) */
 
     while ((got = stream_fill(&A, p, ns, batch, pool)) == 1) {
@@ -1151,6 +1198,7 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
             }
         }
         /* strain-independent part of the run (:444-450,489-512) */
+        t_mark = now_s();
         for (j = 0; j < n; j++) {
             const uint64_t la = ca->len[a0 + j * astep];
             if (la >= SK_K) { reads++; evaluated += la - (SK_K - 1); }
@@ -1161,7 +1209,9 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
             chunk_free(held);
             goto done;
         }
+        t_lens += now_s() - t_mark; t_mark = now_s();
         have_copy = pool_replay(pool, p, ns, f1, ca, a0, cb, b0, astep, n, have_copy);
+        t_replay += now_s() - t_mark;
         if (held) { chunk_free(held); if (cb) A.ci++; }  /* PEI across a chunk boundary: the mate was A's next record */
         else {
             A.ci += n * astep;
@@ -1191,8 +1241,10 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
     }
     status = 0;
 done:
+    t_mark = now_s();
     stream_close(&A);
     stream_close(&B);
+    t_sclose += now_s() - t_mark;
     return status;
 }
 
@@ -1562,8 +1614,10 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
         fclose(fp);
     } else bad = sd_quantify(p, ns, batch, &pool, b, b2, mode);
     pool_stop(&pool);
+    sd_unmap_wait();
+    sd_batch_cache_close();
     if (getenv("SK_LEAK_AT_EXIT") && strcmp(getenv("SK_LEAK_AT_EXIT"), "0")) return bad;     /* (the process is about to end: see sd_strain_close) */
-    sd_unions_close();
+    { const double t0 = now_s(); sd_unions_close(); t_uclose = now_s() - t0; }
     return bad;
 }
 
@@ -1776,8 +1830,8 @@ done:
                 t_open_ctx, t_open_load, t_open_flags);
     if (getenv("SK_SD_TIMING"))
         fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (upload %.2f, launch %.2f, "
-                     "collect+sort+spread per strain on the pool %.2f), total before close %.2f s\n", t_setup, t_wait, t_tally, t_fill,
-                t_launch, t_post, now_s() - t_begin);
+                     "collect+sort+spread per strain on the pool %.2f), read lengths %.2f s, replay on the pool %.2f s, chunks freed %.2f s, files opened %.2f s and closed %.2f s, union tables freed %.2f s, total before close %.2f s\n", t_setup, t_wait, t_tally, t_fill,
+                t_launch, t_post, t_lens, t_replay, t_cfree, t_sopen, t_sclose, t_uclose, now_s() - t_begin);
     sd_pin_close();
     {   /* closing a strain = finishing its gz output, freeing its device context and tables: strain by strain on threads */
         sd_pool cp;

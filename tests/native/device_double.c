@@ -122,6 +122,7 @@ static int64_t find(const sk_ctx *c, uint64_t k)
 
 int sk_batch_create(sk_ctx *c, sk_batch **out) { (void)c; *out = calloc(1, sizeof **out); return *out ? SK_OK : SK_E_NOMEM; }
 void sk_batch_destroy(sk_batch *b) { if (b) { free(b->bytes); free(b->start); free(b); } }
+int sk_batch_sync(sk_batch *b) { return b ? SK_OK : SK_E_ARG; }
 int sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec)
 {
     free(b->bytes); free(b->start);

@@ -100,7 +100,12 @@ def main():
             sizes = two_md5()
             report["variants"] = {}
             for name, env in (("no_scan_ahead", {"SK_SD_NO_AHEAD": "1"}), ("chunks_of_128_mib", {"SK_SD_CHUNK_BYTES": str(128 << 20)}),
+                              ("parse_threads_2", {"SK_PARSE_THREADS": "2"}), ("parse_threads_6", {"SK_PARSE_THREADS": "6"}),
+                              ("parse_threads_8", {"SK_PARSE_THREADS": "8"}),
+                              ("parse_threads_8_chunks_of_128_mib", {"SK_PARSE_THREADS": "8", "SK_SD_CHUNK_BYTES": str(128 << 20)}),
                               ("two_logical_devices_one_card", {"SK_DEVICES": "0,0", "SK_SD_GROUP": "16"})):
+                if os.environ.get("VARIANTS") not in ("1", "all") and name not in os.environ["VARIANTS"].split(","):
+                    continue
                 p2, wall2 = run(exe, ["-S", paths["strains"], "-B", paths["B"]], **env)
                 timing2, _ = split_timing(p2.stderr)
                 same = p2.returncode == 0 and sizes == two_md5()
