@@ -110,7 +110,7 @@ def test_reader_matches_oracle_records(golden):
         assert bases == len(data) - nrec, path
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(60))
 def test_reader_grammar_soup_vs_oracle(seed, tmp_path):
     """files thrown together from header, sequence, '+', quality and blank lines in every order -- equal and unequal
     quality lengths, wrapped sequences, CR line ends, '@' and '>' opening quality lines, a missing last newline,
@@ -129,6 +129,8 @@ def test_reader_grammar_soup_vs_oracle(seed, tmp_path):
         if kind < 0.55:                                    # a well-formed four-line record (now and then not quite)
             q = bytes(rng.choice(b"FFFF:,#@>+I") for _ in range(n if rng.random() < 0.9 else rng.choice([0, 1, max(0, n - 1), n + 1])))
             out += [b"@r%d some text" % len(out), seq, b"+" + (b"r" if rng.random() < 0.2 else b""), q]
+        elif kind < 0.62:                                  # FASTA, the sequence on one line, '>' or '@' header
+            out += [(b">" if rng.random() < 0.8 else b"@") + b"o%d len=%d" % (len(out), n), seq]
         elif kind < 0.7:                                   # FASTA, wrapped
             out += [b">c%d" % len(out)] + [seq[i:i + 60] for i in range(0, n, 60)]
         elif kind < 0.8:                                   # FASTQ with wrapped sequence and quality
