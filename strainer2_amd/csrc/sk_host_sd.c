@@ -169,6 +169,9 @@ static void sd_pin_close(void)
 }
 
 static void sd_unmap_later(void *p, size_t n);
+static double now_s(void);
+static double t_pw_seg, t_pw_parse, t_pw_turn, t_pw_push;   /* SK_SD_TIMING: the parser threads' time, summed over them */
+static pthread_mutex_t t_pw_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static void chunk_free(sd_chunk *c)
 {
@@ -267,6 +270,7 @@ static void *sd_parse_worker(void *arg)
         sd_builder b;
         parser ps;
         int ok = 1, i;
+        double w0 = now_s(), w1, w2, w3;
         pthread_mutex_lock(&st->pmu);
         while (st->segn == 0 && !st->seg_done) pthread_cond_wait(&st->pcv, &st->pmu);
         if (st->segn == 0) { pthread_mutex_unlock(&st->pmu); return NULL; }
@@ -276,6 +280,7 @@ static void *sd_parse_worker(void *arg)
         pthread_cond_broadcast(&st->pcv);
         pthread_mutex_unlock(&st->pmu);
 
+        w1 = now_s();
         memset(&b, 0, sizeof b);
         b.st = st;
         parser_init(&ps, sd_on_record, &b);
@@ -286,9 +291,11 @@ static void *sd_parse_worker(void *arg)
         if (b.cur && (sg->is_last || b.cur->nrec)) builder_finish_chunk(&b);
         else if (b.cur) { chunk_free(b.cur); b.cur = NULL; }
 
+        w2 = now_s();
         pthread_mutex_lock(&st->pmu);                      /* in segment order */
         while (st->next_push != sg->seq && !st->cancel) pthread_cond_wait(&st->pcv, &st->pmu);
         pthread_mutex_unlock(&st->pmu);
+        w3 = now_s();
         if (!ok) st->split_failed = 1;
         {
             size_t end_len = ps.end_len;
@@ -313,6 +320,9 @@ static void *sd_parse_worker(void *arg)
             pthread_cond_broadcast(&st->pcv);
             pthread_mutex_unlock(&st->pmu);
         }
+        pthread_mutex_lock(&t_pw_mu);
+        t_pw_seg += w1 - w0; t_pw_parse += w2 - w1; t_pw_turn += w3 - w2; t_pw_push += now_s() - w3;
+        pthread_mutex_unlock(&t_pw_mu);
         free(b.done);
         parser_free(&ps);
         if (!sg->borrowed) free(sg->buf);
@@ -1832,6 +1842,9 @@ done:
         fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (upload %.2f, launch %.2f, "
                      "collect+sort+spread per strain on the pool %.2f), read lengths %.2f s, replay on the pool %.2f s, chunks freed %.2f s, files opened %.2f s and closed %.2f s, union tables freed %.2f s, total before close %.2f s\n", t_setup, t_wait, t_tally, t_fill,
                 t_launch, t_post, t_lens, t_replay, t_cfree, t_sopen, t_sclose, t_uclose, now_s() - t_begin);
+    if (getenv("SK_SD_TIMING") && t_pw_parse > 0)
+        fprintf(err, "strain_detect timing: parser threads, summed: parsing %.2f s, waiting for a segment %.2f s, for their turn to hand chunks on %.2f s, for room in the queue %.2f s\n",
+                t_pw_parse, t_pw_seg, t_pw_turn, t_pw_push);
     sd_pin_close();
     {   /* closing a strain = finishing its gz output, freeing its device context and tables: strain by strain on threads */
         sd_pool cp;
