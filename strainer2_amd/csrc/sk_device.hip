@@ -381,6 +381,10 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
 #ifndef SK_LAZY_MASKS
 #define SK_LAZY_MASKS 0                      // measured (profiles/r03_kernel_experiments.txt): a third fewer vector instructions and NO gain
 #endif
+#ifndef SK_RUN_PASS
+#define SK_RUN_PASS 0                      // phase 2: three level-1 survivors in a row go to stage 2 unquestioned.  Measured (profiles/r03_kernel_experiments.txt,
+                                           // item 10): -5..8 % when every read is a strain read, +6.5 % with none, +1.3 % at cfg 2.  Off.
+#endif
 #ifndef SK_L2_K
 #define SK_L2_K 2                          // ... chunks per round (4: -3 %, 2: -4.7 % with no strain reads)
 #endif
@@ -752,6 +756,19 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         // round takes the first chunk of every run of survivors, at most SK_L2_K of them, all their lookups in flight together;
         // the rest of a run follows its first chunk's verdict, as in the plain loop.)
         uint32_t m2 = 0, pend = m;
+#if SK_RUN_PASS
+        {   // Three level-1 survivors in a row (five in a union table, where one chunk in seven passes level 1 by chance) are a read of the
+            // strain: the run goes to stage 2 unquestioned, without the round trips to the L2 and to HBM that the questions cost a
+            // wave whose strain read waits for them.  Pruning less is always exact.  (Own chunks only.)
+            constexpr uint32_t RUN = UNION ? 5u : 3u;
+            uint32_t sr = m, members = 0u;
+#pragma unroll
+            for (uint32_t k = 1; k < RUN; k++) sr &= m >> k;
+#pragma unroll
+            for (uint32_t k = 0; k < RUN; k++) members |= sr << k;
+            m2 = members & m; pend = m & ~m2;
+        }
+#endif
         while (pend) {
             uint32_t ap = pend & (m2 << 1);                       // right behind a chunk that passed: passes, and so on down the run
             while (ap) { m2 |= ap; pend &= ~ap; ap = pend & (ap << 1); }
