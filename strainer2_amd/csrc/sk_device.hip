@@ -382,8 +382,10 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
 #define SK_LAZY_MASKS 0                      // measured (profiles/r03_kernel_experiments.txt): a third fewer vector instructions and NO gain
 #endif
 #ifndef SK_RUN_PASS
-#define SK_RUN_PASS 0                      // phase 2: three level-1 survivors in a row go to stage 2 unquestioned.  Measured (profiles/r03_kernel_experiments.txt,
-                                           // item 10): -5..8 % when every read is a strain read, +6.5 % with none, +1.3 % at cfg 2.  Off.
+#define SK_RUN_PASS 5                      // phase 2: this many level-1 survivors in a row (two more in a union table) go to stage 2 unquestioned;
+                                           // 0 = never.  Measured (profiles/r03_kernel_experiments.txt, item 10): 3 costs 6.5 % with no strain reads (runs of three
+                                           // false positives are frequent enough to send a wave in six down stage 2's slow path), 5 costs nothing there
+                                           // and saves 3 % when every read is a strain read, 0.3 % at cfg 2
 #endif
 #ifndef SK_L2_K
 #define SK_L2_K 2                          // ... chunks per round (4: -3 %, 2: -4.7 % with no strain reads)
@@ -737,6 +739,25 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     for (int i = 0; i < SK_SPAN_CH; i++)
         m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) &&
                         ((ABLATE != 4 && ABLATE != 6 && ABLATE != 10) || g[i] == 0x9E3779B9u)) << i;     // (ablations: loads kept alive, verdicts dropped)
+#if SK_RUN_PASS
+    // SK_RUN_PASS level-1 survivors in a row (two more in a union table, where one chunk in seven passes level 1 by chance) are a read of
+    // the strain: the run goes to stage 2 unquestioned, without the round trips to the L2 and to HBM that the questions below cost a
+    // wave whose strain read waits for them.  Pruning less is always exact.  The neighbouring lanes' verdicts carry a run over the
+    // edge of a thread's eight chunks (a 150-base read is nine chunks: with own chunks only, one of its two threads still asks).
+    uint32_t runpass = 0u;
+    if (!CAND && ABLATE != 5) {
+        constexpr uint32_t RUN = UNION ? SK_RUN_PASS + 2u : SK_RUN_PASS, MARGIN = RUN - 1u;
+        static_assert(MARGIN <= 8u, "a run longer than nine chunks needs more than the two neighbouring lanes");
+        const uint32_t mu = (uint32_t)__shfl_up((int)m, 1), md = (uint32_t)__shfl_down((int)m, 1);
+        const uint32_t wide = (lane > 0u ? mu >> (8u - MARGIN) : 0u) | (m << MARGIN) | (lane < 63u ? (md & ((1u << MARGIN) - 1u)) << (8u + MARGIN) : 0u);
+        uint32_t sr = wide, members = 0u;                                                                       // chunks -MARGIN .. 7 + MARGIN of this thread
+#pragma unroll
+        for (uint32_t k = 1; k < RUN; k++) sr &= wide >> k;                                                     // a run of RUN starts here
+#pragma unroll
+        for (uint32_t k = 0; k < RUN; k++) members |= sr << k;
+        runpass = (members >> MARGIN) & m;
+    }
+#endif
     if (m && ABLATE != 5 && !CAND) {                              // (ABLATE 5, exact: no level 2, stage 2 sorts it out)                                                      // level 2 (rare for unrelated reads)
         // A chunk right after one that passed level 2 is taken on its level-1 pass alone: inside a strain read
         // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
@@ -757,17 +778,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         // the rest of a run follows its first chunk's verdict, as in the plain loop.)
         uint32_t m2 = 0, pend = m;
 #if SK_RUN_PASS
-        {   // Three level-1 survivors in a row (five in a union table, where one chunk in seven passes level 1 by chance) are a read of the
-            // strain: the run goes to stage 2 unquestioned, without the round trips to the L2 and to HBM that the questions cost a
-            // wave whose strain read waits for them.  Pruning less is always exact.  (Own chunks only.)
-            constexpr uint32_t RUN = UNION ? 5u : 3u;
-            uint32_t sr = m, members = 0u;
-#pragma unroll
-            for (uint32_t k = 1; k < RUN; k++) sr &= m >> k;
-#pragma unroll
-            for (uint32_t k = 0; k < RUN; k++) members |= sr << k;
-            m2 = members & m; pend = m & ~m2;
-        }
+        m2 = runpass; pend = m & ~runpass;
 #endif
         while (pend) {
             uint32_t ap = pend & (m2 << 1);                       // right behind a chunk that passed: passes, and so on down the run

@@ -47,6 +47,12 @@ VARIANTS = {
     "single_h2":    (0.02, {"pipeline": 1}, False),
     "single_h30":   (0.3,  {"pipeline": 1}, False),
     "single_h100":  (1.0,  {"pipeline": 1}, False),
+    "exact_h100":   (1.0,  {}, False, 0.0),
+    "exact_h30":    (0.3,  {}, False, 0.0),
+    "exact_noprobe_h30": (0.3, {"ablate": 2}, False, 0.0),
+    "noatom_h30":   (0.3,  {"ablate": 3}, False),
+    "noprobe_h30":  (0.3,  {"ablate": 2}, False),
+    "notext_h30":   (0.3,  {"text_stage": 0}, False),
     "div1_h100":    (1.0,  {}, False, 0.01),
     "div3_h100":    (1.0,  {}, False, 0.03),
     "base_h30":     (0.3,  {}, False),
