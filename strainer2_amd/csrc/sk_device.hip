@@ -381,6 +381,10 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
 #ifndef SK_LAZY_MASKS
 #define SK_LAZY_MASKS 0                      // measured (profiles/r03_kernel_experiments.txt): a third fewer vector instructions and NO gain
 #endif
+#ifndef SK_SECOND_SEED
+#define SK_SECOND_SEED 0                    // stage 2: a stretch without a seed tries one more window before its windows go one by one.  Measured (experiments
+                                            // file, item 13): 1 % / 3 % divergence -5 % / -11 %, cfg 2 +1.4 %.  Off: the metric's workload decides.
+#endif
 #ifndef SK_RUN_PASS
 #define SK_RUN_PASS 5                      // phase 2: this many level-1 survivors in a row (two more in a union table) go to stage 2 unquestioned;
                                            // 0 = never.  Measured (profiles/r03_kernel_experiments.txt, item 10): 3 costs 6.5 % with no strain reads (runs of three
@@ -975,33 +979,46 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             const uint32_t hi_lane = above ? (uint32_t)__builtin_ctzll(above) - 1u : 63u;
             const uint32_t kk = lane - lo_lane;
             // ---- seed: one window of the chunk (its last live one: it reaches furthest into the read) in the table
-            const bool anchor = act & (live != 0u) & ((kk & (SK_ANCHOR_CH - 1u)) == 0u);
+            bool anchor = act & (live != 0u) & ((kk & (SK_ANCHOR_CH - 1u)) == 0u), use_first = false;
             uint32_t a_dir = 0u, a_diag = 0u;
             bool seed = false;
-            if (anchor) {
-                const uint32_t j = 31u - (uint32_t)__clz((int)live);
-                const uint32_t e = ch * 16u + 15u + j;                         // tile-relative END of that window
-                uint64_t fwd, rc;
-                sk_window_keys(rec, e, fwd, rc);
-                const uint64_t cn = fwd > rc ? fwd : rc;
-                uint32_t sl = sk_slot0(sk_khash(cn), table.mask);
-                for (;;) {
-                    const sk_u4 en = table.slots[sl];
-                    const uint64_t key = sk_slot_key(en);
-                    if (key == cn) {
-                        const uint32_t tp = en.w >> 1;
-                        if (tp != 0x7FFFFFFFu) {
-                            seed = true;
-                            a_dir = (uint32_t)(fwd > rc) ^ (en.w & 1u);        // 0: the read runs along the strain, 1: against it
-                            // text position of tile-relative stream offset x: along D + x, against D - x
-                            const uint32_t xs = e - 30u;                       // the window's first base (wraps below 0: fine, mod 2^32)
-                            a_diag = a_dir ? tp + 30u + xs : tp - xs;
+#pragma nounroll
+            for (int pass = 0; pass < 2; pass++) {
+                if (anchor) {
+                    const uint32_t j = use_first ? (uint32_t)__builtin_ctz(live) : 31u - (uint32_t)__clz((int)live);
+                    const uint32_t e = ch * 16u + 15u + j;                         // tile-relative END of that window
+                    uint64_t fwd, rc;
+                    sk_window_keys(rec, e, fwd, rc);
+                    const uint64_t cn = fwd > rc ? fwd : rc;
+                    uint32_t sl = sk_slot0(sk_khash(cn), table.mask);
+                    for (;;) {
+                        const sk_u4 en = table.slots[sl];
+                        const uint64_t key = sk_slot_key(en);
+                        if (key == cn) {
+                            const uint32_t tp = en.w >> 1;
+                            if (tp != 0x7FFFFFFFu) {
+                                seed = true;
+                                a_dir = (uint32_t)(fwd > rc) ^ (en.w & 1u);        // 0: the read runs along the strain, 1: against it
+                                // text position of tile-relative stream offset x: along D + x, against D - x
+                                const uint32_t xs = e - 30u;                       // the window's first base (wraps below 0: fine, mod 2^32)
+                                a_diag = a_dir ? tp + 30u + xs : tp - xs;
+                            }
+                            break;
                         }
-                        break;
+                        if (key == SK_EMPTY64) break;
+                        sl = (sl + 1u) & table.mask;
                     }
-                    if (key == SK_EMPTY64) break;
-                    sl = (sl + 1u) & table.mask;
                 }
+                if (pass == 1 || !SK_SECOND_SEED || TALLY) break;          // (the TALLY kernels are short of scalar registers: one try there)
+                // A stretch none of whose seed windows is a k-mer of the strain (a differing base in it: 14 % of the windows at 0.5 %
+                // substitutions) used to send all its windows down the one-by-one path.  One more try first, with the window furthest from
+                // the first seed: the FIRST live window of the stretch's LAST chunk.  (wave-uniform: only when some stretch needs it)
+                const unsigned long long sm1 = __ballot(seed);
+                const unsigned long long span1 = (hi_lane == 63u ? ~0ull : ((2ull << hi_lane) - 1ull)) & ~((1ull << lo_lane) - 1ull);
+                const bool need = act & (live != 0u) & ((sm1 & span1) == 0ull);
+                if (!__ballot(need)) break;
+                anchor = need & (lane == hi_lane);
+                use_first = true;
             }
             // ---- every chunk takes the nearest seed of its stretch
             const unsigned long long sm = __ballot(seed);
