@@ -752,6 +752,7 @@ typedef struct {
     uint32_t        col;
     int             pipe;              /* fewer files than cores: each file's inflate gets a helper thread (> 1: that many) */
     int             gpu_inflate;       /* SK_GPU_INFLATE=1: .gz items go through the device-side decoder first (experimental) */
+    int             dev_workers, worker_ids;   /* ... on this many EXTRA threads (SK_GPU_INFLATE_WORKERS, default 4), which mostly wait for the device */
     pthread_mutex_t submit_mu;         /* sk_scan_stream is one-caller-at-a-time per context */
     pthread_mutex_t queue_mu;
     scan_item      *item;              /* work list of this call (what this rank scans), in list order */
@@ -784,6 +785,7 @@ typedef struct {
     uint64_t   ticket[2];
     int        used[2], cur;
     sk_inflater *inf;                  /* SK_GPU_INFLATE=1: this worker's device-side gzip decoder ... */
+    int          dev_ok;               /* ... which only the pool's first dev_workers threads use (the others inflate on the host) */
     uint8_t   *text; uint64_t text_cap;/* ... and the page-locked buffer its text lands in */
 } scan_worker;
 
@@ -1048,7 +1050,7 @@ static int64_t parse_gz_on_device(scan_worker *w, const scan_item *it, uint64_t 
     uint64_t want, len = 0;
     uint32_t crc = 0;
     int rc;
-    if (!w->pool->gpu_inflate) return -100;
+    if (!w->pool->gpu_inflate || !w->dev_ok) return -100;
     fd = open(it->path, O_RDONLY);
     if (fd < 0) return -100;                              /* (the ordinary path reports it) */
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32) { close(fd); return -100; }
@@ -1137,6 +1139,9 @@ static void *pool_worker(void *arg)
     scan_pool *p = (scan_pool *)arg;
     scan_worker w;
     int wrc = worker_init(&w, p);
+    pthread_mutex_lock(&p->queue_mu);
+    w.dev_ok = p->worker_ids++ < p->dev_workers;
+    pthread_mutex_unlock(&p->queue_mu);
     for (;;) {
         uint32_t i;
         uint64_t bases = 0;
@@ -1381,6 +1386,12 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
         if (pool.pipe > 16) pool.pipe = 16;
 #ifdef SK_EXPERIMENTS
         pool.gpu_inflate = getenv("SK_GPU_INFLATE") ? atoi(getenv("SK_GPU_INFLATE")) : 0;
+        if (pool.gpu_inflate && nthreads > 1) {               /* the device's decoder is fed by threads of its own, beside the host's decode threads */
+            pool.dev_workers = getenv("SK_GPU_INFLATE_WORKERS") ? atoi(getenv("SK_GPU_INFLATE_WORKERS")) : 4;
+            if (pool.dev_workers < 0) pool.dev_workers = 0;
+            if (pool.dev_workers > 16) pool.dev_workers = 16;
+            nthreads += pool.dev_workers;
+        }
 #endif
     }
     if (plan_only) {

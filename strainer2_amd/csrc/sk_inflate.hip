@@ -461,6 +461,7 @@ __global__ void resolve_translate(const chain_seg *__restrict__ ch, uint32_t nch
 struct sk_inflater {
     int device;
     hipStream_t stream;
+    hipEvent_t done;                     // blocking waits (hipEventBlockingSync): a thread that feeds the device sleeps meanwhile
     void *buf[10]; size_t cap[10];       // grow-only device scratch: 0 comp, 1 tabs, 2 sym, 3 out, 4 cand, 5 ncand, 6 chain, 7 gmap, 8 gwin, 9 text
     char err[256];
 };
@@ -492,6 +493,7 @@ extern "C" int sk_inflater_create(int device, sk_inflater **out)
     memset(f, 0, sizeof *f);
     f->device = device;
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return SK_E_HIP; }
+    if (hipEventCreateWithFlags(&f->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(f->stream); delete f; return SK_E_HIP; }
     static bool attrs = false;
     if (!attrs) {
         (void)hipFuncSetAttribute((const void *)tails_compose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WINDOW * 4));
@@ -509,6 +511,7 @@ extern "C" void sk_inflater_destroy(sk_inflater *f)
     hipSetDevice(f->device);
     hipStreamSynchronize(f->stream);
     for (int i = 0; i < 10; i++) hipFree(f->buf[i]);
+    hipEventDestroy(f->done);
     hipStreamDestroy(f->stream);
     delete f;
 }
@@ -560,7 +563,8 @@ extern "C" int sk_inflate_gz(sk_inflater *f, const uint8_t *m, uint64_t ncomp, u
     hipLaunchKernelGGL(extend, dim3((nseg + 63) / 64), dim3(64), 0, f->stream, (const uint32_t *)d_comp, (uint64_t)nwords, nseg, d_tabs, d_sym, cap, d_out);
     std::vector<seg_out> out(nseg);
     SKI_HIP(f, hipMemcpyAsync(out.data(), d_out, nseg * sizeof(seg_out), hipMemcpyDeviceToHost, f->stream));
-    SKI_HIP(f, hipStreamSynchronize(f->stream));
+    SKI_HIP(f, hipEventRecord(f->done, f->stream));
+    SKI_HIP(f, hipEventSynchronize(f->done));               // (a blocking wait: the feeding thread sleeps, the host's decode threads keep their CPUs)
     SKI_HIP(f, hipGetLastError());
     // the chain
     std::vector<chain_seg> ch;
@@ -583,7 +587,8 @@ extern "C" int sk_inflate_gz(sk_inflater *f, const uint8_t *m, uint64_t ncomp, u
     hipLaunchKernelGGL(tails_chain, dim3(1), dim3(1024), WINDOW * 2, f->stream, (const uint16_t *)f->buf[7], ngroups, (uint8_t *)f->buf[8]);
     hipLaunchKernelGGL(resolve_translate, dim3(ngroups), dim3(1024), WINDOW * 2, f->stream, (const chain_seg *)f->buf[6], nch, (const uint16_t *)d_sym, cap, (const uint8_t *)f->buf[8], (uint8_t *)f->buf[9]);
     SKI_HIP(f, hipMemcpyAsync(host_text, f->buf[9], off, hipMemcpyDeviceToHost, f->stream));
-    SKI_HIP(f, hipStreamSynchronize(f->stream));
+    SKI_HIP(f, hipEventRecord(f->done, f->stream));
+    SKI_HIP(f, hipEventSynchronize(f->done));               // (a blocking wait: the feeding thread sleeps, the host's decode threads keep their CPUs)
     SKI_HIP(f, hipGetLastError());
     *text_len = off;
     return SK_OK;
