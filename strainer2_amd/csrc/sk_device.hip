@@ -381,6 +381,23 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
 #ifndef SK_LAZY_MASKS
 #define SK_LAZY_MASKS 0                      // measured (profiles/r03_kernel_experiments.txt): a third fewer vector instructions and NO gain
 #endif
+#ifndef SK_PRIO_BASE
+#define SK_PRIO_BASE 0                       // ... the decode section's priority
+#endif
+#ifndef SK_PRIO_P2
+#define SK_PRIO_P2 SK_PRIO_BASE              // ... phase 2's (records read, hashes, the eight lookups issued)
+#endif
+#ifndef SK_PRIO_TAIL
+#define SK_PRIO_TAIL SK_PRIO_P2              // ... everything behind that
+#endif
+#ifndef SK_PRIO_LVL
+#define SK_PRIO_LVL 3
+#endif
+#ifndef SK_PRIO
+#define SK_PRIO 1                            // wave priority (s_setprio): 1 = raised to SK_PRIO_LVL while a wave issues phase 1's stream loads, back to SK_PRIO_BASE
+                                             // for the decode; 4 = kept up until the barrier.  A wave that starts a tile gets its nine loads out at once instead of
+                                             // taking turns with the waves that decode: 0.724 -> 0.645 ms at cfg 2 (profiles/r03_kernel_experiments.txt, item 14)
+#endif
 #ifndef SK_SECOND_SEED
 #define SK_SECOND_SEED 0                    // stage 2: a stretch without a seed tries one more window before its windows go one by one.  Measured (experiments
                                             // file, item 13): 1 % / 3 % divergence -5 % / -11 %, cfg 2 +1.4 %.  Off: the metric's workload decides.
@@ -598,6 +615,9 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         constexpr int NIT = (SK_NCHUNK_GRID + SK_THREADS - 1) / SK_THREADS;
         sk_u4 vv[NIT];
         const bool inside = tile0 >= SK_SPAN && tile0 + SK_TILE + 16u <= nbytes;      // (workgroup-uniform)
+#if SK_PRIO & 1
+        __builtin_amdgcn_s_setprio(SK_PRIO_LVL);
+#endif
         if (inside) {
     #pragma unroll
             for (int it = 0; it < NIT; it++) {
@@ -620,6 +640,9 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                 vv[it] = (sk_u4){w[0], w[1], w[2], w[3]};
             }
         }
+#if (SK_PRIO & 5) == 1
+        __builtin_amdgcn_s_setprio(SK_PRIO_BASE);
+#endif
     #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const uint32_t c = tid + (uint32_t)it * SK_THREADS;
@@ -709,10 +732,16 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
         }
     }
+#if (SK_PRIO & 5) == 5
+    __builtin_amdgcn_s_setprio(SK_PRIO_BASE);
+#endif
     __syncthreads();
     if (ABLATE == 8) { if (rec[tid] == 0x12345u && candm == 0x77u) flags[3] = 1u; return; }               // timing: phase 1 alone
 
     // ================= phase 2: one filter lookup per chunk ======================================
+#if SK_PRIO_P2 != SK_PRIO_BASE
+    __builtin_amdgcn_s_setprio(SK_PRIO_P2);
+#endif
     uint16_t *const wq = wq_all[tid >> 6];
     uint32_t qw = 0;                                              // queue fill (wave-uniform)
     const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;            // this thread's 8 chunks
@@ -738,6 +767,9 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         else if (ABLATE == 10) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)]; }         // timing: the real level-1 lookups, verdicts dropped (no level 2, no stage 2)
         else if (ABLATE != 1 && ((okm >> i) & 1u)) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)];
     }
+#if SK_PRIO_TAIL != SK_PRIO_P2
+    __builtin_amdgcn_s_setprio(SK_PRIO_TAIL);
+#endif
     uint32_t m = 0;                                               // chunks that may be in the strain
 #pragma unroll
     for (int i = 0; i < SK_SPAN_CH; i++)
