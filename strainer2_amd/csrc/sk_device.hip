@@ -332,6 +332,23 @@ __device__ __forceinline__ void sk_decode4(uint32_t w, uint32_t &codes8, uint32_
     inv4 = ((sk_nz_msb(d) & 0x80808080u) * 0x00204081u) >> 28;             // bit i <=> byte i is non-zero (the four top bits gathered)
 }
 
+// The same, and `odd` |= a word that is non-zero iff one of the four bytes is neither A/C/G/T (any case) nor N/n nor '\n' -- a byte only
+// the exact byte-string kernel can judge.  One more permute with the same selector: '\n' (low bits 2) and N (6) get their own
+// expected byte.  For that the case fold must spare what is no letter ('*' is 0x2A = '\n' + bit 5): bit 5 is cleared only where bit 6
+// is set -- which changes nothing for A/C/G/T, whose expected bytes all have bit 6.  (Round 3: the kernel is bound by vector
+// instructions since the wave-priority change, and the loop this replaces -- sk_chunk_has_odd_byte, 21 instructions per invalid byte of
+// the busiest lane, entered for nearly every chunk because some lane of the wave always holds a '\n' -- was a seventh of them.)
+__device__ __forceinline__ void sk_decode4o(uint32_t w, uint32_t &codes8, uint32_t &inv4, uint32_t &odd)
+{
+    const uint32_t u   = w & ~((w >> 1) & 0x20202020u);                    // letters upper-cased, everything else as it is
+    const uint32_t sel = w & 0x07070707u;
+    const uint32_t cd  = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, sel);   // A0 C1 G2 T3
+    codes8 = (cd * 0x40100401u) >> 24;                                     // gather 4 x 2 bits
+    const uint32_t d   = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, sel) ^ u;   // 0 <=> the byte is that letter
+    inv4 = ((sk_nz_msb(d) & 0x80808080u) * 0x00204081u) >> 28;             // bit i <=> byte i is non-zero (the four top bits gathered)
+    odd |= __builtin_amdgcn_perm(0x474EFF54u, 0x430A41FFu, sel) ^ u;       // 0 <=> every byte is one of A C G T a c g t N n '\n'
+}
+
 // Among the (few) non-ACGT bytes of a 16-byte chunk, is there one that is neither N/n nor '\n'?
 // Such a byte can only be judged by the exact byte-string kernel.  inv16 = the chunk's mask.
 __device__ __forceinline__ uint32_t sk_chunk_has_odd_byte(const sk_u4 v, uint32_t inv16)
@@ -659,13 +676,13 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                     inv16 = (d0 | d1 | d2 | d3) ? 0xFFFFu : 0u;                  // 0xFFFF: "not clean; the exact mask on demand" (sk_exact_inv16)
                     odd = (x0 | x1 | x2 | x3) != 0u;
                 } else {
-                    uint32_t i0, i1, i2, i3;
-                    sk_decode4(v.x, c0, i0);
-                    sk_decode4(v.y, c1, i1);
-                    sk_decode4(v.z, c2, i2);
-                    sk_decode4(v.w, c3, i3);
+                    uint32_t i0, i1, i2, i3, oddw = 0u;
+                    sk_decode4o(v.x, c0, i0, oddw);
+                    sk_decode4o(v.y, c1, i1, oddw);
+                    sk_decode4o(v.z, c2, i2, oddw);
+                    sk_decode4o(v.w, c3, i3, oddw);
                     inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
-                    odd = sk_chunk_has_odd_byte(v, inv16) != 0u;
+                    odd = oddw != 0u;
                 }
                 // bytes of the chunk after the tile belong to the next tile, which reports them itself
                 if (c < SK_NCHUNK && odd) {
