@@ -425,6 +425,9 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
                                            // false positives are frequent enough to send a wave in six down stage 2's slow path), 5 costs nothing there
                                            // and saves 3 % when every read is a strain read, 0.3 % at cfg 2
 #endif
+#ifndef SK_L2_LANES
+#define SK_L2_LANES 1                      // phase 2's second and third questions: the chunks to be asked compacted over the wave, one per lane (0: every thread its own)
+#endif
 #ifndef SK_L2_K
 #define SK_L2_K 2                          // ... chunks per round (4: -3 %, 2: -4.7 % with no strain reads)
 #endif
@@ -602,7 +605,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                   sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags, const uint8_t *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) uint32_t rec[(SK_NREC + 1) * SK_REC_DW];
-    __shared__ uint16_t wq_all[SK_WAVES][128 + 16];              // below 128 before a push of at most 16
+    __shared__ __attribute__((aligned(16))) uint16_t wq_all[SK_WAVES][128 + 16];   // below 128 before a push of at most 16 (phase 2 borrows its first 64 bytes)
     __shared__ uint16_t cq_all[SK_WAVES][64 * SK_SPAN_CH];       // the wave's surviving chunks
     // COUNT mode: difference-array indices this workgroup has already touched once in this tile; further updates
     // of them are added up here and flushed with one atomic each at the end.  Reads that repeat (duplicates)
@@ -760,6 +763,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     __builtin_amdgcn_s_setprio(SK_PRIO_P2);
 #endif
     uint16_t *const wq = wq_all[tid >> 6];
+    uint16_t *const cq = cq_all[tid >> 6];                        // the wave's list of chunks: phase 2's questions first, stage 2's survivors then
     uint32_t qw = 0;                                              // queue fill (wave-uniform)
     const uint32_t *my = rec + (tid + 1u) * SK_REC_DW;            // this thread's 8 chunks
 
@@ -811,6 +815,77 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         runpass = (members >> MARGIN) & m;
     }
 #endif
+#if SK_L2_LANES
+    // Level 2, a CHUNK PER LANE (round 3, when the kernel had become bound by vector instructions).  The false positives of level 1 are
+    // 7 % of the chunks: nearly every thread-wise loop over "my survivors" runs in every wave (some lane always has one), one or two
+    // rounds of ~220 instructions for two or three busy lanes.  Here the chunks to be asked (level-1 survivors outside the runs that pass
+    // unquestioned) are compacted over the wave -- 36 of 512 on average: ONE round with half the lanes busy -- each lane asks about one
+    // chunk (the two half-shifted 16-mers, then the 24-mer of a side that passed), and the verdicts go back to the owners as bits of a
+    // word in LDS.  Every asked chunk stands for itself (no "right behind a chunk that passed"): strain reads are the runs.
+    if (ABLATE != 5 && !CAND) {
+        uint32_t ask = m;
+#if SK_RUN_PASS
+        ask &= ~runpass;
+#endif
+        const unsigned long long anyask = __ballot(ask != 0u);
+        uint32_t m2 = m & ~ask;
+        if (anyask) {                                             // (wave-uniform)
+            uint32_t *const pb = (uint32_t *)wq;                  // 64 bytes: one verdict byte per lane of the wave
+            if (lane < 16u) pb[lane] = 0u;
+            uint32_t incl = (uint32_t)__popc(ask);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            const uint32_t nask = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            {
+                uint32_t at = incl - (uint32_t)__popc(ask), a = ask;
+                while (a) { const uint32_t i = (uint32_t)__builtin_ctz(a); a &= a - 1u; cq[at++] = (uint16_t)(tid * SK_SPAN_CH + i); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t b0 = 0; b0 < nask; b0 += 64u) {         // (wave-uniform)
+                if (b0 + lane < nask) {
+                    const uint32_t ct = cq[b0 + lane];                                       // chunk of the tile: owner thread * 8 + i
+                    const uint32_t cid = ct + SK_SPAN_CH;                                    // record 0 = the 8 chunks before the tile
+                    const uint32_t cw  = rec[(cid >> 3) * SK_REC_DW + (cid & 7u)];
+                    const uint32_t cwp = rec[((cid - 1u) >> 3) * SK_REC_DW + ((cid - 1u) & 7u)];
+                    const uint32_t cwn = rec[((cid + 1u) >> 3) * SK_REC_DW + ((cid + 1u) & 7u)];
+                    uint32_t ivp = sk_chunk_inv(rec, cid - 1u), ivn = sk_chunk_inv(rec, cid + 1u);
+                    if (LAZY) {                                                              // (phase 1 only noted THAT a neighbour is not clean)
+                        if (ivp == 0xFFFFu) ivp = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid - 1u));
+                        if (ivn == 0xFFFFu) ivn = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid + 1u));
+                    }
+                    const bool lv_ok = (ivp >> 8) == 0u, rv_ok = (ivn & 0xFFu) == 0u;        // the 8 bases borrowed from either neighbour are ACGT
+                    const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
+                    const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr);
+                    const uint32_t gl = sk_gmix(wl < rl ? wl : rl), gr = sk_gmix(wr < rr ? wr : rr);
+                    uint2 bl = make_uint2(0u, 0u), br = make_uint2(0u, 0u);                  // (both lookups in flight together)
+                    if (lv_ok) bl = table.grid1[sk_grid1_block(gl, table.grid1_blocks)];
+                    if (rv_ok) br = table.grid1[sk_grid1_block(gr, table.grid1_blocks)];
+                    const bool al = lv_ok && sk_grid_test(bl, sk_grid1_bits(gl)), ar = rv_ok && sk_grid_test(br, sk_grid1_bits(gr));
+                    bool pass = false;
+                    if (al | ar) {                                // level 2: the 24-mer of a side that passed, the other side's only if that one is no 24-mer of the strain
+                        const uint64_t l24 = ((uint64_t)(cwp & 0xFFFFu) << 32) | cw, r24 = ((uint64_t)cw << 16) | (cwn >> 16);
+                        uint64_t c24 = sk_canon24(al ? l24 : r24);
+                        pass = sk_grid_test(table.grid2[sk_grid2_block(sk_h24_block(c24), table.grid2_shift)], sk_grid2_bits(sk_h24_bits(c24)));
+                        if (!pass && al && ar) {
+                            c24 = sk_canon24(r24);
+                            pass = sk_grid_test(table.grid2[sk_grid2_block(sk_h24_block(c24), table.grid2_shift)], sk_grid2_bits(sk_h24_bits(c24)));
+                        }
+                    }
+                    if (pass) atomicOr(&pb[(ct >> 5) & 15u], 1u << (ct & 31u));              // owner lane = (ct >> 3) & 63: byte (lane & 3) of word lane >> 2
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            m2 |= (pb[lane >> 2] >> ((lane & 3u) * 8u)) & 0xFFu;
+            __builtin_amdgcn_wave_barrier();                      // (wq is stage 2's again)
+        }
+        m = m2;
+    }
+#else
     if (m && ABLATE != 5 && !CAND) {                              // (ABLATE 5, exact: no level 2, stage 2 sorts it out)                                                      // level 2 (rare for unrelated reads)
         // A chunk right after one that passed level 2 is taken on its level-1 pass alone: inside a strain read
         // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
@@ -901,6 +976,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         }
         m = m2;
     }
+#endif
 
     if (ABLATE == 9) { if (m == 0x77u && tid == 100u) flags[3] = 1u; return; }                            // timing: phases 1 and 2 alone
 
@@ -972,7 +1048,6 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     };
 
     // the wave's surviving chunks (index in the tile), compacted in stream order
-    uint16_t *const cq = cq_all[tid >> 6];
     uint32_t nq = 0;
     if (__ballot(m != 0u) != 0ull) {                              // (wave-uniform; most waves of an unrelated metagenome have none)
         uint32_t incl = (uint32_t)__popc(m);
@@ -2129,13 +2204,14 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
         }
         hipLaunchKernelGGL(sk_table_insert, dim3((nrows + 255) / 256), dim3(256), 0, c->stream,
                            d_in, nrows, c->d_keys, (uint32_t)(slots - 1), c->d_flags, c->d_perm, c->d_locality);
-        {   // grid filters.  Level 1: ~5 bits per key -- 3 MiB for a 5 Mbp strain, which stays in the L2 (4 MiB per XCD,
-            // shared with everything else).  For bigger strains it is better to keep the 5 bits per key and leave the L2
+        {   // grid filters.  Level 1: 5.75 bits per key -- 3.4 MiB for a 5 Mbp strain, which stays in the L2 (4 MiB per XCD,
+            // shared with everything else; round 3, once the kernel was bound by vector instructions: 3.0 -> 3.5 MiB saves more in
+            // false positives' rounds than it costs in L2 misses: -1 % / -3 % / -6 % at 0 / 2 / 30 % strain reads; 4.5 MiB and up lose).  For bigger strains it is better to keep the 5 bits per key and leave the L2
             // than to keep the size and let the filter fill up (tools/grid_size_sweep.sh, 20 Mbp strain: 3 MiB 540,
             // 6 MiB 731, 12 MiB 850, 24 MiB 815 Gbase/s; 100 Mbp: 3 MiB 192, 64 MiB 465): misses of a sparse level 1
             // are served by the 256 MB Infinity Cache, the level-2 lookups a full one lets through are not.
             // Level 2 settles what level 1 lets through: >= 32 bits per key, false positives ~1e-5.
-            uint64_t kib = c->grid_kib > 0 ? (uint64_t)c->grid_kib : ((uint64_t)nrows * 5ull / 8ull + 1023ull) / 1024ull;
+            uint64_t kib = c->grid_kib > 0 ? (uint64_t)c->grid_kib : ((uint64_t)nrows * 23ull / 32ull + 1023ull) / 1024ull;
             if (kib > (1ull << 22)) kib = 1ull << 22;
             if (kib < 4ull) kib = 4ull;
             c->grid1_blocks = (uint32_t)(kib * 1024ull / sizeof(uint2));
@@ -2302,7 +2378,7 @@ extern "C" int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const 
         hipLaunchKernelGGL(sk_build_index, grid, block, 0, c->stream, (const uint32_t *)c->d_text2, nbases, c->d_keys, mask, (const sk_u4 *)c->d_rank, c->d_keys_by_row);
         if (col0_value) hipLaunchKernelGGL(sk_fill32, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, c->d_counts, nrows, col0_value);
         // the filter levels, sized as sk_table_load_ex sizes them, filled from the text
-        uint64_t kib = c->grid_kib > 0 ? (uint64_t)c->grid_kib : ((uint64_t)nrows * 5ull / 8ull + 1023ull) / 1024ull;
+        uint64_t kib = c->grid_kib > 0 ? (uint64_t)c->grid_kib : ((uint64_t)nrows * 23ull / 32ull + 1023ull) / 1024ull;
         if (kib > (1ull << 22)) kib = 1ull << 22;
         if (kib < 4ull) kib = 4ull;
         c->grid1_blocks = (uint32_t)(kib * 1024ull / sizeof(uint2));
@@ -2977,7 +3053,7 @@ extern "C" int sk_union_create(sk_ctx *const *members, uint32_t n, uint32_t type
     }
     hipLaunchKernelGGL(sk_union_mask_b, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, u->d_umask, (const uint32_t *)d_canon, nrows);
     {   // the filters, sized for all the keys (level 1 no longer fits the L2: its misses go to the Infinity Cache)
-        uint64_t kib = first->grid_kib > 0 ? (uint64_t)first->grid_kib * n : ((uint64_t)nrows * 5ull / 8ull + 1023ull) / 1024ull;
+        uint64_t kib = first->grid_kib > 0 ? (uint64_t)first->grid_kib * n : ((uint64_t)nrows * 23ull / 32ull + 1023ull) / 1024ull;
         if (kib > (1ull << 22)) kib = 1ull << 22;
         if (kib < 4ull) kib = 4ull;
         c->grid1_blocks = (uint32_t)(kib * 1024ull / sizeof(uint2));

@@ -33,6 +33,7 @@ VARIANTS = {
     "g1536_h2":     (0.02, {"grid_kib": 1536}, False),
     "g4096_h2":     (0.02, {"grid_kib": 4096}, False),
     "g8192_h2":     (0.02, {"grid_kib": 8192}, False),
+    **{f"g{k}_h{h}": (f, {"grid_kib": k}, False) for k in (3072, 3584, 4096, 4608, 5120, 6144, 8192, 12288) for h, f in ((0, 0.0), (2, 0.02), (30, 0.3)) if f"g{k}_h{h}" not in ("g4096_h2", "g8192_h2")},
     "unc_h0":       (0.0,  {}, True),
     "unc_h2":       (0.02, {}, True),
     "unc_g2048_h2": (0.02, {"grid_kib": 2048}, True),
