@@ -1551,8 +1551,11 @@ template <bool TALLY, bool UNION = false>
 __global__ __launch_bounds__(256)
 void sk_scan_wide(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, sk_wide_view wide, sk_sink sink,
-                  const uint32_t *__restrict__ flags)
+                  const uint32_t *__restrict__ flags, uint32_t *__restrict__ next_flags)
 {
+    // the NEXT launch's flag words (the context alternates between two sets) are zeroed here, behind this launch's scan kernel and
+    // before the next one's: a memset per scan less on the stream
+    if (blockIdx.x == 0u && threadIdx.x < 4u) next_flags[threadIdx.x] = 0u;
     if (flags[0] == 0u) return;                        // no window with a non-ACGT byte in this batch
     // Work list: phase 1 of the scan kernel noted every 16-byte chunk that holds such a byte (flags[2] of them).
     // A window that needs this kernel contains one; it is handled from the chunk that holds its LAST non-ACGT
@@ -1974,6 +1977,8 @@ struct sk_ctx {
     uint64_t     tickets;              // tickets issued so far
     // flags: [0] wide windows seen in the current batch, [1] table build errors
     uint32_t    *d_flags;
+    uint32_t     flag_set;            // which of the two sets of scan flags (words 0..3 / 4..7) the launch in hand uses
+    bool         flags_ready;         // both sets are zero (false after anything else wrote to the flag block)
     uint32_t    *d_oddlist;           // chunks with a byte for the byte-string kernel (SK_ODDCAP entries)
     // timing
     std::vector<hipEvent_t> ev;        // begin/end pairs of launches not yet added up: a ring of at most SK_EV_PAIRS
@@ -2186,6 +2191,7 @@ extern "C" int sk_table_load_ex(sk_ctx *c, const uint64_t *keys, uint32_t nrows,
     SK_HIP(c, hipMemsetAsync(c->d_counts, 0, cbytes, c->stream));
     hipLaunchKernelGGL(sk_fill64, dim3(2048), dim3(256), 0, c->stream, (uint64_t *)c->d_keys, 2 * slots, SK_EMPTY64);
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 16 * sizeof(uint32_t), c->stream));
+    c->flags_ready = false;
     if (nrows) {
         uint64_t *d_in = NULL;
         SK_HIP(c, hipMalloc((void **)&d_in, (size_t)nrows * sizeof(uint64_t)));
@@ -2356,6 +2362,7 @@ extern "C" int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const 
     SK_HIP(c, hipMemsetAsync(c->d_text2, 0, words * 4, c->stream));
     SK_HIP(c, hipMemsetAsync(c->d_rank, 0, nblk * sizeof(sk_u4), c->stream));
     SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 16 * sizeof(uint32_t), c->stream));
+    c->flags_ready = false;
     SK_HIP(c, hipMemcpyAsync(c->d_text2, text2, have * 4, hipMemcpyHostToDevice, c->stream));
     SK_HIP(c, hipMemcpyAsync(d_ok, startok, bwords * 4, hipMemcpyHostToDevice, c->stream));
     const dim3 grid((nbases + 255) / 256), block(256);
@@ -2504,7 +2511,14 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     if (!c->d_grid1) return sk_fail(c, SK_E_STATE, "no table loaded");
     { int grc = sk_grid_ensure(c); if (grc) return grc; }
 
-    SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(uint32_t), c->stream));     // [0] odd bytes seen, [2] listed chunks
+    // [0] odd bytes seen, [2] listed chunks: two sets of four words taking turns -- this launch's byte-string kernel zeroes the other set
+    // for the next launch (both sets are zero after a table load)
+    if (!c->flags_ready) {                                    // (the first scan after a table was built: its kernels used the same words)
+        SK_HIP(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(uint32_t), c->stream));
+        c->flags_ready = true;
+    }
+    c->flag_set ^= 1u;
+    uint32_t *const d_fl = c->d_flags + 4u * c->flag_set, *const d_fl_next = c->d_flags + 4u * (c->flag_set ^ 1u);
     // timing: a begin/end event pair per launch from a small ring -- the oldest pair is added to the totals (its launch is
     // long over, SK_EV_PAIRS launches later) and used again, so a program that never asks for the timing holds 128 events,
     // not two per launch
@@ -2552,7 +2566,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         if ((rc = sk_scratch(c, &c->p_cand, &c->p_cand_cap, (size_t)ntiles_bin * SK_BIN_CH + 64)) != SK_OK) return rc;
         SK_HIP(c, hipMemsetAsync(c->p_cand, 0, (size_t)ntiles_bin * SK_BIN_CH + 64, c->stream));
         hipLaunchKernelGGL(sk_bin, dim3((uint32_t)ntiles_bin), dim3(256), 0, c->stream, d_stream, nbytes, tv,
-                           (uint32_t *)c->p_bins, (uint8_t *)c->p_binn, (uint32_t)ntiles_bin, (uint8_t *)c->p_cand, c->d_flags);
+                           (uint32_t *)c->p_bins, (uint8_t *)c->p_binn, (uint32_t)ntiles_bin, (uint8_t *)c->p_cand, d_fl);
         // one workgroup per CU at a time (128 KiB of LDS each): a few shares per partition keep all 256 CUs busy
         uint32_t splits = ntiles_bin >= 4096 ? 4u : ntiles_bin >= 1024 ? 2u : 1u;
         static bool lds_attr = false;
@@ -2565,9 +2579,9 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         d_cand = (const uint8_t *)c->p_cand;
     }
 #define SK_LAUNCH_GRID(T, A, C) hipLaunchKernelGGL((sk_scan_grid<T, A, C>), grid, block, 0, c->stream, \
-                                                   d_stream, nbytes, emit_begin, tv, sink, c->d_flags, d_cand)
+                                                   d_stream, nbytes, emit_begin, tv, sink, d_fl, d_cand)
     if (tally_sink && tally_sink->ns)
-        hipLaunchKernelGGL((sk_scan_grid<true, 0, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, c->d_flags, d_cand);
+        hipLaunchKernelGGL((sk_scan_grid<true, 0, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl, d_cand);
     else if (piped && tally_sink) SK_LAUNCH_GRID(true, 0, true);
 #ifdef SK_EXPERIMENTS
     else if (piped && c->ablate == 7) SK_LAUNCH_GRID(false, 7, true);
@@ -2594,15 +2608,16 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     }
     uint64_t wblocks = (nbytes - emit_begin + 255) / 256;
     if (wblocks > 16384) wblocks = 16384;
+    if (wblocks == 0) { wblocks = 1; }                        // (the kernel also readies the next launch's flag words)
     if (tally_sink && tally_sink->ns)
         hipLaunchKernelGGL((sk_scan_wide<true, true>), dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, wv, sink, c->d_flags);
+                           d_stream, nbytes, emit_begin, tv, wv, sink, d_fl, d_fl_next);
     else if (tally_sink)
         hipLaunchKernelGGL(sk_scan_wide<true>, dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, wv, sink, c->d_flags);
+                           d_stream, nbytes, emit_begin, tv, wv, sink, d_fl, d_fl_next);
     else
         hipLaunchKernelGGL(sk_scan_wide<false>, dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
-                           d_stream, nbytes, emit_begin, tv, wv, sink, c->d_flags);
+                           d_stream, nbytes, emit_begin, tv, wv, sink, d_fl, d_fl_next);
     SK_HIP(c, hipGetLastError());
     return SK_OK;
 }
