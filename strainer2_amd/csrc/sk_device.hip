@@ -2607,7 +2607,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
         c->ev.push_back(e1);
     }
     uint64_t wblocks = (nbytes - emit_begin + 255) / 256;
-    if (wblocks > 16384) wblocks = 16384;
+    if (wblocks > 2048) wblocks = 2048;                        // (grid-stride: eight workgroups per CU; with nothing to do -- the usual case -- the launch is over in 3 us)
     if (wblocks == 0) { wblocks = 1; }                        // (the kernel also readies the next launch's flag words)
     if (tally_sink && tally_sink->ns)
         hipLaunchKernelGGL((sk_scan_wide<true, true>), dim3((uint32_t)wblocks), dim3(256), 0, c->stream,
