@@ -425,6 +425,16 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
                                            // false positives are frequent enough to send a wave in six down stage 2's slow path), 5 costs nothing there
                                            // and saves 3 % when every read is a strain read, 0.3 % at cfg 2
 #endif
+#ifndef SK_PHASE_CLOCK
+#define SK_PHASE_CLOCK 0                    // experiment: wave-cycles per phase of the scan kernel, summed into the last words of the odd list (sk_debug_phase_clock)
+#endif
+#if SK_PHASE_CLOCK
+#define SK_PHASE(k) do { if (!TALLY && !CAND) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0u) atomicAdd((unsigned long long *)(table.oddlist + table.oddcap - 1024u) + (((blockIdx.x * SK_WAVES + (tid >> 6)) & 63u) * 8u + (k)), now_ - pc_last); \
+        pc_last = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define SK_PHASE(k) do { } while (0)
+#endif
 #ifndef SK_L2_LANES
 #define SK_L2_LANES 1                      // phase 2's second and third questions: the chunks to be asked compacted over the wave, one per lane (0: every thread its own)
 #endif
@@ -615,6 +625,9 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+#if SK_PHASE_CLOCK
+    unsigned long long pc_last = __builtin_amdgcn_s_memtime();
+#endif
     // the cheap phase 1 (sk_decode4_lazy): in COUNT mode; the TALLY kernels, short of scalar registers, keep the exact masks
     constexpr bool LAZY = SK_LAZY_MASKS && !CAND && !TALLY;
     __shared__ uint32_t hl_n[2];                                  // TALLY: the hit log's LDS share (agg is free in that mode)
@@ -663,6 +676,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
 #if (SK_PRIO & 5) == 1
         __builtin_amdgcn_s_setprio(SK_PRIO_BASE);
 #endif
+        SK_PHASE(0);                                                 // start -> the tile's loads issued
     #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const uint32_t c = tid + (uint32_t)it * SK_THREADS;
@@ -752,10 +766,12 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
         }
     }
+    SK_PHASE(1);                                                     // waiting for the loads + decode
 #if (SK_PRIO & 5) == 5
     __builtin_amdgcn_s_setprio(SK_PRIO_BASE);
 #endif
     __syncthreads();
+    SK_PHASE(2);                                                     // the barrier
     if (ABLATE == 8) { if (rec[tid] == 0x12345u && candm == 0x77u) flags[3] = 1u; return; }               // timing: phase 1 alone
 
     // ================= phase 2: one filter lookup per chunk ======================================
@@ -788,6 +804,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         else if (ABLATE == 10) { if (inv == 0u) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)]; }         // timing: the real level-1 lookups, verdicts dropped (no level 2, no stage 2)
         else if (ABLATE != 1 && ((okm >> i) & 1u)) b1[i] = table.grid1[sk_grid1_block(g[i], table.grid1_blocks)];
     }
+    SK_PHASE(3);                                                     // records read, hashes, lookups issued
 #if SK_PRIO_TAIL != SK_PRIO_P2
     __builtin_amdgcn_s_setprio(SK_PRIO_TAIL);
 #endif
@@ -796,6 +813,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     for (int i = 0; i < SK_SPAN_CH; i++)
         m |= (uint32_t)(((okm >> i) & 1u) != 0u && sk_grid_test(b1[i], sk_grid1_bits(g[i])) &&
                         ((ABLATE != 4 && ABLATE != 6 && ABLATE != 10) || g[i] == 0x9E3779B9u)) << i;     // (ablations: loads kept alive, verdicts dropped)
+    SK_PHASE(4);                                                     // waiting for the lookups + their verdicts
 #if SK_RUN_PASS
     // SK_RUN_PASS level-1 survivors in a row (two more in a union table, where one chunk in seven passes level 1 by chance) are a read of
     // the strain: the run goes to stage 2 unquestioned, without the round trips to the L2 and to HBM that the questions below cost a
@@ -978,6 +996,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     }
 #endif
 
+    SK_PHASE(5);                                                     // the second and third questions
     if (ABLATE == 9) { if (m == 0x77u && tid == 100u) flags[3] = 1u; return; }                            // timing: phases 1 and 2 alone
 
     // ================= stage 2: the windows of the surviving chunks ==============================
@@ -1378,6 +1397,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (qw) probe_windows(qw);
+    SK_PHASE(6);                                                     // stage 2
     if (bad) atomicAdd(&flags[0], 1u);
     if (!TALLY) {                                                 // the repeats of this tile, one atomic per index
         __syncthreads();
@@ -1385,6 +1405,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             const uint2 e = agg[i];
             if (e.y != 0u && ABLATE != 3) atomicAdd(&sink.diff[e.x], e.y);
         }
+        SK_PHASE(7);                                                 // the closing barrier + flush
     } else {                                                      // the tile's share of the hit log: one atomic, one copy
         __syncthreads();
         const uint32_t nl = hl_n[0] < hl_n[1] ? hl_n[0] : hl_n[1];
@@ -3648,3 +3669,18 @@ extern "C" int sk_dev_download(sk_ctx *c, void *host, const void *dev, uint64_t 
     SK_HIP(c, hipStreamSynchronize(c->stream));
     return SK_OK;
 }
+
+#if SK_PHASE_CLOCK
+// experiment builds only: the eight phase sums (wave-cycles of s_memtime) since the last call, then zeroed
+extern "C" int sk_debug_phase_clock(sk_ctx *c, unsigned long long out[8])
+{
+    if (!c || !out) return SK_E_ARG;
+    SK_HIP(c, hipSetDevice(c->device));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long *d = (unsigned long long *)(c->d_oddlist + (c->odd_cap ? c->odd_cap : SK_ODDCAP) - 1024u), h[512];
+    SK_HIP(c, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    SK_HIP(c, hipMemset(d, 0, sizeof h));
+    for (int k = 0; k < 8; k++) { out[k] = 0; for (int s = 0; s < 64; s++) out[k] += h[s * 8 + k]; }
+    return SK_OK;
+}
+#endif
