@@ -64,7 +64,9 @@ static_assert(SK_THREADS <= 256 && SK_THREADS % 64 == 0, "a tile's window number
 #define SK_STREAM_POLICY 0
 #endif
 #define SK_NCHUNK_GRID  (SK_NCHUNK + 1)
+#ifndef SK_AGG_LOG2
 #define SK_AGG_LOG2     8
+#endif
 #define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
 #define SK_EV_PAIRS     64u                 // launches whose timing events are kept before they are added up
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
