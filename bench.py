@@ -221,6 +221,23 @@ def measured_traffic(args, kernel_name):
     return tj.get("hbm_bytes_per_launch"), tj.get("correction")
 
 
+def measured_vector_issue():
+    """vector-instruction issue of the scan kernel as a fraction of the SIMDs' issue slots, from the same stamped PMC passes:
+    SQ_INSTS_VALU x 4 cycles (a wave64 instruction on a 16-lane SIMD) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); None if stale"""
+    tp = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tp))
+        if tj.get("sk_device_hip_sha256") != device_source_sha():
+            return None
+        n, cyc = tj.get("vector_instructions_per_launch"), tj.get("gpu_cycles_per_launch_per_xcd")
+        if not n or not cyc:
+            return None
+        return {"instructions_per_launch": n, "cycles_per_launch": cyc, "frac": n * 4.0 / 1024.0 / cyc,
+                "what": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), profiled run of the same source (profiles/traffic.json)"}
+    except Exception:                                        # noqa: BLE001
+        return None
+
+
 # ----------------------------------------------------------------------------- strain_detect side measurement
 def strain_detect_leg(device, oracle_sample_reads=20_000, repeat=10):
     """The second deliverable's kernel (sk_scan_grid<TALLY, UNION>: per-read tallies against ONE table over 32 resident strains,
@@ -650,7 +667,9 @@ def main():
                                                  "measured TCC_REQ in profiles/)",
                                          "achieved_per_s": (nbytes / 16.0 + nbytes / 128.0) / (avg_ms * 1e-3), "ceiling_per_s": L2_REQ_CEILING,
                                          "frac": (nbytes / 16.0 + nbytes / 128.0) / (avg_ms * 1e-3) / L2_REQ_CEILING,
-                                         "ceiling_source": "random 8-byte loads from a <= 4 MiB table, profiles/r01_gather_microbench.txt"}},
+                                         "ceiling_source": "random 8-byte loads from a <= 4 MiB table, profiles/r01_gather_microbench.txt"},
+                         # ... and the third: the SIMDs' issue slots (the kernel is integer SWAR work, 13 vector instructions per base)
+                         "vector_issue": measured_vector_issue()},
             "cpu_baseline": cpu,
             "strain_detect": sd_leg,
         }

@@ -26,6 +26,8 @@ stream_bytes = reads * 151                       # the record stream: the only w
 t = {"kernel": [n for n in s["kernels"] if "sk_scan_grid" in n][0].split("<")[0].replace("void ", ""), "reads": reads, "read_len": 150,
      "hbm_bytes_per_launch": fetch + stream_bytes / 2 + write, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
      "streaming_share_bytes": stream_bytes,
+     "vector_instructions_per_launch": c.get("SQ_INSTS_VALU"), "gpu_cycles_per_launch_per_xcd": (c.get("GRBM_GUI_ACTIVE") or 0) / 8 or None,
+     "tcc_requests_per_launch": c.get("TCC_REQ_sum"),
      "sk_device_hip_sha256": hashlib.sha256(open("strainer2_amd/csrc/sk_device.hip", "rb").read()).hexdigest(),
      "correction": "FETCH_SIZE raw + half of the record stream's bytes (gfx950: 128-B streaming requests are tallied at 64 B; "
                    "applied to the streaming share only, random lookups as counted) + WRITE_SIZE (exact). Separate --pmc passes (tools/profile.sh).",
