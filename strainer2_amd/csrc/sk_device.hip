@@ -508,8 +508,10 @@ __device__ __forceinline__ uint64_t sk_text_key(const uint32_t *__restrict__ tex
 
 __device__ __forceinline__ bool sk_grid_test(const uint2 blk, uint32_t bits)
 {
-    const uint32_t t = (blk.x >> (bits >> 27)) & (blk.x >> ((bits >> 22) & 31u)) &
-                       (blk.y >> ((bits >> 17) & 31u)) & (blk.y >> ((bits >> 12) & 31u));
+    // the four bit positions are the low five bits of the four BYTES of `bits`: a shift takes its amount straight from a byte of
+    // a register (SDWA), so a position costs no instruction of its own (round 3; same false-positive rate as the 5-bit fields it replaces)
+    const uint32_t t = (blk.x >> ((bits >> 24) & 31u)) & (blk.x >> ((bits >> 16) & 31u)) &
+                       (blk.y >> ((bits >> 8) & 31u)) & (blk.y >> (bits & 31u));
     return (t & 1u) != 0u;
 }
 
@@ -541,7 +543,7 @@ __device__ __forceinline__ void sk_grid2_insert24(uint32_t *__restrict__ w2, uin
     const uint64_t c24 = sk_canon24(f24);
     const uint32_t b = sk_grid2_bits(sk_h24_bits(c24));
     uint32_t *blk = w2 + 2u * (size_t)sk_grid2_block(sk_h24_block(c24), shift2);
-    const uint32_t m0 = (1u << (b >> 27)) | (1u << ((b >> 22) & 31u)), m1 = (1u << ((b >> 17) & 31u)) | (1u << ((b >> 12) & 31u));
+    const uint32_t m0 = (1u << ((b >> 24) & 31u)) | (1u << ((b >> 16) & 31u)), m1 = (1u << ((b >> 8) & 31u)) | (1u << (b & 31u));
     if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
     if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
 }
@@ -1807,7 +1809,7 @@ __global__ void sk_grid_insert(const uint64_t *__restrict__ in, uint32_t n, uint
         const uint32_t a = sk_grid1_bits(g);
         // consecutive keys share 15 of their 16 sub-words: most bits are set already, so look before the atomic
         uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
-        const uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
+        const uint32_t m0 = (1u << ((a >> 24) & 31u)) | (1u << ((a >> 16) & 31u)), m1 = (1u << ((a >> 8) & 31u)) | (1u << (a & 31u));
         if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
         if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
     }
@@ -1921,7 +1923,7 @@ __global__ void sk_grid_insert_slots(const sk_u4 *__restrict__ slots, uint64_t n
             const uint32_t g = sk_gmix(f < r ? f : r);
             const uint32_t a = sk_grid1_bits(g);
             uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
-            const uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
+            const uint32_t m0 = (1u << ((a >> 24) & 31u)) | (1u << ((a >> 16) & 31u)), m1 = (1u << ((a >> 8) & 31u)) | (1u << (a & 31u));
             if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
             if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
         }
@@ -1944,7 +1946,7 @@ __global__ void sk_grid_insert_text(const uint32_t *__restrict__ text2, uint32_t
     const uint32_t g = sk_gmix(f < r ? f : r);
     const uint32_t a = sk_grid1_bits(g);
     uint32_t *blk = w1 + 2u * (size_t)sk_grid1_block(g, nblocks1);
-    const uint32_t m0 = (1u << (a >> 27)) | (1u << ((a >> 22) & 31u)), m1 = (1u << ((a >> 17) & 31u)) | (1u << ((a >> 12) & 31u));
+    const uint32_t m0 = (1u << ((a >> 24) & 31u)) | (1u << ((a >> 16) & 31u)), m1 = (1u << ((a >> 8) & 31u)) | (1u << (a & 31u));
     if ((__builtin_nontemporal_load(&blk[0]) & m0) != m0) atomicOr(&blk[0], m0);
     if ((__builtin_nontemporal_load(&blk[1]) & m1) != m1) atomicOr(&blk[1], m1);
     if (q + 24u <= nbases) sk_grid2_insert24(w2, shift2, sk_text_24(text2, q));       // level 2: the text's 24-mer at this place
