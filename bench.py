@@ -24,7 +24,13 @@ passes of tools/profile.sh, taken from profiles/traffic.json ONLY if that file w
 sk_device.hip (sha256 stamp), else null.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu]
-  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  N > 1, either way:
+    python bench.py --gpus N ...                       (no WORLD_SIZE in the environment: this process starts the N ranks itself --
+                                                        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+                                                        127.0.0.1 --master-port <a free one> bench.py --gpus N ...` as a CHILD process,
+                                                        never touching the GPU itself -- passes rank 0's JSON line on and exits with
+                                                        the child's status)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (already under a launcher: a rank)
 """
 import argparse
 import json
@@ -362,6 +368,48 @@ def strain_detect_leg(device, oracle_sample_reads=20_000, repeat=10):
     return out
 
 
+# ----------------------------------------------------------------------------- N > 1 from the plain command
+def launch_ranks(gpus, argv):
+    """`python bench.py --gpus N` with no launcher around it (the driver's own command): start the N ranks as a
+    child `python -m torch.distributed.run ...` on a free port, relay rank 0's JSON line (stdout lines that are not the line go to
+    stderr: RCCL/torch banners must not break the one-line contract) and return the child's exit status.  This parent imports
+    neither torch nor the library: a process that has initialised the GPU must not start others by exec, and it has no need to.
+    SK_BENCH_RANK_SCRIPT (tests only): the script the ranks run instead of this file."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = os.environ.get("SK_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: what RCCL needs between processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench.py: starting %d ranks: %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    lines = 0
+    for raw in child.stdout:
+        text = raw.decode("utf-8", "replace")
+        is_line = False
+        if text.lstrip().startswith("{"):
+            try:
+                is_line = "metric" in json.loads(text)
+            except ValueError:
+                is_line = False
+        if is_line:
+            lines += 1
+            sys.stdout.write(text if text.endswith("\n") else text + "\n")
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(text)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        print("bench.py: the ranks ended with status 0 but printed %d result lines" % lines, file=sys.stderr)
+        rc = 1
+    return rc if rc >= 0 else 128 - rc
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -382,11 +430,13 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments: 1 = no filter/table memory, 2 = no table probes (counts are wrong)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # the plain command: be the launcher (no GPU, no torch in this process)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world and --gpus must be the same")
 
     from strainer2_amd import synth
     contigs = synth.make_strain(total_bp=args.strain_bp)
@@ -567,18 +617,17 @@ def main():
         except Exception as e:                               # noqa: BLE001
             ok, why = False, f"could not write the files: {e}"
         ok, file_fed = everyone_ok(ok, "a rank could not write its FASTQ files under " + root + (": " + why if why else ""))
-        if ok and world > 1:                                 # the ranks must follow the same plan (they reduce through torch here)
-            from strainer2_amd.dist import plans_agree
-            agreed = plans_agree(os.path.join(root, "list.txt"), world)
-            ok, file_fed = everyone_ok(agreed, "the ranks computed different work plans for the list (skh_list_plan_hash)")
         if ok:
+            # dist.scan_list_sharded: the plans are compared, a cut that does not hold sends EVERY rank round again uncut, and any
+            # failure raises on every rank together (the same collectives on all ranks whatever happens to one of them)
+            from strainer2_amd.dist import scan_list_sharded
             cold = None
             try:                                             # first pass, not the one reported: page-locks the decode threads' buffers
                 t1 = time.perf_counter()
-                ctx.scan_list(os.path.join(root, "list.txt"), 1, rank=rank, world=world)
+                scan_list_sharded(ctx, os.path.join(root, "list.txt"), 1, rank, world)
                 ctx.sync()
                 cold = time.perf_counter() - t1
-            except Exception as e:                           # noqa: BLE001
+            except (OSError, ValueError) as e:
                 ok, why = False, f"scan_list failed: {e}"
             barrier()
             ctx.zero_counts(1)
@@ -586,9 +635,9 @@ def main():
             fb = 0
             try:
                 if ok:
-                    fb = ctx.scan_list(os.path.join(root, "list.txt"), 1, rank=rank, world=world)
+                    fb = scan_list_sharded(ctx, os.path.join(root, "list.txt"), 1, rank, world)
                     ctx.sync()
-            except Exception as e:                           # noqa: BLE001
+            except (OSError, ValueError) as e:
                 ok, why = False, f"scan_list failed: {e}"
             if world > 1:
                 allreduce_counts(ctx, 1)

@@ -234,6 +234,11 @@ int  sk_comm_sum_u32(sk_ctx *ctx, uint32_t value, uint32_t *sum);
 /* *agree = 1 iff every rank passed the same value (one max all-reduce of {v, ~v}); without a communicator: 1.
  * skh_scan_list uses it to compare the ranks' work plans before any of them scans. */
 int  sk_comm_agree_u64(sk_ctx *ctx, uint64_t value, int *agree);
+/* vals[i] = the maximum of vals[i] over all ranks, i < n <= 8 (one all-reduce); without a communicator: unchanged.  The list
+ * walk's two agreements per list are built on it (skh_scan_list below): whatever happens to a rank locally, every rank issues
+ * the same sequence of collectives.  sk_comm_world: ranks of the context's communicator, 0 without one. */
+int  sk_comm_max_u64(sk_ctx *ctx, uint64_t *vals, uint32_t n);
+int  sk_comm_world(const sk_ctx *ctx);
 int  sk_counts_allreduce(sk_ctx *ctx, void *rccl_comm);
 
 /* Device-side timing of the scan kernel, from HIP events recorded on the context's stream
@@ -305,6 +310,15 @@ int skh_scan_file(sk_ctx *ctx, const char *path, uint32_t col, uint64_t *bases);
  * GEN_all_kmer_counts_skip_file(): src/genome_compare.c:115-146. */
 int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col,
                   FILE *progress, FILE *err, uint32_t rank, uint32_t world, uint64_t *bases);
+/* What happens when a big text file's cut does not hold (a piece does not end between two records: SK_E_SPLIT inside).  One
+ * process, or ranks that are all in the context's communicator (sk_comm_init): nothing the caller sees -- the column is put
+ * back on every rank and the list scanned again uncut, every rank returning the same status (two small agreements per list
+ * scan, sk_comm_max_u64: the same sequence of collectives on every rank whatever fails where).  Ranks WITHOUT the library's
+ * communicator (a caller that reduces through torch.distributed): SK_E_SPLIT comes back and the caller does the same steps
+ * itself -- copy the column before, agree after, sk_counts_set + skh_scan_list_uncut on every rank (strainer2_amd/dist.py:
+ * scan_list_sharded).  skh_scan_list_uncut = skh_scan_list over the plan without byte-range pieces (SK_NO_SPLIT=1). */
+int skh_scan_list_uncut(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col,
+                        FILE *progress, FILE *err, uint32_t rank, uint32_t world, uint64_t *bases);
 /* Hash of the work plan skh_scan_list(list, skip, .., world) follows (items, byte ranges, file sizes, owners): a function
  * of the list, the files and `world` (and of SK_SPLIT_BYTES / SK_NO_SPLIT) only, never of a rank's thread count.  With the
  * library's own communicator skh_scan_list compares it across ranks itself (SK_E_PLAN); a caller that reduces the counters

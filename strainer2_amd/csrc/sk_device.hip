@@ -2087,9 +2087,9 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     c->diff_col = -1;
     c->err[0] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SK_E_NODEVICE; }
-    if (hipMalloc((void **)&c->d_flags, 16 * sizeof(uint32_t)) != hipSuccess) { delete c; return SK_E_NOMEM; }
+    if (hipMalloc((void **)&c->d_flags, 32 * sizeof(uint32_t)) != hipSuccess) { delete c; return SK_E_NOMEM; }   // (words 16..31: scratch of the small collectives)
     if (hipMalloc((void **)&c->d_oddlist, (size_t)SK_ODDCAP * sizeof(uint32_t)) != hipSuccess) { hipFree(c->d_flags); delete c; return SK_E_NOMEM; }
-    hipMemsetAsync(c->d_flags, 0, 16 * sizeof(uint32_t), c->stream);
+    hipMemsetAsync(c->d_flags, 0, 32 * sizeof(uint32_t), c->stream);
     {   // the complement map goes to the device once per process and device, not once per context: the copy to a symbol
         // waits for the device, and 32 strains opened at once (strain_detect -S) spent 0.19 s each in here
         static pthread_mutex_t once_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -2363,6 +2363,8 @@ extern "C" int sk_table_load_text(sk_ctx *c, const uint32_t *text2, uint32_t nba
 // bases (2 bits each, records end to end) and, per position, whether a window of 31 A/C/G/T bases of one record starts there; keys,
 // first occurrences, row numbers (by first occurrence: "strain order"), rank map, both filter levels and column 0 are made here --
 // no 40 MB of keys, no permutations and no column 0 over PCIe, no hash table on the host.  *nrows_out = distinct keys.
+static int sk_table_build_from_text_steps(sk_ctx *c, const uint32_t *text2, const uint32_t *startok, uint32_t nbases, uint32_t nstarts,
+                                          uint32_t ncols, uint32_t col0_value, uint32_t *nrows_out, uint32_t *&d_ok);
 extern "C" int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const uint32_t *startok, uint32_t nbases, uint32_t nstarts,
                                         uint32_t ncols, uint32_t col0_value, uint32_t *nrows_out)
 {
@@ -2371,13 +2373,29 @@ extern "C" int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const 
     SK_HIP(c, hipSetDevice(c->device));
     SK_HIP(c, hipStreamSynchronize(c->stream));
     sk_table_release(c);
+    // a build that fails midway (out of memory with many strains on one device) must leave neither its scratch nor half a table
+    // behind: the caller falls back to the host builder on this same context
+    uint32_t *d_ok = NULL;
+    const int rc = sk_table_build_from_text_steps(c, text2, startok, nbases, nstarts, ncols, col0_value, nrows_out, d_ok);
+    if (d_ok) (void)hipFree(d_ok);
+    if (rc != SK_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        sk_table_release(c);
+        c->nrows = 0; c->ncols = 0;
+    }
+    return rc;
+}
+
+static int sk_table_build_from_text_steps(sk_ctx *c, const uint32_t *text2, const uint32_t *startok, uint32_t nbases, uint32_t nstarts,
+                                          uint32_t ncols, uint32_t col0_value, uint32_t *nrows_out, uint32_t *&d_ok)
+{
     uint32_t lg = 10;
     while (((uint64_t)1 << lg) * (uint64_t)c->table_load_pct < (uint64_t)nstarts * 100ull && lg < 31) lg++;
     const uint64_t slots = (uint64_t)1 << lg;
     const uint32_t mask = (uint32_t)(slots - 1);
     c->slots_log2 = lg;
     const size_t words = (size_t)nbases / 16 + 4, have = ((size_t)nbases + 15) / 16, nblk = (size_t)nbases / 64 + 2, bwords = ((size_t)nbases + 31) / 32;
-    uint32_t *d_ok = NULL, *d_total = NULL;
+    uint32_t *d_total = NULL;
     SK_HIP(c, hipMalloc((void **)&c->d_keys, slots * sizeof(sk_u4)));
     SK_HIP(c, hipMalloc((void **)&c->d_text2, words * 4));
     SK_HIP(c, hipMalloc((void **)&c->d_rank, nblk * sizeof(sk_u4)));
@@ -2398,6 +2416,7 @@ extern "C" int sk_table_build_from_text(sk_ctx *c, const uint32_t *text2, const 
     SK_HIP(c, hipMemcpyAsync(&nrows, d_total, 4, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(d_ok);
+    d_ok = NULL;
     *nrows_out = nrows;
     c->nrows = nrows; c->ncols = ncols;
     c->text_bases = nbases;
@@ -3601,21 +3620,35 @@ extern "C" int sk_comm_sum_u32(sk_ctx *c, uint32_t value, uint32_t *sum)
     return SK_OK;
 }
 
+// Element-wise maximum of up to 8 host words over all ranks, in place: the one small collective the list walk is built on
+// (plan hash + local failure flags before a list is scanned, what went wrong where after it: every rank issues the same
+// sequence of these whatever happens to it locally).  No communicator: the values stay as they are.
+extern "C" int sk_comm_max_u64(sk_ctx *c, uint64_t *vals, uint32_t n)
+{
+    if (!vals || n == 0 || n > 8) return SK_E_ARG;
+    if (!c || !c->comm) return SK_OK;
+    SK_HIP(c, hipSetDevice(c->device));
+    uint64_t *d = (uint64_t *)(c->d_flags + 16);      // scratch words of the flag block (64 bytes in: 8-byte aligned)
+    SK_HIP(c, hipMemcpyAsync(d, vals, 8u * n, hipMemcpyHostToDevice, c->stream));
+    const int ncclUint64 = 5, ncclMax = 2;            // rccl.h: ncclDataType_t / ncclRedOp_t
+    if (g_rccl.allreduce(d, d, n, ncclUint64, ncclMax, c->comm, c->stream) != 0) return sk_fail(c, SK_E_RCCL, "ncclAllReduce failed");
+    SK_HIP(c, hipMemcpyAsync(vals, d, 8u * n, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(c, hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+// ranks of the context's communicator (0: none) -- the list walk coordinates its fall-backs only when every rank of the run is in it
+extern "C" int sk_comm_world(const sk_ctx *c) { return c && c->comm ? c->comm_world : 0; }
+
 // Do all ranks hold the same 64-bit value (a hash of the work plan, before anyone scans)?  One max all-reduce over
 // {v, ~v}: the values agree iff max(v) == min(v) == ~max(~v).  No communicator: a world of one agrees with itself.
 extern "C" int sk_comm_agree_u64(sk_ctx *c, uint64_t value, int *agree)
 {
     if (!agree) return SK_E_ARG;
     *agree = 1;
-    if (!c || !c->comm) return SK_OK;
-    SK_HIP(c, hipSetDevice(c->device));
-    uint64_t *d = (uint64_t *)(c->d_flags + 12);      // spare words of the flag block (8-byte aligned: 48 bytes in)
     uint64_t h[2] = {value, ~value};
-    SK_HIP(c, hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, c->stream));
-    const int ncclUint64 = 5, ncclMax = 2;            // rccl.h: ncclDataType_t / ncclRedOp_t
-    if (g_rccl.allreduce(d, d, 2, ncclUint64, ncclMax, c->comm, c->stream) != 0) return sk_fail(c, SK_E_RCCL, "ncclAllReduce failed");
-    SK_HIP(c, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(c, hipStreamSynchronize(c->stream));
+    const int rc = sk_comm_max_u64(c, h, 2);
+    if (rc != SK_OK) return rc;
     *agree = h[0] == value && h[1] == ~value;         // (max v == v and min v == v on this rank <=> on every rank)
     return SK_OK;
 }

@@ -622,8 +622,14 @@ static int dk_record(void *user, char *seq, size_t len)
     if ((d->n + len + 64) / 16 + 1 > d->cap_words) {
         uint64_t want = d->cap_words ? d->cap_words * 2 : 1u << 16;
         while (want < (d->n + len + 64) / 16 + 1) want *= 2;
-        d->text2 = (uint32_t *)realloc(d->text2, want * sizeof(uint32_t));
-        d->ok = (uint32_t *)realloc(d->ok, (want / 2 + 2) * sizeof(uint32_t));          /* (one bit per base: 16 bases per text word) */
+        {   /* (one bit per base: 16 bases per text word); a failed realloc leaves the old block in place for the caller to free */
+            uint32_t *t2 = (uint32_t *)realloc(d->text2, want * sizeof(uint32_t)), *okb;
+            if (!t2) return SK_E_NOMEM;
+            d->text2 = t2;
+            okb = (uint32_t *)realloc(d->ok, (want / 2 + 2) * sizeof(uint32_t));
+            if (!okb) return SK_E_NOMEM;
+            d->ok = okb;
+        }
         memset(d->text2 + d->cap_words, 0, (want - d->cap_words) * sizeof(uint32_t));
         memset(d->ok + d->ok_words, 0, (want / 2 + 2 - d->ok_words) * sizeof(uint32_t));
         d->cap_words = want;
@@ -1219,13 +1225,26 @@ static uint64_t plan_digest(const scan_item *items, const uint32_t *owner, uint3
 
 typedef struct { uint64_t *hash; uint32_t *owner; uint32_t cap, *nlines; } plan_report;
 
-/* What a cut that does not hold costs (single process): nothing but time.  Before a list with pieces is scanned the column is
- * copied; if a piece fails its check (SK_E_SPLIT: a record that ends the FILE for the reference in the middle of it, a layout
- * the guess misjudges) the column and the progress file are put back and the list is scanned again UNCUT -- the reference's
- * strict record sequence per file, which reports what the reference reports (src/kseq.h:205-209, src/genome_compare.c:203).
- * The cut is an optimisation that is checked, not a new way to fail.  With several ranks the run still fails (other ranks
- * have counted their pieces already): SK_NO_SPLIT=1 is the way round there. */
+/* What a cut that does not hold costs: nothing but time.  Before a list with pieces is scanned the column is copied; if a
+ * piece fails its check (SK_E_SPLIT: a record that ends the FILE for the reference in the middle of it, a layout the guess
+ * misjudges) the column and the progress file are put back and the list is scanned again UNCUT -- the reference's strict
+ * record sequence per file, which reports what the reference reports (src/kseq.h:205-209, src/genome_compare.c:203).
+ * The cut is an optimisation that is checked, not a new way to fail.  With several ranks in the library's communicator
+ * the same holds (round 4): the plan is global, so EVERY rank copies its column when the plan has pieces, the ranks learn of
+ * a failed check through the agreement that closes every list scan, and all of them put their columns back and scan their
+ * share of the whole-file plan.  Only a caller that runs ranks WITHOUT the library's communicator still gets SK_E_SPLIT
+ * (its other ranks cannot be told from here): it coordinates the same steps itself (strainer2_amd/dist.py:
+ * scan_list_sharded) with skh_scan_list_uncut.
+ *
+ * Collectives: whatever happens to a rank locally -- a list it cannot open, a file only it owns that is
+ * missing, a cut that fails -- every rank issues the same sequence: per list scan ONE agreement before (plan hash, "my
+ * set-up for this list failed") and ONE after (first unreadable line, "a cut failed", "a device error"), each a max
+ * all-reduce of a few words (sk_comm_max_u64), and every rank returns the SAME status, so the callers' decisions
+ * (skip the remaining lists, go to the big all-reduce) are the same everywhere. */
 typedef struct { uint32_t *snap; long prog_at; int armed; } split_guard;
+
+#define LIST_FAIL_OPEN  1u    /* agreement before the scan: this rank could not read the list itself */
+#define LIST_FAIL_GUARD 2u    /*                            ... could not copy its column (no memory, device error) */
 
 static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
                           FILE *err, uint32_t rank, uint32_t world, uint64_t *bases, int plan_only, const plan_report *report,
@@ -1241,11 +1260,18 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
     scan_item *all = NULL;
     uint64_t *est = NULL, total = 0, plan_hash = 0;
     uint32_t *owner = NULL;
+    uint64_t local_fail = 0;
+    uint32_t open_line = UINT32_MAX;            /* the first list line whose file some rank could not open */
+    int any_ranged = 0, coordinated, by_other = 0;
+    if (world == 0) world = 1;
+    /* several ranks act together only when all of them are in the library's communicator */
+    coordinated = world <= 1 || (ctx && (uint32_t)sk_comm_world(ctx) == world);
     if (!fp) {
         if (err) fprintf(err, "could not read file %s in GEN_all_kmer_counts()\n", list_path);
-        return SK_E_OPEN;
+        if (!ctx || plan_only || world <= 1 || !coordinated) return SK_E_OPEN;
+        local_fail |= LIST_FAIL_OPEN;                       /* (the other ranks are waiting in the agreement below) */
     }
-    if (world == 0) world = 1;
+    if (no_split == 2) local_fail |= LIST_FAIL_GUARD;       /* (second scan after a failed cut: this rank could not put its column back) */
     memset(&pool, 0, sizeof pool);
     pool.ctx = ctx;
     pool.col = col;
@@ -1257,7 +1283,7 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
 
     /* the list's lines; what the reference says about each of them (progress line, skip message) is said in list
      * order: the progress line when a decode thread takes the line's file, the skip messages behind the scans */
-    while (getline(&line, &cap, fp) != -1) {
+    while (fp && getline(&line, &cap, fp) != -1) {
         struct stat st;
         if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
         if (nline == lcap) { lcap = lcap ? lcap * 2 : 64; pool.ll = (list_line *)realloc(pool.ll, lcap * sizeof *pool.ll); }
@@ -1275,7 +1301,7 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
         nall++;
     }
     free(line);
-    fclose(fp);
+    if (fp) fclose(fp);
     pool.nll = nline;
     pool.progress = rank == 0 ? progress : NULL;
 
@@ -1342,19 +1368,40 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
                 *o = *o == SKH_PLAN_SKIPPED || *o == owner[i] ? owner[i] : SKH_PLAN_SHARED;
             }
     }
+    for (i = 0; i < nall; i++) any_ranged |= all[i].ranged;
+    if (guard && ctx && !plan_only && !no_split && coordinated && any_ranged && sk_table_rows(ctx)) {
+        /* pieces ahead (somewhere in the plan: on every rank, then): keep what a failed cut would spoil */
+        guard->snap = (uint32_t *)malloc((size_t)sk_table_rows(ctx) * sizeof(uint32_t));
+        if (guard->snap && sk_counts_fetch(ctx, col, guard->snap) == SK_OK) {
+            guard->prog_at = progress ? (fflush(progress), ftell(progress)) : -1;
+            guard->armed = 1;
+        } else local_fail |= LIST_FAIL_GUARD;
+    }
     if (ctx && !plan_only) {                            /* (a world of one with a communicator -- SK_FORCE_COMM -- takes the same road: tests) */
-        /* local settings that change the plan (SK_SPLIT_BYTES, SK_NO_SPLIT) or a file whose size another rank sees
-         * differently would have byte ranges scanned twice or never and the summed table silently wrong: every rank
-         * leaves instead.  (Without an in-library communicator -- a caller that reduces the counters itself -- the
-         * caller compares skh_list_plan_hash() through its own collective.) */
-        int same = 1;
-        const int arc = sk_comm_agree_u64(ctx, plan_hash, &same);
-        if (arc != SK_OK || !same) {
+        /* The agreement before the scan.  Local settings that change the plan (SK_SPLIT_BYTES, SK_NO_SPLIT) or a file whose
+         * size another rank sees differently would have byte ranges scanned twice or never and the summed table silently
+         * wrong: every rank leaves instead (SK_E_PLAN) -- and so does every rank when ONE of them could not read the list or
+         * copy its column.  (Without an in-library communicator -- a caller that reduces the counters itself -- the caller
+         * compares skh_list_plan_hash() through its own collective.) */
+        uint64_t v[3];
+        int arc;
+        v[0] = plan_hash; v[1] = ~plan_hash; v[2] = local_fail;
+        arc = sk_comm_max_u64(ctx, v, 3);
+        if (arc != SK_OK) {
+            if (err) fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(arc), sk_last_error(ctx));
+            pool.rc = arc; plan_only = 1;
+        } else if (v[2] & LIST_FAIL_OPEN) {
+            if (err && !(local_fail & LIST_FAIL_OPEN)) fprintf(err, "kmer_scrub_count: another rank could not read %s; nothing is reported\n", list_path);
+            pool.rc = SK_E_OPEN; plan_only = 1;
+        } else if (v[2] & LIST_FAIL_GUARD) {
+            if (err) fprintf(err, "kmer_scrub_count: %s could not keep a copy of its counters before cutting the files of %s\n",
+                             (local_fail & LIST_FAIL_GUARD) ? "this rank" : "another rank", list_path);
+            pool.rc = SK_E_NOMEM; plan_only = 1;
+        } else if (v[0] != plan_hash || v[1] != ~plan_hash) {
             if (err) fprintf(err, "kmer_scrub_count: the ranks computed different work plans for %s (rank %u: %016llx) -- check "
                                   "SK_SPLIT_BYTES / SK_NO_SPLIT and that every rank sees the same files; nothing is reported\n",
                              list_path, rank, (unsigned long long)plan_hash);
-            pool.rc = arc != SK_OK ? arc : SK_E_PLAN;
-            plan_only = 1;                                /* (fall through to the clean-up) */
+            pool.rc = SK_E_PLAN; plan_only = 1;           /* (fall through to the clean-up) */
         }
     }
     pool.item = (scan_item *)malloc(((size_t)nall + 1) * sizeof *pool.item);
@@ -1364,17 +1411,6 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
     }
     free(all); free(est); free(owner);
 
-    if (guard && !plan_only && world <= 1 && !no_split) {      /* pieces ahead: keep what a failed cut would spoil */
-        int ranged = 0;
-        for (i = 0; i < pool.nitem; i++) ranged |= pool.item[i].ranged;
-        if (ranged && sk_table_rows(ctx)) {
-            guard->snap = (uint32_t *)malloc((size_t)sk_table_rows(ctx) * sizeof(uint32_t));
-            if (guard->snap && sk_counts_fetch(ctx, col, guard->snap) == SK_OK) {
-                guard->prog_at = progress ? (fflush(progress), ftell(progress)) : -1;
-                guard->armed = 1;
-            }
-        }
-    }
     {   /* with fewer files than half the cores, a file's inflate and its record parsing take a core each; with
          * fewer still, the threads left over inflate inside the files (a speculative segment costs about twice a
          * serial one, so it takes three threads per file to be worth it).  SK_GZ_THREADS sets the number per file. */
@@ -1417,25 +1453,53 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
         for (i = 0; i < (uint32_t)nthreads; i++) pthread_join(th[i], NULL);
         free(th);
     }
+    if (!plan_only && ctx) {
+        /* The agreement after the scan: what went wrong, anywhere.  The first list line whose file could not be opened (the
+         * reference stops there: the earliest line wins), "a cut did not hold", "a device error" -- one max all-reduce, and
+         * from here on every rank holds the same status. */
+        uint64_t v[3] = {0, 0, 0};
+        int arc;
+        if (pool.rc == SK_E_OPEN) v[0] = (uint64_t)UINT32_MAX - pool.item[pool.rc_index].line + 1;       /* (larger = earlier) */
+        else if (pool.rc == SK_E_SPLIT) v[1] = 1;
+        else if (pool.rc != SK_OK) v[2] = (uint64_t)(uint32_t)(-pool.rc);
+        arc = sk_comm_max_u64(ctx, v, 3);
+        if (arc != SK_OK) {
+            if (err) fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(arc), sk_last_error(ctx));
+            pool.rc = arc; by_other = 1;
+        } else if (v[2]) {
+            if (pool.rc == SK_OK || pool.rc == SK_E_OPEN || pool.rc == SK_E_SPLIT) {
+                pool.rc = -(int)(uint32_t)v[2]; by_other = 1;
+                if (err) fprintf(err, "kmer_scrub_count: another rank reported an error while scanning %s: %s\n", list_path, sk_strerror(pool.rc));
+            }
+        } else if (v[0]) {
+            open_line = (uint32_t)((uint64_t)UINT32_MAX - (v[0] - 1));
+            if (!(pool.rc == SK_E_OPEN && pool.item[pool.rc_index].line == open_line)) by_other = 1;   /* (the line's owner says which file) */
+            pool.rc = SK_E_OPEN;
+        } else if (v[1]) {
+            if (pool.rc != SK_E_SPLIT) by_other = 1;
+            pool.rc = SK_E_SPLIT;
+        }
+    }
     if (!plan_only) {
         /* What the reference has said by now.  All went well: every progress line, every skip message.  A file could not be
          * opened: it stopped right there (src/genome_compare.c:195-198) -- the progress file ends with that file's line
          * (lines of later files that other decode threads had taken meanwhile are cut off again) and no skip message of a
-         * later line was printed.  (With several ranks only rank 0 writes, and knows only of its own failures.) */
+         * later line was printed.  (With several ranks only rank 0 writes; it knows the first failing line of ANY rank from
+         * the agreement above.) */
         uint32_t upto = pool.nll;
-        if (pool.rc == SK_E_OPEN) upto = pool.item[pool.rc_index].line + 1;
+        if (pool.rc == SK_E_OPEN) upto = (open_line != UINT32_MAX ? open_line : pool.item[pool.rc_index].line) + 1;
         if (pool.rc == SK_OK || pool.rc == SK_E_OPEN) {
             if (upto) progress_upto(&pool, upto - 1);
             if (pool.progress && upto < pool.ll_next && upto > 0 && fflush(pool.progress) == 0 &&
                 ftruncate(fileno(pool.progress), (off_t)pool.ll[upto - 1].end) == 0)
                 fseek(pool.progress, pool.ll[upto - 1].end, SEEK_SET);
         }
-        if (err && rank == 0 && !(pool.rc == SK_E_SPLIT && guard && guard->armed))
+        if (err && rank == 0 && (pool.rc == SK_OK || pool.rc == SK_E_OPEN))
             for (i = 0; i < upto; i++)
                 if (pool.ll[i].skipped) fprintf(err, "skipping %s (identical match)\n", pool.ll[i].text);
     }
-    if (plan_only) {
-        /* (said above, or nothing to say) */
+    if (plan_only || by_other) {
+        /* (said above or by the rank it happened to, or nothing to say) */
     } else if (pool.rc == SK_E_OPEN) {
         if (err) fprintf(err, "could not read file %s in GEN_calculate_kmer_count()\n", pool.item[pool.rc_index].path);
     } else if (pool.rc == SK_E_SPLIT && guard && guard->armed) {
@@ -1459,18 +1523,18 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
 }
 
 static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
-                          FILE *err, uint32_t rank, uint32_t world, uint64_t *bases, int plan_only, const plan_report *report)
+                          FILE *err, uint32_t rank, uint32_t world, uint64_t *bases, int plan_only, const plan_report *report, int no_split)
 {
     split_guard guard = {NULL, -1, 0};
-    int rc = scan_list_once(ctx, list_path, skip, col, progress, err, rank, world, bases, plan_only, report, 0, &guard);
-    if (rc == SK_E_SPLIT && guard.armed) {
+    int rc = scan_list_once(ctx, list_path, skip, col, progress, err, rank, world, bases, plan_only, report, no_split, &guard);
+    if (rc == SK_E_SPLIT && guard.armed) {               /* (armed on every rank of a coordinated run, or on none) */
         rc = sk_counts_set(ctx, col, guard.snap);
         if (rc == SK_OK && progress && guard.prog_at >= 0 && fflush(progress) == 0 && ftruncate(fileno(progress), (off_t)guard.prog_at) == 0)
             fseek(progress, guard.prog_at, SEEK_SET);
-        if (rc == SK_OK) {
-            if (getenv("SK_TIMING") && err) fprintf(err, "kmer_scrub_count timing: a cut of %s did not hold; the list is scanned again uncut\n", list_path);
-            rc = scan_list_once(ctx, list_path, skip, col, progress, err, rank, world, bases, plan_only, report, 1, NULL);
-        }
+        if (rc != SK_OK && err) fprintf(err, "kmer_scrub_count: could not put the counters back: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx));
+        if (getenv("SK_TIMING") && err && rc == SK_OK) fprintf(err, "kmer_scrub_count timing: a cut of %s did not hold; the list is scanned again uncut\n", list_path);
+        /* the second scan opens with an agreement too: a rank whose restore failed says so there and everybody leaves */
+        rc = scan_list_once(ctx, list_path, skip, col, progress, err, rank, world, bases, plan_only, report, rc == SK_OK ? 1 : 2, NULL);
     }
     free(guard.snap);
     return rc;
@@ -1479,21 +1543,27 @@ static int scan_list_impl(sk_ctx *ctx, const char *list_path, const char *skip, 
 int skh_scan_list(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
                   FILE *err, uint32_t rank, uint32_t world, uint64_t *bases)
 {
-    return scan_list_impl(ctx, list_path, skip, col, progress, err, rank, world, bases, 0, NULL);
+    return scan_list_impl(ctx, list_path, skip, col, progress, err, rank, world, bases, 0, NULL, 0);
+}
+
+int skh_scan_list_uncut(sk_ctx *ctx, const char *list_path, const char *skip, uint32_t col, FILE *progress,
+                        FILE *err, uint32_t rank, uint32_t world, uint64_t *bases)
+{
+    return scan_list_impl(ctx, list_path, skip, col, progress, err, rank, world, bases, 0, NULL, 1);
 }
 
 int skh_list_plan_hash(const char *list_path, const char *skip, uint32_t world, uint64_t *hash)
 {
     plan_report rp = {hash, NULL, 0, NULL};
     if (!list_path || !hash) return SK_E_ARG;
-    return scan_list_impl(NULL, list_path, skip, 0, NULL, NULL, 0, world ? world : 1, NULL, 1, &rp);
+    return scan_list_impl(NULL, list_path, skip, 0, NULL, NULL, 0, world ? world : 1, NULL, 1, &rp, 0);
 }
 
 int skh_list_plan_owners(const char *list_path, const char *skip, uint32_t world, uint32_t *owner, uint32_t cap, uint32_t *nlines)
 {
     plan_report rp = {NULL, owner, cap, nlines};
     if (!list_path || !nlines || (cap && !owner)) return SK_E_ARG;
-    return scan_list_impl(NULL, list_path, skip, 0, NULL, NULL, 0, world ? world : 1, NULL, 1, &rp);
+    return scan_list_impl(NULL, list_path, skip, 0, NULL, NULL, 0, world ? world : 1, NULL, 1, &rp, 0);
 }
 
 /* =========================================================================================
@@ -1584,7 +1654,8 @@ static int env_int(const char *a, const char *b, const char *c3, int dflt)
  *   SK_RCCL_ID_FILE (rendezvous file for the RCCL unique id; default /tmp/sk_rccl_id.<MASTER_PORT|uid>).
  * List items (files, byte ranges of big plain-text files) are dealt to the ranks by size -- the same plan on every rank,
  * compared before anyone scans (SK_E_PLAN) --, every rank's counters are summed with one RCCL all-reduce, rank 0 alone
- * writes stdout, the progress file and the skip/progress messages. */
+ * writes stdout, the progress file and the skip/progress messages.  The sequence of collectives is the same on every rank
+ * whatever fails where: set-up (in the rendezvous), table load (one sum), per list scan two agreements, one sum, the all-reduce. */
 int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
 {
     const char *A = NULL, *B = NULL, *C = NULL, *R = NULL, *P = NULL, *env;
@@ -1713,11 +1784,21 @@ int skh_kmer_scrub_count_main(int argc, char **argv, FILE *out, FILE *err)
         failed = 1;
     }
 
+    if (use_comm) {
+        /* a rank whose table did not load must not leave the others alone in the lists' agreements: from here to the big
+         * all-reduce every rank issues the same collectives (skh_scan_list returns the same status on all of them) */
+        rc = sk_comm_sum_u32(ctx, (uint32_t)failed, &nfailed);
+        if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
+        if (nfailed) {
+            if (!failed) fprintf(err, "kmer_scrub_count: another rank could not load the table; nothing is reported\n");
+            goto done;
+        }
+    }
     if (!failed && skh_scan_list(ctx, A, NULL, 1, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;
     if (!failed && skh_scan_list(ctx, B, NULL, 2, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;
     if (!failed && C && skh_scan_list(ctx, C, R, 3, progress, err, (uint32_t)rank, (uint32_t)world, NULL) != SK_OK) failed = 1;
     if (use_comm) {
-        /* agree first: a rank that could not read a file must not leave the others in the collective */
+        /* agree once more (the lists' own agreements have made `failed` the same everywhere: a belt to those braces) */
         rc = sk_comm_sum_u32(ctx, (uint32_t)failed, &nfailed);
         if (rc != SK_OK) { fprintf(err, "kmer_scrub_count: %s (%s)\n", sk_strerror(rc), sk_last_error(ctx)); goto done; }
         if (nfailed) goto done;

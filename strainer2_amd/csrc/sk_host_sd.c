@@ -964,8 +964,10 @@ static void sd_launch_ahead(sd_stream *st, sd_prog *p, uint32_t ns)
     const double t0 = now_s();
     if (!st->solo || !st->pre || st->ahead || getenv("SK_SD_NO_AHEAD")) return;
     if (sd_launch(p, ns, st->bat[st->bcur ^ 1]) == SK_OK) st->ahead = st->pre;
-    /* (a failed launch is not an error here: the chunk is launched again, and the error reported, when its turn comes --
-     * but scans that did start must be collected first: see stream_fill) */
+    else sd_drain_scans();
+    /* (a failed launch is not an error here: the chunk is launched again, and the error reported, when its turn comes -- but
+     * the launches that DID start before the one that failed are waited for first: a context takes one launch at a time, and
+     * their results are not collected -- ADVICE r03) */
     t_launch += now_s() - t0;
 }
 
@@ -1045,8 +1047,10 @@ static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *
     uint32_t j;
     char key[32];
     for (j = 0; j < n; j++) {
-        if (p->table_on_device && p->ks.packed[rows[j]] == 0 && skh_keyset_fetch_keys(&p->ks, p->ctx, &rows[j], 1) != SK_OK)
+        if (p->table_on_device && p->ks.packed[rows[j]] == 0 && skh_keyset_fetch_keys(&p->ks, p->ctx, &rows[j], 1) != SK_OK) {
             p->job_rc = SK_E_HIP;                            /* (a row whose key was not fetched with the informative ones: one at a time) */
+            return;                                          /* never print a line without its k-mer (a key of 0 would decode to thirty-one A's): the run fails */
+        }
         skh_keyset_key(&p->ks, rows[j], key);
         if (nl <= 3800) {
             unsigned char *w0 = skzo_reserve(p->zo, nl + 128), *w = w0;

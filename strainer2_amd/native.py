@@ -36,6 +36,8 @@ SK_KEY_NONE = 0xFFFFFFFFFFFFFFFF
 SK_OK = 0
 SK_E_NODEVICE = -1
 SK_E_OPEN = -5
+SK_E_SPLIT = -9
+SK_E_PLAN = -10
 
 # every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
@@ -43,10 +45,10 @@ ABI_SYMBOLS = [
     "sk_table_load_wide", "sk_table_load_text", "sk_table_build_from_text", "sk_table_export_keys", "sk_table_export_keys_of", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned",
     "sk_ticket_wait", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_set_rows", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
-    "sk_counts_allreduce", "sk_comm_init", "sk_comm_init_ex", "sk_rendezvous_exchange", "sk_comm_destroy", "sk_comm_sum_u32", "sk_comm_agree_u64", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
+    "sk_counts_allreduce", "sk_comm_init", "sk_comm_init_ex", "sk_rendezvous_exchange", "sk_comm_destroy", "sk_comm_sum_u32", "sk_comm_agree_u64", "sk_comm_max_u64", "sk_comm_world", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
     "sk_dev_upload", "sk_dev_download",
     "skh_keyset_from_file", "skh_keyset_from_stream", "skh_keyset_free", "skh_keyset_key",
-    "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_list_plan_hash", "skh_list_plan_owners", "skh_print_counts",
+    "skh_keyset_load", "skh_scan_file", "skh_scan_list", "skh_scan_list_uncut", "skh_list_plan_hash", "skh_list_plan_owners", "skh_print_counts",
     "skh_kmer_scrub_count_main", "skh_strain_detect_main", "skh_strain_detect_resident", "skh_decode_file",
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
@@ -119,6 +121,7 @@ lib.skh_list_plan_owners.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_voi
 lib.skh_list_plan_owners.restype = C.c_int
 lib.skh_scan_list.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p,
                               C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.skh_scan_list_uncut.argtypes = lib.skh_scan_list.argtypes
 lib.skh_print_counts.argtypes = [C.c_void_p, C.POINTER(_KeysetStruct), C.c_void_p, C.c_int]
 lib.skh_kmer_scrub_count_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
 lib.skh_decode_file.argtypes = [C.c_char_p, C.c_uint64, _SINK, C.c_void_p, C.POINTER(C.c_uint64)]
@@ -308,10 +311,14 @@ class KmerContext:
         self._ck(lib.skh_scan_file(self._h, os.fsencode(path), col, C.byref(bases)))
         return bases.value
 
-    def scan_list(self, list_path, col, skip=None, rank=0, world=1):
+    def scan_list(self, list_path, col, skip=None, rank=0, world=1, uncut=False):
+        """skh_scan_list; uncut=True: the whole-file plan (skh_scan_list_uncut).  With world > 1 and no in-library communicator
+        a cut that does not hold raises SKError(SK_E_SPLIT): use strainer2_amd.dist.scan_list_sharded, which agrees across
+        the ranks and scans again uncut."""
         bases = C.c_uint64(0)
-        self._ck(lib.skh_scan_list(self._h, os.fsencode(list_path), None if skip is None else os.fsencode(skip),
-                                   col, None, None, rank, world, C.byref(bases)))
+        fn = lib.skh_scan_list_uncut if uncut else lib.skh_scan_list
+        self._ck(fn(self._h, os.fsencode(list_path), None if skip is None else os.fsencode(skip),
+                    col, None, None, rank, world, C.byref(bases)))
         return bases.value
 
     @staticmethod

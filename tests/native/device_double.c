@@ -264,12 +264,102 @@ int sk_pinned_free(sk_ctx *c, void *p) { (void)c; free(p); return SK_OK; }
 int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64_t *t) { if (t) *t = 1; return sk_scan_stream(c, s, n, col); }
 int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return SK_OK; }
 int sk_sync(sk_ctx *c) { (void)c; return SK_OK; }
-int sk_comm_init(sk_ctx *c, int r, int w, const char *f, int t) { (void)c; (void)r; (void)w; (void)f; (void)t; return die("sk_comm_init"); }
-int sk_comm_init_ex(sk_ctx *c, int r, int w, const char *f, int t, int s) { (void)c; (void)r; (void)w; (void)f; (void)t; (void)s; return die("sk_comm_init_ex"); }
-int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s) { (void)c; (void)v; (void)s; return die("sk_comm_sum_u32"); }
-int sk_comm_agree_u64(sk_ctx *c, uint64_t v, int *a) { (void)c; (void)v; *a = 1; return SK_OK; }
-int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return die("sk_counts_zero"); }
-int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return die("sk_counts_allreduce"); }
+/* ---- a communicator for the multi-PROCESS CPU tests (tests/test_multirank_protocol.py).  DOUBLE_COMM_DIR names a fresh
+ * directory all ranks see.  Collective number k of rank r is the file c<k>.r<r> = {kind, element count, payload}; a rank
+ * writes its own, then waits (bounded: DOUBLE_COMM_TIMEOUT seconds, default 20) for every other rank's file of the SAME
+ * number and checks that kind and count are the same -- what RCCL needs to be true and cannot check: a mismatch (exit 98) or a
+ * rank that never arrives (exit 97) is exactly the hang ADVICE r03 found.  Every call is also appended to log.r<r>, so the
+ * test can compare the ranks' sequences line by line.  Without DOUBLE_COMM_DIR the collectives are outside the double, as before. */
+#include <time.h>
+#include <unistd.h>
+static struct { int on, rank, world, seq; char dir[400]; } g_comm;
+enum { DC_SUM_U32, DC_MAX_U64 };
+static int dc_collective(const char *kind, int op, void *buf, size_t count)
+{
+    const size_t esz = op == DC_SUM_U32 ? 4 : 8, bytes = count * esz;
+    char path[512], tmp[512], head[64], theirs[64];
+    unsigned char *acc = malloc(bytes + 1), *in = malloc(bytes + 1);
+    const double limit = getenv("DOUBLE_COMM_TIMEOUT") ? atof(getenv("DOUBLE_COMM_TIMEOUT")) : 20.0;
+    FILE *f;
+    int r;
+    size_t i;
+    g_comm.seq++;
+    snprintf(head, sizeof head, "%s %zu", kind, count);
+    snprintf(path, sizeof path, "%s/log.r%d", g_comm.dir, g_comm.rank);
+    if ((f = fopen(path, "a")) != NULL) { fprintf(f, "%s\n", head); fclose(f); }
+    snprintf(tmp, sizeof tmp, "%s/c%d.r%d.tmp", g_comm.dir, g_comm.seq, g_comm.rank);
+    snprintf(path, sizeof path, "%s/c%d.r%d", g_comm.dir, g_comm.seq, g_comm.rank);
+    if (!(f = fopen(tmp, "wb"))) return die("double comm: cannot write");
+    fwrite(head, 1, sizeof head, f); fwrite(buf, 1, bytes, f); fclose(f);
+    rename(tmp, path);
+    memcpy(acc, buf, bytes);
+    for (r = 0; r < g_comm.world; r++) {
+        struct timespec t0, t1, nap = {0, 1000000};
+        if (r == g_comm.rank) continue;
+        snprintf(path, sizeof path, "%s/c%d.r%d", g_comm.dir, g_comm.seq, r);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        while (!(f = fopen(path, "rb"))) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit) {
+                fprintf(stderr, "double comm: rank %d waited %.0f s for rank %d in collective #%d (%s): the ranks' sequences differ\n",
+                        g_comm.rank, limit, r, g_comm.seq, head);
+                exit(97);
+            }
+            nanosleep(&nap, NULL);
+        }
+        if (fread(theirs, 1, sizeof theirs, f) != sizeof theirs || strcmp(theirs, head) != 0) {
+            fprintf(stderr, "double comm: collective #%d is '%s' on rank %d and '%s' on rank %d\n", g_comm.seq, head, g_comm.rank, theirs, r);
+            exit(98);
+        }
+        if (fread(in, 1, bytes, f) != bytes) { fprintf(stderr, "double comm: short payload\n"); exit(98); }
+        fclose(f);
+        if (op == DC_SUM_U32) for (i = 0; i < count; i++) ((uint32_t *)acc)[i] += ((uint32_t *)in)[i];
+        else for (i = 0; i < count; i++) if (((uint64_t *)in)[i] > ((uint64_t *)acc)[i]) ((uint64_t *)acc)[i] = ((uint64_t *)in)[i];
+    }
+    memcpy(buf, acc, bytes);
+    free(acc); free(in);
+    return SK_OK;
+}
+int sk_comm_init_ex(sk_ctx *c, int r, int w, const char *f, int t, int s)
+{
+    uint32_t bad = s != 0;
+    (void)c; (void)f; (void)t;
+    if (!getenv("DOUBLE_COMM_DIR")) return die("sk_comm_init_ex");
+    g_comm.on = 1; g_comm.rank = r; g_comm.world = w; g_comm.seq = 0;
+    snprintf(g_comm.dir, sizeof g_comm.dir, "%s", getenv("DOUBLE_COMM_DIR"));
+    dc_collective("rendezvous", DC_SUM_U32, &bad, 1);        /* (the real one: sk_rendezvous.h, every rank learns of a failed set-up) */
+    return bad ? SK_E_RCCL : SK_OK;
+}
+int sk_comm_init(sk_ctx *c, int r, int w, const char *f, int t) { return sk_comm_init_ex(c, r, w, f, t, 0); }
+int sk_comm_world(const sk_ctx *c) { (void)c; return g_comm.on ? g_comm.world : 0; }
+int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s)
+{
+    (void)c;
+    if (!g_comm.on) return die("sk_comm_sum_u32");
+    *s = v;
+    return dc_collective("sum_u32", DC_SUM_U32, s, 1);
+}
+int sk_comm_max_u64(sk_ctx *c, uint64_t *v, uint32_t n)
+{
+    (void)c;
+    if (!g_comm.on) return SK_OK;                             /* no communicator: the values stay */
+    return dc_collective("max_u64", DC_MAX_U64, v, n);
+}
+int sk_comm_agree_u64(sk_ctx *c, uint64_t v, int *a)
+{
+    uint64_t h[2];
+    h[0] = v; h[1] = ~v;
+    sk_comm_max_u64(c, h, 2);
+    *a = h[0] == v && h[1] == ~v;
+    return SK_OK;
+}
+int sk_counts_zero(sk_ctx *c, uint32_t col) { memset(c->cols + (size_t)col * c->n, 0, (size_t)c->n * 4); return SK_OK; }
+int sk_counts_allreduce(sk_ctx *c, void *comm)
+{
+    (void)comm;
+    if (!g_comm.on) return die("sk_counts_allreduce");
+    return dc_collective("allreduce_u32", DC_SUM_U32, c->cols, (size_t)c->n * c->ncols);
+}
 int skh_scrub_filter_resident(sk_ctx *c, const skh_keyset *k, int d, double m, int i, FILE *o, FILE *e) { (void)c; (void)k; (void)d; (void)m; (void)i; (void)o; (void)e; return die("skh_scrub_filter_resident"); }
 
 int sk_first_seen_count(sk_ctx *ctx, const uint32_t *id, const uint32_t *sample, uint64_t n, uint32_t nids, uint32_t ns, uint64_t *uniq, uint64_t *total)

@@ -29,6 +29,8 @@ int sk_comm_init_ex(sk_ctx *c, int r, int w, const char *f, int t, int s) { (voi
 int skh_strain_detect_resident(sk_ctx *c, skh_keyset *k, const char *a, int n, char **v, FILE *o, FILE *e) { (void)c; (void)k; (void)a; (void)n; (void)v; (void)o; (void)e; return unreachable("skh_strain_detect_resident"); }
 int sk_comm_sum_u32(sk_ctx *c, uint32_t v, uint32_t *s) { (void)c; (void)v; (void)s; return unreachable("sk_comm_sum_u32"); }
 int sk_comm_agree_u64(sk_ctx *c, uint64_t v, int *a) { (void)c; (void)v; *a = 1; return SK_OK; }
+int sk_comm_max_u64(sk_ctx *c, uint64_t *v, uint32_t n) { (void)c; (void)v; (void)n; return SK_OK; }
+int sk_comm_world(const sk_ctx *c) { (void)c; return 0; }
 int sk_counts_zero(sk_ctx *c, uint32_t col) { (void)c; (void)col; return unreachable("sk_counts_zero"); }
 int sk_counts_allreduce(sk_ctx *c, void *comm) { (void)c; (void)comm; return unreachable("sk_counts_allreduce"); }
 int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t n) { (void)c; (void)p; (void)n; return unreachable("sk_pinned_alloc"); }

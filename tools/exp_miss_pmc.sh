@@ -1,8 +1,13 @@
+# usage (GPU box): bash tools/exp_miss_pmc.sh [NAME]   -- NAME = a variant built by tools/exp_variant_build.sh into build_exp/libsk_NAME.so
+#                                                       (default: the library that ships)
 export TMPDIR=/tmp
 V=base_h0,l2hit_h2,nofilt_h2,base_h2
 OUT=gpurun_out/exp_miss
 mkdir -p $OUT
-export SK_LIBRARY=$PWD/strainer2_amd/lib/libsk_exp_lazy0.so
+if [ -n "$1" ]; then
+  export SK_LIBRARY=$PWD/build_exp/libsk_$1.so
+  [ -f "$SK_LIBRARY" ] || { echo "no $SK_LIBRARY: run tools/exp_variant_build.sh $1 ... first"; exit 1; }
+fi
 i=0
 for PMC in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))

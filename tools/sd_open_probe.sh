@@ -7,6 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 WORK=/dev/shm/sk_open_probe
 OUT=$ROOT/gpurun_out/sd_open_probe
 mkdir -p $OUT
+trap 'rm -rf $WORK' EXIT                 # (the inputs live in memory: they go whatever happens below)
 python3 - <<PY
 import sys
 sys.path.insert(0, "$ROOT")
@@ -19,5 +20,4 @@ cat $OUT/plain_timing.txt
 export TMPDIR=/tmp
 SK_LEAK_AT_EXIT=0 SK_SD_TIMING=1 rocprofv3 --hip-trace --kernel-trace --stats -d $OUT/prof -o sd -- $ROOT/strainer2_amd/bin/strain_detect -S strains_prefix.txt -b prefix.fa -t SE > $OUT/rocprof.log 2>&1 || true
 ls $OUT/prof | head
-find $OUT/prof -name "*hip_api_stats.csv" -exec head -30 {} ;
-rm -rf $WORK
+find $OUT/prof -name "*hip_api_stats.csv" -exec head -30 {} \;
