@@ -422,6 +422,7 @@ def main():
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of reads drawn from the strain (cfg 2: 0.02)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-sd", action="store_true", help="skip the strain_detect (TALLY/UNION kernel) side measurement")
+    ap.add_argument("--sd-only", action="store_true", help="only the strain_detect side leg (for tools/profile.sh --sd): prints its object, no `value`")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive host-buffer passes (keeps profiles clean)")
     ap.add_argument("--file-reads", type=int, default=1_000_000, help="reads per FASTQ file of the file-fed, rank-sharded side measurement (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -437,6 +438,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world and --gpus must be the same")
+
+    if args.sd_only:                                            # (profiles of sk_scan_grid<TALLY,UNION>: nothing else on the card)
+        if world != 1:
+            raise SystemExit("--sd-only is a single-GPU measurement")
+        print(json.dumps({"metric": "strain_detect side leg only (not the headline metric)", "value": None, "n_gpus": 1,
+                          "strain_detect": strain_detect_leg(0)}), flush=True)
+        return
 
     from strainer2_amd import synth
     contigs = synth.make_strain(total_bp=args.strain_bp)

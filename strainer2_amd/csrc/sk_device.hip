@@ -351,6 +351,40 @@ __device__ __forceinline__ void sk_decode4o(uint32_t w, uint32_t &codes8, uint32
     odd |= __builtin_amdgcn_perm(0x474EFF54u, 0x430A41FFu, sel) ^ u;       // 0 <=> every byte is one of A C G T a c g t N n '\n'
 }
 
+// Phase 1's decode of a whole 16-byte chunk (round 4: the kernel is bound by vector instructions, and the decode is nearly half of
+// them -- 72 per chunk in the word-by-word form above, 53 here).  Same results, bit for bit:
+//   code32  the chunk's packed 16-mer, first base in bits 31..30 (A0 C1 G2 T3; 0 for bytes that are no A/C/G/T)
+//   inv16   bit i <=> byte i is not A/C/G/T (any case)
+//   oddw    non-zero <=> some byte is neither A/C/G/T, N/n nor '\n' (a byte only the byte-string kernel can judge)
+// What changed: (1) the four 2-bit codes of a word, and the four "invalid" flags of a word, are gathered by a byte dot product
+// (v_dot4_u32_u8: one instruction where a multiply and a shift stood; the flags of two words accumulate through its addend);
+// (2) the flag "this byte is not the letter its low three bits say it should be" is bit 7 of ((u ^ e) & 0x7F) + 0x7F OR'ed with
+// bit 7 of the BYTE instead of bit 7 of u ^ e (one instruction less: where e = 0xFF the low seven bits already differ -- a byte
+// whose low seven bits are all ones selects 'G' --, and where e is a letter its bit 7 is clear), with the ANDs and ORs folded into
+// three-input bit operations (v_bitop3_b32); (3) the case fold is two instructions, the odd-byte word two per input word.
+__device__ __forceinline__ void sk_decode16(const sk_u4 v, uint32_t &code32, uint32_t &inv16, uint32_t &oddw)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t r[4], f[4], odd = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t u   = __builtin_amdgcn_bitop3_b32(w[k], w[k] >> 1, 0x20202020u, 0x70);    // a & ~(b & c): letters upper-cased, everything else as it is
+        const uint32_t sel = w[k] & 0x07070707u;
+        const uint32_t cd  = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, sel);               // A0 C1 G2 T3, a byte each
+        r[k] = __builtin_amdgcn_udot4(cd, 0x01041040u, 0u, false);                               // first base x 64 + ... + fourth x 1
+        const uint32_t e   = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, sel);               // the letter the byte would have to be (0xFF: none)
+        const uint32_t t   = __builtin_amdgcn_bitop3_b32(u, e, 0x7F7F7F7Fu, 0x28) + 0x7F7F7F7Fu;   // (a ^ b) & c, + 0x7F: bit 7 <=> the low seven bits differ
+        f[k] = __builtin_amdgcn_bitop3_b32(t, w[k], 0x80808080u, 0xA8);                          // (a | b) & c: 0x80 where the byte is no A/C/G/T
+        const uint32_t px  = __builtin_amdgcn_perm(0x474EFF54u, 0x430A41FFu, sel);               // ... N and '\n' expected as well
+        odd = __builtin_amdgcn_bitop3_b32(odd, px, u, 0xF6);                                      // a | (b ^ c)
+    }
+    code32 = (((((r[0] << 8) + r[1]) << 8) + r[2]) << 8) + r[3];
+    const uint32_t lo = __builtin_amdgcn_udot4(f[1], 0x80402010u, __builtin_amdgcn_udot4(f[0], 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(f[3], 0x80402010u, __builtin_amdgcn_udot4(f[2], 0x08040201u, 0u, false), false);
+    inv16 = ((hi << 8) + lo) >> 7;                                                                // (the flags are 0x80 each: everything x 128)
+    oddw = odd;
+}
+
 // Among the (few) non-ACGT bytes of a 16-byte chunk, is there one that is neither N/n nor '\n'?
 // Such a byte can only be judged by the exact byte-string kernel.  inv16 = the chunk's mask.
 __device__ __forceinline__ uint32_t sk_chunk_has_odd_byte(const sk_u4 v, uint32_t inv16)
@@ -367,39 +401,6 @@ __device__ __forceinline__ uint32_t sk_chunk_has_odd_byte(const sk_u4 v, uint32_
     return odd;
 }
 
-// ---- phase 1, the cheap form (SK_LAZY_MASKS = 1; an EXPERIMENT of round 3, off: it removes a third of the kernel's vector
-// instructions and changes the launch time by less than 1 % without strain reads, and costs 10-17 % with many of them -- the
-// kernel is not bound by vector issue): codes for every byte, but of the validity only what EVERY chunk needs ----
-// Phase 2 asks of a chunk only "is every byte A/C/G/T?", and the byte-string kernel's work list only "is there a byte that is
-// neither A/C/G/T nor N/n nor the separator?".  Both are ONE comparison per chunk on the OR of four words that are zero where a
-// byte is as wanted: d = expected letter (by the byte's low three bits) ^ the byte with its case folded, and x = the same with
-// 'N' and the separator expected as well.  The exact 16-bit "not ACGT" mask -- 5 operations per word to squeeze out of d, and
-// before round 3 a loop over its set bits to tell N and the separator from the rest -- is wanted only by stage 2, and only
-// for the two neighbours of a SURVIVING chunk (the strain's reads: 2 % of the chunks at cfg 2): those few are worked out there,
-// from the stream's bytes (sk_exact_inv16), when the record says "not clean" (mask field 0xFFFF).
-// Case folding touches letters only (bit 6 set): '*' (0x2A) must not turn into the separator (0x0A).
-__device__ __forceinline__ void sk_decode4_lazy(uint32_t w, uint32_t &codes8, uint32_t &d, uint32_t &x)
-{
-    const uint32_t sel = w & 0x07070707u;
-    const uint32_t cd  = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, sel);   // A0 C1 G2 T3
-    codes8 = (cd * 0x40100401u) >> 24;
-    const uint32_t u   = w & ~((w >> 1) & 0x20202020u);                           // lower-case letters -> upper case
-    d = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, sel) ^ u;                 // 0 <=> A/C/G/T (0xFF: no folded byte is that)
-    x = __builtin_amdgcn_perm(0x474EFF54u, 0x430A41FFu, sel) ^ u;                 // 0 <=> A/C/G/T, N/n or '\n'
-}
-// the exact "not ACGT" mask of a chunk's 16 bytes (bit i <=> byte i), the same bits sk_decode4 gives
-__device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
-{
-    uint32_t c, i0, i1, i2, i3;
-    sk_decode4(v.x, c, i0);
-    sk_decode4(v.y, c, i1);
-    sk_decode4(v.z, c, i2);
-    sk_decode4(v.w, c, i3);
-    return i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
-}
-#ifndef SK_LAZY_MASKS
-#define SK_LAZY_MASKS 0                      // measured (profiles/r03_kernel_experiments.txt): a third fewer vector instructions and NO gain
-#endif
 #ifndef SK_PRIO_BASE
 #define SK_PRIO_BASE 0                       // ... the decode section's priority
 #endif
@@ -437,30 +438,6 @@ __device__ __forceinline__ uint32_t sk_exact_inv16(const sk_u4 v)
 #else
 #define SK_PHASE(k) do { } while (0)
 #endif
-#ifndef SK_L2_LANES
-#define SK_L2_LANES 1                      // phase 2's second and third questions: the chunks to be asked compacted over the wave, one per lane (0: every thread its own)
-#endif
-#ifndef SK_L2_K
-#define SK_L2_K 2                          // ... chunks per round (4: -3 %, 2: -4.7 % with no strain reads)
-#endif
-// ... of the chunk at stream offset off; a chunk that sticks out of the batch (its first and last tiles only) is put together
-// byte by byte, '\n' where there is nothing -- out of line, so that the rare case costs the scan kernel no registers
-__device__ __noinline__ uint32_t sk_exact_inv16_edge(const uint8_t *__restrict__ stream, uint64_t nbytes, int64_t off)
-{
-    uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-#pragma nounroll
-    for (int i = 0; i < 16; i++) {
-        const int64_t p = off + i;
-        if (p >= 0 && (uint64_t)p < nbytes) w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
-    }
-    return sk_exact_inv16((sk_u4){w[0], w[1], w[2], w[3]});
-}
-__device__ __forceinline__ uint32_t sk_exact_inv16_at(const uint8_t *__restrict__ stream, uint64_t nbytes, int64_t off)
-{
-    if (off >= 0 && (uint64_t)off + 16u <= nbytes) return sk_exact_inv16(*(const sk_u4 *)(stream + off));
-    return sk_exact_inv16_edge(stream, nbytes, off);
-}
-
 __device__ __forceinline__ uint32_t sk_revcomp32(uint32_t x)              // 16 packed bases
 {
     uint32_t y = __builtin_bitreverse32(x);
@@ -597,6 +574,19 @@ __device__ __forceinline__ sk_u4 sk_stream_load(const sk_u4 *p)
 #endif
 }
 
+// the first `keep` (< 16) bytes of a chunk, '\n' behind them
+__device__ __forceinline__ sk_u4 sk_mask_tail(sk_u4 v, uint32_t keep)
+{
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = (int)keep - 4 * j;                           // bytes of this word that are kept
+        const uint32_t m = k >= 4 ? 0xFFFFFFFFu : k <= 0 ? 0u : (1u << (8 * k)) - 1u;
+        w[j] = (w[j] & m) | (0x0A0A0A0Au & ~m);
+    }
+    return (sk_u4){w[0], w[1], w[2], w[3]};
+}
+
 // one 16-byte chunk of the stream at byte offset off (may start before 0 or end beyond nbytes: '\n' fill there)
 __device__ __forceinline__ sk_u4 sk_load_chunk(const uint8_t *__restrict__ stream, uint64_t nbytes, int64_t off)
 {
@@ -613,8 +603,14 @@ __device__ __forceinline__ sk_u4 sk_load_chunk(const uint8_t *__restrict__ strea
 // CAND: third pass of the partitioned pipeline (sk_bin -> sk_lds_probe -> this): `cand` holds one byte per chunk of the
 // batch, non-zero for the chunks the LDS-resident filter slices could not rule out; only those chunks (and the lines
 // around them) are read and looked at.
+// Scalar registers decide how many workgroups a CU admits: <= 80 -> 8 of these 256-thread groups, 81..96 -> 7, 97..112 -> 6
+// (MI355X_MICROARCH.md, "Residency").  The COUNT kernel is held at 80, the TALLY kernels at 96 (round 3: 100 and 94 = 6 and 7 groups).
 template <bool TALLY, int ABLATE, bool CAND, bool UNION = false>
+#if defined(SK_NO_SGPR_CAP)                                       // (A/B builds: round 3's register budget -- TALLY 100 scalar registers = 6 groups per CU, UNION 94 = 7)
 __global__ __launch_bounds__(SK_THREADS)
+#else
+__global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_sgpr(80)))
+#endif
 void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t emit_begin,
                   sk_table_view table, sk_sink sink, uint32_t *__restrict__ flags, const uint8_t *__restrict__ cand)
 {
@@ -626,14 +622,11 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
     // would otherwise serialise on a few words in the L2 (same-address atomics).
     __shared__ uint2 agg[SK_AGG];
 
-    const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
 #if SK_PHASE_CLOCK
     unsigned long long pc_last = __builtin_amdgcn_s_memtime();
 #endif
-    // the cheap phase 1 (sk_decode4_lazy): in COUNT mode; the TALLY kernels, short of scalar registers, keep the exact masks
-    constexpr bool LAZY = SK_LAZY_MASKS && !CAND && !TALLY;
     __shared__ uint32_t hl_n[2];                                  // TALLY: the hit log's LDS share (agg is free in that mode)
     if (!TALLY)
         for (uint32_t i = tid; i < SK_AGG; i += SK_THREADS) agg[i] = make_uint2(0xFFFFFFFFu, 0u);   // (visible after phase 1's barrier)
@@ -642,16 +635,16 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         sink.lds_hits = agg;
         sink.lds_n = hl_n;
     }
-
-    // ================= phase 1: bytes -> packed codes + invalid masks ==========================
-    // All of a thread's 16-byte loads are issued before the first is decoded (nine HBM latencies in
-    // flight instead of one after the other); tiles at the ends of the batch take the byte-wise path.
+    const uint64_t tile0 = (uint64_t)blockIdx.x * SK_TILE;        // stream offset of the tile's first chunk
     uint32_t bad = 0;
-    uint32_t candm = 0xFFu;                                        // this thread's chunks that are candidates (CAND)
-    if (!CAND) {
-        constexpr int NIT = (SK_NCHUNK_GRID + SK_THREADS - 1) / SK_THREADS;
-        sk_u4 vv[NIT];
-        const bool inside = tile0 >= SK_SPAN && tile0 + SK_TILE + 16u <= nbytes;      // (workgroup-uniform)
+
+    // A tile's stream loads: all of a thread's 16-byte loads are issued together (nine HBM latencies in flight instead of one
+    // after the other), at raised wave priority -- a wave that starts a tile must not take turns, instruction by instruction, with
+    // the waves that decode or hash (round 3).  Tiles at the ends of the batch mask what lies outside it.
+    constexpr int NIT = CAND ? 1 : (SK_NCHUNK_GRID + SK_THREADS - 1) / SK_THREADS;
+    sk_u4 vv[NIT];
+    auto issue_loads = [&](uint64_t t0) {
+        const bool inside = t0 >= SK_SPAN && t0 + SK_TILE + 16u <= nbytes;      // (workgroup-uniform)
 #if SK_PRIO & 1
         __builtin_amdgcn_s_setprio(SK_PRIO_LVL);
 #endif
@@ -660,51 +653,43 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
             for (int it = 0; it < NIT; it++) {
                 const uint32_t c = tid + (uint32_t)it * SK_THREADS;
                 vv[it] = (sk_u4){0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-                if (c < SK_NCHUNK_GRID) vv[it] = sk_stream_load((const sk_u4 *)(stream + (tile0 - SK_SPAN) + (uint64_t)c * 16u));
+                if (c < SK_NCHUNK_GRID) vv[it] = sk_stream_load((const sk_u4 *)(stream + (t0 - SK_SPAN) + (uint64_t)c * 16u));
             }
         } else {
+            // a tile at either end of the batch: chunks that lie outside it read as separators, and so do the bytes of the last chunk
+            // beyond the batch's end.  The chunk itself is loaded whole -- the stream is 16-byte aligned, so a chunk that begins
+            // inside the batch lies in a mapped page to its last byte
     #pragma unroll
-            for (int it = 0; it < NIT; it++) {                         // (unrolled: vv must stay in registers)
+            for (int it = 0; it < NIT; it++) {
                 const uint32_t c = tid + (uint32_t)it * SK_THREADS;
-                const int64_t off = (int64_t)tile0 - SK_SPAN + (int64_t)c * 16;
-                uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};       // '\n' fill
-                if (c < SK_NCHUNK_GRID)
-                    for (int i = 0; i < 16; i++) {
-                        const int64_t p = off + i;
-                        if (p >= 0 && (uint64_t)p < nbytes)
-                            w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3) * 8))) | ((uint32_t)stream[p] << ((i & 3) * 8));
-                    }
-                vv[it] = (sk_u4){w[0], w[1], w[2], w[3]};
+                const int64_t off = (int64_t)t0 - SK_SPAN + (int64_t)c * 16;
+                sk_u4 v = (sk_u4){0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};       // '\n' fill
+                if (c < SK_NCHUNK_GRID && off >= 0 && (uint64_t)off < nbytes) {
+                    v = sk_stream_load((const sk_u4 *)(stream + off));
+                    const uint64_t rem = nbytes - (uint64_t)off;
+                    if (rem < 16u) v = sk_mask_tail(v, (uint32_t)rem);
+                }
+                vv[it] = v;
             }
         }
 #if (SK_PRIO & 5) == 1
         __builtin_amdgcn_s_setprio(SK_PRIO_BASE);
 #endif
+    };
+    if (!CAND) issue_loads(tile0);
+
+    // ================= phase 1: bytes -> packed codes + invalid masks ==========================
+    uint32_t candm = 0xFFu;                                        // this thread's chunks that are candidates (CAND)
+    if (!CAND) {
         SK_PHASE(0);                                                 // start -> the tile's loads issued
     #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const uint32_t c = tid + (uint32_t)it * SK_THREADS;
             if (c < SK_NCHUNK_GRID) {
                 const sk_u4 v = vv[it];
-                uint32_t c0, c1, c2, c3, inv16;
-                bool odd;
-                if (LAZY) {
-                    uint32_t d0, d1, d2, d3, x0, x1, x2, x3;
-                    sk_decode4_lazy(v.x, c0, d0, x0);
-                    sk_decode4_lazy(v.y, c1, d1, x1);
-                    sk_decode4_lazy(v.z, c2, d2, x2);
-                    sk_decode4_lazy(v.w, c3, d3, x3);
-                    inv16 = (d0 | d1 | d2 | d3) ? 0xFFFFu : 0u;                  // 0xFFFF: "not clean; the exact mask on demand" (sk_exact_inv16)
-                    odd = (x0 | x1 | x2 | x3) != 0u;
-                } else {
-                    uint32_t i0, i1, i2, i3, oddw = 0u;
-                    sk_decode4o(v.x, c0, i0, oddw);
-                    sk_decode4o(v.y, c1, i1, oddw);
-                    sk_decode4o(v.z, c2, i2, oddw);
-                    sk_decode4o(v.w, c3, i3, oddw);
-                    inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
-                    odd = oddw != 0u;
-                }
+                uint32_t code32, inv16, oddw;
+                sk_decode16(v, code32, inv16, oddw);
+                const bool odd = oddw != 0u;
                 // bytes of the chunk after the tile belong to the next tile, which reports them itself
                 if (c < SK_NCHUNK && odd) {
                     bad = 1;
@@ -714,7 +699,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                     }
                 }
                 const uint32_t r = c >> 3, sl = c & 7u;
-                rec[r * SK_REC_DW + sl] = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+                rec[r * SK_REC_DW + sl] = code32;
                 ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)inv16;
             }
         }
@@ -837,7 +822,6 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         runpass = (members >> MARGIN) & m;
     }
 #endif
-#if SK_L2_LANES
     // Level 2, a CHUNK PER LANE (round 3, when the kernel had become bound by vector instructions).  The false positives of level 1 are
     // 7 % of the chunks: nearly every thread-wise loop over "my survivors" runs in every wave (some lane always has one), one or two
     // rounds of ~220 instructions for two or three busy lanes.  Here the chunks to be asked (level-1 survivors outside the runs that pass
@@ -874,11 +858,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                     const uint32_t cw  = rec[(cid >> 3) * SK_REC_DW + (cid & 7u)];
                     const uint32_t cwp = rec[((cid - 1u) >> 3) * SK_REC_DW + ((cid - 1u) & 7u)];
                     const uint32_t cwn = rec[((cid + 1u) >> 3) * SK_REC_DW + ((cid + 1u) & 7u)];
-                    uint32_t ivp = sk_chunk_inv(rec, cid - 1u), ivn = sk_chunk_inv(rec, cid + 1u);
-                    if (LAZY) {                                                              // (phase 1 only noted THAT a neighbour is not clean)
-                        if (ivp == 0xFFFFu) ivp = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid - 1u));
-                        if (ivn == 0xFFFFu) ivn = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid + 1u));
-                    }
+                    const uint32_t ivp = sk_chunk_inv(rec, cid - 1u), ivn = sk_chunk_inv(rec, cid + 1u);
                     const bool lv_ok = (ivp >> 8) == 0u, rv_ok = (ivn & 0xFFu) == 0u;        // the 8 bases borrowed from either neighbour are ACGT
                     const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
                     const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr);
@@ -907,98 +887,6 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         }
         m = m2;
     }
-#else
-    if (m && ABLATE != 5 && !CAND) {                              // (ABLATE 5, exact: no level 2, stage 2 sorts it out)                                                      // level 2 (rare for unrelated reads)
-        // A chunk right after one that passed level 2 is taken on its level-1 pass alone: inside a strain read
-        // every chunk passes anyway and the lookup (always an L2 miss) would buy nothing; a false positive of
-        // level 1 next to a level-2 pass is as rare as level 2's own false positives.  Pruning less is always
-        // exact: stage 2 verifies every window.
-        // (a loop over the set bits, not over the eight chunks: a thread rarely has more than one survivor of level 1,
-        // and the unrolled form cost every wave all eight bodies)
-        // Round 3.  What the false positives of level 1 cost is not the latency of their level-2 questions (asking them together
-        // changed nothing) but their NUMBER: 7 % of all chunks, each a random 64-byte line from a 32 MiB array that
-        // never stays in the L2 -- 2.4 M line fetches per 0.6 Gbase competing with the stream for the fabric: 0.082 ms of a
-        // 0.293 ms launch (ablation: the same kernel with level 1's verdicts dropped takes 0.211 ms).  Level 1 itself has room --
-        // its lookups are L2 hits and the L2 serves 60 % of the requests it could --, so a false positive is first asked two
-        // more L2 questions: every window of a chunk also holds the 16-mer that starts 8 bases before the chunk (the windows that
-        // begin 8..15 bases before it) or the one that starts 8 bases into it (the others); a chunk both of whose half-shifted
-        // 16-mers are strangers to the strain (or hold a non-ACGT byte) has no window left.  7 % -> ~1 % go on to level 2.
-        // (Round 2 tried the same question as eight unrolled bodies with their lookups one after the other: no gain.  Here: a
-        // round takes the first chunk of every run of survivors, at most SK_L2_K of them, all their lookups in flight together;
-        // the rest of a run follows its first chunk's verdict, as in the plain loop.)
-        uint32_t m2 = 0, pend = m;
-#if SK_RUN_PASS
-        m2 = runpass; pend = m & ~runpass;
-#endif
-        while (pend) {
-            uint32_t ap = pend & (m2 << 1);                       // right behind a chunk that passed: passes, and so on down the run
-            while (ap) { m2 |= ap; pend &= ~ap; ap = pend & (ap << 1); }
-            if (!pend) break;
-            uint32_t starts = pend & ~(pend << 1), st = starts, taken = 0u;
-            uint32_t ix[SK_L2_K], gl[SK_L2_K], gr[SK_L2_K], oks[SK_L2_K], w3[SK_L2_K][3];
-            uint2 bl[SK_L2_K], br[SK_L2_K];
-#pragma unroll
-            for (int k = 0; k < SK_L2_K; k++) {
-                ix[k] = 8u; gl[k] = gr[k] = oks[k] = 0u;
-                w3[k][0] = w3[k][1] = w3[k][2] = 0u;
-                bl[k] = br[k] = make_uint2(0u, 0u);
-                if (st) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(st);
-                    st &= st - 1u;
-                    taken |= 1u << i;
-                    const uint32_t cid = tid * SK_SPAN_CH + SK_SPAN_CH + i;                 // record 0 = the 8 chunks before the tile
-                    const uint32_t cw  = rec[(cid >> 3) * SK_REC_DW + (cid & 7u)];
-                    const uint32_t cwp = rec[((cid - 1u) >> 3) * SK_REC_DW + ((cid - 1u) & 7u)];
-                    const uint32_t cwn = rec[((cid + 1u) >> 3) * SK_REC_DW + ((cid + 1u) & 7u)];
-                    uint32_t ivp = sk_chunk_inv(rec, cid - 1u), ivn = sk_chunk_inv(rec, cid + 1u);
-                    if (LAZY) {                                                              // (phase 1 only noted THAT a neighbour is not clean)
-                        if (ivp == 0xFFFFu) ivp = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid - 1u));
-                        if (ivn == 0xFFFFu) ivn = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(cid + 1u));
-                    }
-                    const bool lv_ok = (ivp >> 8) == 0u, rv_ok = (ivn & 0xFFu) == 0u;        // the 8 bases borrowed from either neighbour are ACGT
-                    const uint32_t wl = __builtin_amdgcn_alignbit(cwp, cw, 16), wr = __builtin_amdgcn_alignbit(cw, cwn, 16);
-                    const uint32_t rl = sk_revcomp32(wl), rr = sk_revcomp32(wr);
-                    ix[k] = i;
-                    gl[k] = sk_gmix(wl < rl ? wl : rl); gr[k] = sk_gmix(wr < rr ? wr : rr);
-                    w3[k][0] = cwp; w3[k][1] = cw; w3[k][2] = cwn;
-                    oks[k] = (lv_ok ? 1u : 0u) | (rv_ok ? 2u : 0u);
-                    if (lv_ok) bl[k] = table.grid1[sk_grid1_block(gl[k], table.grid1_blocks)];
-                    if (rv_ok) br[k] = table.grid1[sk_grid1_block(gr[k], table.grid1_blocks)];
-                }
-            }
-            // level 2, keyed on 24-mers: a side whose half-shifted 16-mer the strain has is asked about its 24-mer (the chunk and the
-            // 8 bases on that side); the chunk goes on if either side's 24-mer is the strain's.  One side first (inside a strain read
-            // it passes, and the other side's question -- always a miss in the L2 -- would buy nothing), the other only if that fails.
-            uint32_t hb[SK_L2_K];
-            uint2 q2[SK_L2_K];
-#pragma unroll
-            for (int k = 0; k < SK_L2_K; k++) {
-                const bool al = ix[k] < 8u && (oks[k] & 1u) && sk_grid_test(bl[k], sk_grid1_bits(gl[k]));
-                const bool ar = ix[k] < 8u && (oks[k] & 2u) && sk_grid_test(br[k], sk_grid1_bits(gr[k]));
-                oks[k] = (al ? 1u : 0u) | (ar ? 2u : 0u);
-                q2[k] = make_uint2(0u, 0u);
-                hb[k] = 0u;
-                if (al | ar) {
-                    const uint64_t c24 = sk_canon24(al ? ((uint64_t)(w3[k][0] & 0xFFFFu) << 32) | w3[k][1] : ((uint64_t)w3[k][1] << 16) | (w3[k][2] >> 16));
-                    hb[k] = sk_h24_bits(c24);
-                    q2[k] = table.grid2[sk_grid2_block(sk_h24_block(c24), table.grid2_shift)];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < SK_L2_K; k++) {
-                if (!oks[k]) continue;
-                bool pass = sk_grid_test(q2[k], sk_grid2_bits(hb[k]));
-                if (!pass && oks[k] == 3u) {                                   // (both sides were candidates and the first is not the strain's)
-                    const uint64_t c24 = sk_canon24(((uint64_t)w3[k][1] << 16) | (w3[k][2] >> 16));
-                    pass = sk_grid_test(table.grid2[sk_grid2_block(sk_h24_block(c24), table.grid2_shift)], sk_grid2_bits(sk_h24_bits(c24)));
-                }
-                if (pass) m2 |= 1u << ix[k];
-            }
-            pend &= ~taken;
-        }
-        m = m2;
-    }
-#endif
 
     SK_PHASE(5);                                                     // the second and third questions
     if (ABLATE == 9) { if (m == 0x77u && tid == 100u) flags[3] = 1u; return; }                            // timing: phases 1 and 2 alone
@@ -1097,12 +985,6 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         if (act) {
             inv_prev = sk_chunk_inv(rec, ch + SK_SPAN_CH - 1u);
             inv_next = sk_chunk_inv(rec, ch + SK_SPAN_CH + 1u);
-            // a neighbour that is not clean: its exact mask, from the stream's bytes (phase 1 only noted THAT it is not clean;
-            // chunk index c of the records = bytes tile0 - SK_SPAN + 16 c ..., '\n' beyond the batch's ends as in phase 1)
-            if (LAZY) {
-                if (inv_prev == 0xFFFFu) inv_prev = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(ch + SK_SPAN_CH - 1u));
-                if (inv_next == 0xFFFFu) inv_next = sk_exact_inv16_at(stream, nbytes, (int64_t)tile0 - SK_SPAN + 16 * (int64_t)(ch + SK_SPAN_CH + 1u));
-            }
             const uint64_t v = ~((uint64_t)inv_prev | ((uint64_t)inv_next << 32)) & 0x0000FFFFFFFFFFFFull;
             uint64_t rr = v & (v << 1);
             rr &= rr << 2;

@@ -9,7 +9,12 @@ md5 + length of the TSV on stdout, per column sum / non-zero rows / max / md5 of
 stderr, and the progress file without its time stamps.  Prints one JSON object (kept as profiles/r03_cfg3_full_facts.txt);
 exit status 1 on any difference.
 
-  python3 tools/cfg3_full.py            (env: WORK, PROCS = writers, SK_THREADS = decode threads of the program, KEEP=1)
+  python3 tools/cfg3_full.py            (env: WORK, PROCS = writers, SK_THREADS = decode threads of the program, KEEP=1,
+                                        LIST_REPEAT=1: the -B files listed ONCE -- the facts hold the one-pass column of the
+                                        reference's run (metagenome_count_one_pass; the ten-fold list is that column x 10 mod 2^32),
+                                        so the job is as pinned as at x 10 and fits a test suite: 15.5 Gbase scanned.  What cannot be
+                                        compared then is the md5 of the whole TSV and of the progress file, which name the ten-fold
+                                        list; the progress file is checked line by line against the lists instead.)
 """
 import hashlib
 import json
@@ -35,7 +40,8 @@ def main():
     facts = json.load(open(FACTS))
     procs = int(os.environ.get("PROCS", "16"))
     t0 = time.time()
-    argv = cfg3.write_all(WORK, procs=procs, n_genomes=facts["genomes"], n_b=facts["b_files"], reads_per_file=facts["reads_per_file"],
+    repeat = int(os.environ.get("LIST_REPEAT", str(facts["list_repeat"])))
+    argv = cfg3.write_all(WORK, procs=procs, n_genomes=facts["genomes"], n_b=facts["b_files"], reads_per_file=facts["reads_per_file"], repeat=repeat,
                           progress=lambda n, m: print(f"  inputs {n}/{m} {time.time() - t0:.0f} s", file=sys.stderr, flush=True))
     t_write = time.time() - t0
     assert argv == facts["argv"]
@@ -65,13 +71,23 @@ def main():
            "stderr": stderr, "md5_progress_without_times": hashlib.md5(b"\n".join(prog)).hexdigest()}
     want = {k: facts[k] for k in ("stdout_md5", "stdout_bytes", "stdout_lines", "columns", "stderr", "md5_progress_without_times")}
     want["returncode"] = 0
-    diffs = [k for k in want if got[k] != want[k]]
     bases = sum(facts["bases_scanned"].values())
+    if repeat != facts["list_repeat"]:
+        assert repeat == 1, "the facts hold the ten-fold list and the one-pass column"
+        want["columns"] = dict(facts["columns"], metagenome_count=facts["metagenome_count_one_pass"])
+        for k in ("stdout_md5", "stdout_bytes", "md5_progress_without_times"):
+            del want[k]
+        # the progress file, line by line: the header, then every list line in order (-A, -B, -C; src/kmer_scrub_count.c:78-94)
+        lists = [open(os.path.join(WORK, argv[argv.index(f) + 1])).read().split("\n")[:-1] for f in ("-A", "-B", "-C")]
+        want["progress_lines"] = ["adding kmer counts for:"] + [ln for lst in lists for ln in lst] + [""]
+        got["progress_lines"] = [ln.decode() for ln in prog]
+        bases = facts["bases_scanned"]["A"] + facts["bases_scanned"]["B"] // facts["list_repeat"] + facts["bases_scanned"]["C"]
+    diffs = [k for k in want if got[k] != want[k]]
     report = {"job": facts["workload"], "facts": "tests/golden/cfg3_full_facts.json (" + facts["producer"] + ")",
               "identical_to_the_reference": not diffs, "differences": diffs,
-              "bases_scanned": facts["bases_scanned"], "wall_seconds_program": round(wall, 2), "bases_per_s_end_to_end": round(bases / wall),
+              "list_repeat": repeat, "bases_scanned_total": bases, "wall_seconds_program": round(wall, 2), "bases_per_s_end_to_end": round(bases / wall),
               "program_timing": timing, "decode_threads": os.environ.get("SK_THREADS", "default (CPU budget, at most 16)"),
-              "inputs_written_in_s": round(t_write, 1), "got": got}
+              "inputs_written_in_s": round(t_write, 1), "got": {k: v for k, v in got.items() if k != "progress_lines"}}
     print(json.dumps(report, indent=1))
     if not os.environ.get("KEEP"):
         shutil.rmtree(WORK, ignore_errors=True)

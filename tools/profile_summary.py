@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
         summary["kernels"][name] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]),
                                     "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"]),
                                     "pct": float(row["Percentage"])}
-for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     acc = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].split("(")[0]

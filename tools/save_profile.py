@@ -9,12 +9,31 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-src = os.path.join("gpurun_out", "prof_" + tag)
+# the NEWEST run of the tag (tools/profile.sh writes every run into gpurun_out/prof_TAG_<time>; gpurun merges them all into this
+# directory, so "the" run must be chosen, never globbed): by the directory's own time stamp in its name
+runs = sorted(d for d in glob.glob(os.path.join("gpurun_out", "prof_" + tag + "_*")) if os.path.isfile(os.path.join(d, "summary.json")))
+if not runs:
+    sys.exit(f"no run of tag {tag} under gpurun_out/ (tools/profile.sh {tag} on the GPU box first)")
+src = runs[-1]
 s = json.load(open(os.path.join(src, "summary.json")))
+want = "sk_scan_grid"
+kname = [n for n in s["kernels"] if want in n]
+if not kname:
+    sys.exit(f"{src}: no {want} in the kernel trace")
+# the kernel-stats file that is copied must be THIS run's: its average for the scan kernel is the one in summary.json
+import csv
+ks = os.path.join(src, "kernel_stats.csv")
+rows = [r for r in csv.DictReader(open(ks)) if want in r["Name"]]
+for r in rows:
+    avg = s["kernels"][r["Name"].split("(")[0]]["avg_ns"]
+    assert abs(float(r["AverageNs"]) - avg) < 1e-6 * max(avg, 1.0), f"{ks}: {r['Name'][:40]} averages {r['AverageNs']} ns, summary.json says {avg}"
+assert rows, f"{ks}: no {want} row"
 shutil.copy(os.path.join(src, "summary.txt"), f"profiles/{tag}_summary.txt")
 shutil.copy(os.path.join(src, "summary.json"), f"profiles/{tag}_summary.json")
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(ks, f"profiles/{tag}_kernel_stats.csv")
+if len(sys.argv) > 2 and sys.argv[2] == "--no-traffic":          # (a profile of another kernel/workload: profiles/traffic.json stays)
+    print(f"{tag}: copied from {src}")
+    sys.exit(0)
 c = [v for k, v in s["counters"].items() if "sk_scan_grid" in k][0]
 fetch, write = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
 bl = s.get("bench_line", {})
@@ -31,7 +50,7 @@ t = {"kernel": [n for n in s["kernels"] if "sk_scan_grid" in n][0].split("<")[0]
      "sk_device_hip_sha256": hashlib.sha256(open("strainer2_amd/csrc/sk_device.hip", "rb").read()).hexdigest(),
      "correction": "FETCH_SIZE raw + half of the record stream's bytes (gfx950: 128-B streaming requests are tallied at 64 B; "
                    "applied to the streaming share only, random lookups as counted) + WRITE_SIZE (exact). Separate --pmc passes (tools/profile.sh).",
-     "source": f"profiles/{tag}_summary.txt"}
+     "source": f"profiles/{tag}_summary.txt", "run": src}
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 k = [v for n, v in s["kernels"].items() if "sk_scan_grid" in n][0]
 print(f"{tag}: kernel-trace avg {k['avg_ns'] / 1e6:.3f} ms over {k['calls']} calls; bench events avg "

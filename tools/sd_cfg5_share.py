@@ -12,7 +12,8 @@ against a 100 Gbase SE metagenome (the 10 Gbase reads file of strainer2_amd/cfg5
      (same reads in the same order; only the file name in column 1 differs)
 Prints one JSON object (kept as profiles/r03_cfg5_share.json); exit status 1 on any difference.
 
-  python3 tools/sd_cfg5_share.py        (env: WORK, PROCS, KEEP=1, SKIP_FULL=1)
+  python3 tools/sd_cfg5_share.py        (env: WORK, PROCS, KEEP=1, SKIP_FULL=1; ONLY_PREFIX=1: write and run only the pinned prefix --
+                                        32 strains resident x 1 Gbase, what tests/test_scale_checks_gpu.py runs)
 """
 import gzip
 import hashlib
@@ -49,7 +50,8 @@ def main():
     assert facts["prefix_reads"] == cfg5.PREFIX_READS
     exe = os.path.join(REPO, "strainer2_amd", "bin", "strain_detect")
     t0 = time.time()
-    paths = cfg5.write_all(WORK, procs=int(os.environ.get("PROCS", "16")),
+    only_prefix = bool(os.environ.get("ONLY_PREFIX"))
+    paths = cfg5.write_all(WORK, procs=int(os.environ.get("PROCS", "16")), only_prefix=only_prefix,
                            progress=lambda n, m: print(f"  inputs {n}/{m} {time.time() - t0:.0f} s", file=sys.stderr, flush=True))
     t_write = time.time() - t0
     report = {"job": "strain_detect -S, %d strains x %d bp resident; SE FASTA of %d x %d bp reads (%.2f Gbase) listed %d times = %.1f Gbase scanned"
@@ -70,7 +72,7 @@ def main():
     report["prefix_%.1f_gbase_pinned" % (cfg5.PREFIX_READS * cfg5.READ_LEN / 1e9)] = pin
     report["facts"] = "tests/golden/cfg5_share_facts.json (" + facts["producer"] + ")"
     # ---- 3. the whole list
-    if not os.environ.get("SKIP_FULL"):
+    if not os.environ.get("SKIP_FULL") and not only_prefix:
         p, wall = run(exe, ["-S", paths["strains"], "-B", paths["B"]])
         timing, rest = split_timing(p.stderr)
         bases = cfg5.LIST_REPEAT * cfg5.READS * cfg5.READ_LEN

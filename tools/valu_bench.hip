@@ -70,6 +70,15 @@ KERNEL(k_cvt,      "v_cvt_f32_u32 %0, %0")
 KERNEL(k_mul_f32,  "v_mul_f32 %0, %0, %1")
 KERNEL(k_add_f32,  "v_add_f32 %0, %0, %1")
 KERNEL(k_fma,      "v_fma_f32 %0, %0, %1, %2")
+KERNEL(k_dot4,     "v_dot4_u32_u8 %0, %0, %1, %2")
+KERNEL(k_dot4acc,  "v_dot4_u32_u8 %0, %1, %2, %0")
+KERNEL(k_sad_u8,   "v_sad_u8 %0, %0, %1, %2")
+KERNEL(k_msad_u8,  "v_msad_u8 %0, %0, %1, %2")
+KERNEL(k_and_k,    "v_and_b32 %0, 0x7070707, %0")
+KERNEL(k_lshl1,    "v_lshlrev_b32 %0, 1, %0")
+KERNEL(k_add_self, "v_add_u32 %0, %0, %0")
+KERNEL(k_mul_i24,  "v_mul_i32_i24 %0, %0, %1")
+
 
 template <typename K> int run(const char *name, K k, uint32_t *out, int regs64)
 {
@@ -95,5 +104,6 @@ int main()
     R(k_add3) R(k_lshl_add) R(k_xad) R(k_bfrev) R(k_bitop3) R(k_cndmask) R(k_cmp) R(k_mbcnt)
     R(k_pk_mul16) R(k_pk_add16) R(k_pk_min16) R(k_fma) R(k_and) R(k_or) R(k_lshl) R(k_lshr) R(k_sub) R(k_not) R(k_min3) R(k_andor)
     R(k_min_f32) R(k_max_f32) R(k_min3_f32) R(k_max_u32) R(k_min_i32) R(k_cnd_e64) R(k_cmp_e64) R(k_cmp_f32) R(k_mov) R(k_or3) R(k_bfi) R(k_addlshl) R(k_bfe_i32) R(k_ashr) R(k_lshl_v) R(k_sdwa) R(k_cvt) R(k_mul_f32) R(k_add_f32)
+    R(k_dot4) R(k_dot4acc) R(k_sad_u8) R(k_msad_u8) R(k_and_k) R(k_lshl1) R(k_add_self) R(k_mul_i24)
     return 0;
 }
