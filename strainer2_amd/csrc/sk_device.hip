@@ -68,6 +68,7 @@ static_assert(SK_THREADS <= 256 && SK_THREADS % 64 == 0, "a tile's window number
 #define SK_AGG_LOG2     8
 #endif
 #define SK_AGG          (1u << SK_AGG_LOG2) // per-workgroup table of rows already counted in the tile
+#define SK_UNION_EAGER  16384u              // union tally: records and log entries that travel back with the counters (320 KiB of page-locked memory)
 #define SK_EV_PAIRS     64u                 // launches whose timing events are kept before they are added up
 #define SK_ODDCAP       (1u << 20)          // list of chunks with odd bytes; beyond it the byte-string kernel scans everything     // grid kernel: plus the chunk after the tile
 #ifndef SK_CHUNK_REJECT
@@ -418,9 +419,11 @@ __device__ __forceinline__ uint32_t sk_chunk_has_odd_byte(const sk_u4 v, uint32_
                                              // for the decode; 4 = kept up until the barrier.  A wave that starts a tile gets its nine loads out at once instead of
                                              // taking turns with the waves that decode: 0.724 -> 0.645 ms at cfg 2 (profiles/r03_kernel_experiments.txt, item 14)
 #endif
-#ifndef SK_SECOND_SEED
-#define SK_SECOND_SEED 0                    // stage 2: a stretch without a seed tries one more window before its windows go one by one.  Measured (experiments
-                                            // file, item 13): 1 % / 3 % divergence -5 % / -11 %, cfg 2 +1.4 %.  Off: the metric's workload decides.
+#ifndef SK_SEED2_MIN
+#define SK_SEED2_MIN 128                    // stage 2: in a wave with at least this many surviving chunks (of 512: a stretch of strain reads) a stretch without a seed
+                                            // tries one more window before its windows go one by one; 0 = never, 1 = always.  Round 3 measured the compile-time
+                                            // form: 1 % / 3 % divergence -5 % / -11 %, cfg 2 +1.4..2.7 % -- so the choice is made at run time, by the density the
+                                            // wave already knows (round 4): cfg 2's waves (ten survivors) never try, a diverged genome's always do
 #endif
 #ifndef SK_RUN_PASS
 #define SK_RUN_PASS 5                      // phase 2: this many level-1 survivors in a row (two more in a union table) go to stage 2 unquestioned;
@@ -1038,7 +1041,7 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
                         sl = (sl + 1u) & table.mask;
                     }
                 }
-                if (pass == 1 || !SK_SECOND_SEED || TALLY) break;          // (the TALLY kernels are short of scalar registers: one try there)
+                if (pass == 1 || !SK_SEED2_MIN || TALLY || nq < (uint32_t)SK_SEED2_MIN) break;   // (the TALLY kernels are short of scalar registers: one try there)
                 // A stretch none of whose seed windows is a k-mer of the strain (a differing base in it: 14 % of the windows at 0.5 %
                 // substitutions) used to send all its windows down the one-by-one path.  One more try first, with the window furthest from
                 // the first seed: the FIRST live window of the stretch's LAST chunk.  (wave-uniform: only when some stretch needs it)
@@ -3056,7 +3059,15 @@ extern "C" int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hi
     if ((rc = sk_scratch(c, &u->d_raw, &u->raw_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
     if ((rc = sk_scratch(c, &c->t_compact, &c->t_compact_cap, (size_t)vrec * 12 + 16)) != SK_OK) return rc;
     if ((rc = sk_scratch(c, &c->t_hits, &c->t_hits_cap, (size_t)(hits_cap ? hits_cap : 1) * sizeof(uint2))) != SK_OK) return rc;
-    if (!c->h_tally) { SK_HIP(c, hipHostMalloc((void **)&c->h_tally, 4096, hipHostMallocDefault)); c->h_tally_cap = 4096; }
+    // the page-locked landing area: the three counters, then room for the first SK_UNION_EAGER records and log entries, which come
+    // back WITH the counters (round 4: collecting used to be three dependent trips -- wait, copy the records, copy the log, the
+    // last two through pageable memory; a 32 MiB chunk against 32 strains brings ~4 K records and ~5 K entries, far below the room)
+    const size_t land = 64 + (size_t)SK_UNION_EAGER * (sizeof(sk_tally_rec) + sizeof(uint2));
+    if (c->h_tally_cap < land) {
+        if (c->h_tally) { SK_HIP(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_tally); c->h_tally = NULL; c->h_tally_cap = 0; }
+        SK_HIP(c, hipHostMalloc((void **)&c->h_tally, land, hipHostMallocDefault));
+        c->h_tally_cap = land;
+    }
     SK_HIP(c, hipStreamWaitEvent(c->stream, b->ready, 0));
     SK_HIP(c, hipMemsetAsync(u->d_cnt, 0, 32, c->stream));
     sk_sink sink;
@@ -3074,6 +3085,11 @@ extern "C" int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hi
                        (unsigned long long)hits_cap, (uint2 *)c->t_hits, u->d_cnt + 2, (unsigned long long)hits_cap,
                        (const uint64_t *)u->d_ukeys, (const uint2 *)u->d_umask, (const sk_union_member *)u->d_members);
     SK_HIP(c, hipMemcpyAsync(c->h_tally, u->d_cnt, 24, hipMemcpyDeviceToHost, c->stream));
+    {
+        const size_t er = vrec < SK_UNION_EAGER ? (size_t)vrec : (size_t)SK_UNION_EAGER, eh = hits_cap < SK_UNION_EAGER ? (size_t)hits_cap : (size_t)SK_UNION_EAGER;
+        if (er) SK_HIP(c, hipMemcpyAsync(c->h_tally + 64, c->t_compact, er * sizeof(sk_tally_rec), hipMemcpyDeviceToHost, c->stream));
+        if (eh) SK_HIP(c, hipMemcpyAsync(c->h_tally + 64 + (size_t)SK_UNION_EAGER * sizeof(sk_tally_rec), c->t_hits, eh * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    }
     SK_HIP(c, hipGetLastError());
     c->t_inflight_nrec = (uint32_t)vrec;
     c->t_inflight_cap = hits_cap;
@@ -3094,7 +3110,11 @@ extern "C" int sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t c
     unsigned long long cnt[3];
     memcpy(cnt, c->h_tally, 24);
     const unsigned long long take_r = cnt[1] < cap ? cnt[1] : cap;
-    if (take_r) SK_HIP(c, hipMemcpy(out, c->t_compact, (size_t)take_r * sizeof(sk_tally_rec), hipMemcpyDeviceToHost));
+    {   // what came back with the counters, then (rarely) the rest
+        const unsigned long long have = take_r < SK_UNION_EAGER ? take_r : SK_UNION_EAGER;
+        if (have) memcpy(out, c->h_tally + 64, (size_t)have * sizeof(sk_tally_rec));
+        if (take_r > have) SK_HIP(c, hipMemcpy(out + have, (const sk_tally_rec *)c->t_compact + have, (size_t)(take_r - have) * sizeof(sk_tally_rec), hipMemcpyDeviceToHost));
+    }
     *n = cnt[1];
     // the raw log holds one entry per hit, the caller gets one per hit AND strain: if the raw log itself ran over, entries are
     // missing from the count below -- report at least one more than the room there was
@@ -3102,7 +3122,11 @@ extern "C" int sk_union_tally_collect(sk_union *u, sk_tally_rec *out, uint64_t c
     if (cnt[0] > c->t_inflight_cap && nh <= c->t_inflight_cap) nh = cnt[0] > nh ? cnt[0] : c->t_inflight_cap + 1;
     const unsigned long long take = nh < c->t_inflight_cap ? nh : c->t_inflight_cap;
     if (take && !out_hits) return SK_E_ARG;
-    if (take) SK_HIP(c, hipMemcpy(out_hits, c->t_hits, (size_t)take * sizeof(uint2), hipMemcpyDeviceToHost));
+    {
+        const unsigned long long have = take < SK_UNION_EAGER ? take : SK_UNION_EAGER;
+        if (have) memcpy(out_hits, c->h_tally + 64 + (size_t)SK_UNION_EAGER * sizeof(sk_tally_rec), (size_t)have * sizeof(uint2));
+        if (take > have) SK_HIP(c, hipMemcpy(out_hits + have, (const uint2 *)c->t_hits + have, (size_t)(take - have) * sizeof(uint2), hipMemcpyDeviceToHost));
+    }
     *out_nhits = nh;
     return SK_OK;
 }

@@ -6,7 +6,11 @@
  * hits (a strain that really is in the metagenome) that was the whole run time.
  *
  * One pool (skzo_pool) serves any number of files (skzo_file); a file is appended to by one thread at a time.
- * SK_GZ_LEVEL sets the deflate level (default 6).
+ * SK_GZ_LEVEL sets the deflate level.  Default 4 (round 4): at level 6 the compression of the hit lines was the LARGEST single
+ * consumer of CPU time in a 32-strain pass -- 35 of 75 CPU-seconds per 100 Gbase (14 M lines, 0.7 GB of text; sixteen pool threads
+ * at 2.2 s each, SK_SD_TIMING=1), on a box whose quota is sixteen CPUs and whose decode side wants them.  zlib on this text
+ * (tab-separated counts + a 31-mer per line): level 1 78 MB/s at 0.269 of the size, level 4 63 MB/s at 0.244, level 6 11 MB/s at
+ * 0.227, level 9 (the reference's gzprintf "wb9") 2.9 MB/s at 0.220.  The decompressed bytes are the same at every level.
  */
 #ifndef SK_GZOUT_H
 #define SK_GZOUT_H
@@ -103,8 +107,8 @@ static void skzo_pool_start(skzo_pool *p, int nthreads)
     const char *lv = getenv("SK_GZ_LEVEL");
     int i;
     memset(p, 0, sizeof *p);
-    p->level = lv ? atoi(lv) : 6;
-    if (p->level < 0 || p->level > 9) p->level = 6;
+    p->level = lv ? atoi(lv) : 4;
+    if (p->level < 0 || p->level > 9) p->level = 4;
     if (nthreads > 16) nthreads = 16;
     if (nthreads < 1) nthreads = 1;
     p->max_outstanding = 4 * nthreads;

@@ -14,11 +14,13 @@
  * FASTQ record in a PE2 file the file is treated as ended.
  */
 #define _GNU_SOURCE
+#include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/resource.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -84,7 +86,6 @@ typedef struct {
     skc_acc    *cov; char *cov_path, *o_path;           /* --coverage-depth: step 4 of the workflow, fed at emission */
     sk_hit     *hitbuf; uint64_t hitcap;   /* landing area of the hit log */
     uint32_t   *tallybuf; uint32_t tallycap;
-    uint64_t    u_nsp, u_nh;               /* union table: this strain's share of a batch's results, dealt out by sd_tally_chunk */
     int         job_rc;                    /* result of this strain's part of a pool job */
 } sd_prog;
 
@@ -103,6 +104,11 @@ typedef struct sd_chunk {
      * (read, strain) pair is a blank */
     struct sd_sp *sp;
     uint32_t  nstrains;
+    /* what the scan of this chunk brought back, strain by strain (round 4: owned by the chunk, so that the per-strain work on it
+     * -- sort, spread, replay -- runs on the lanes while the main thread is on to the next chunk): strain s's hit records are
+     * res_recs[res_off[s] .. res_off[s + 1]), its log entries res_hits[res_hoff[s] .. res_hoff[s + 1]) */
+    sk_tally_rec *res_recs; sk_hit *res_hits; uint64_t *res_off, *res_hoff;
+    int       refs;                          /* holders: the stream (queue, current chunk), every lane job that names it */
 } sd_chunk;
 typedef struct sd_sp { uint32_t n; uint32_t *rec, *all, *inf, *hbeg /* n + 1 */, *rows; } sd_sp;
 
@@ -145,6 +151,7 @@ static struct {
     void *idle[SD_PIN_MAX]; int nidle, total;
 } sd_pin = { PTHREAD_MUTEX_INITIALIZER, NULL, 0, {NULL}, 0, 0 };
 
+static unsigned long n_unpinned_chunks;     /* chunks whose text had to live in ordinary memory (their upload goes through the runtime's staging path) */
 static void *sd_pin_get(void)
 {
     void *q = NULL;
@@ -171,14 +178,32 @@ static void sd_pin_close(void)
 static void sd_unmap_later(void *p, size_t n);
 static double now_s(void);
 static double t_pw_seg, t_pw_parse, t_pw_turn, t_pw_push;   /* SK_SD_TIMING: the parser threads' time, summed over them */
+static double cpu_parsers, cpu_readers, cpu_lanes;          /* SK_SD_TIMING: CPU time (user + system) of those threads, summed when they end */
+static double thread_cpu_s(void)
+{
+    struct rusage ru;
+    if (getrusage(RUSAGE_THREAD, &ru) != 0) return 0.0;
+    return (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec + (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec;
+}
 static pthread_mutex_t t_pw_mu = PTHREAD_MUTEX_INITIALIZER;
 
+static sd_chunk *chunk_new(void)
+{
+    sd_chunk *c = (sd_chunk *)calloc(1, sizeof *c);
+    if (c) c->refs = 1;
+    return c;
+}
+static void chunk_ref(sd_chunk *c) { if (c) __atomic_add_fetch(&c->refs, 1, __ATOMIC_RELAXED); }
+
+/* drop one holder's claim; the last one frees */
 static void chunk_free(sd_chunk *c)
 {
     uint32_t s;
     if (!c) return;
+    if (__atomic_sub_fetch(&c->refs, 1, __ATOMIC_ACQ_REL) > 0) return;
     for (s = 0; c->sp && s < c->nstrains; s++) { free(c->sp[s].rec); free(c->sp[s].rows); }   /* (rec, all, inf, hbeg: one block) */
     free(c->sp);
+    free(c->res_recs); free(c->res_hits); free(c->res_off);                                    /* (res_off, res_hoff: one block) */
     if (c->pinned) sd_pin_put(c->buf); else free(c->buf);
     free(c->pstart); free(c->prec); free(c->len);
     free(c);
@@ -221,7 +246,7 @@ static int sd_on_record(void *user, char *seq, size_t len)
     sd_chunk *c = b->cur;
     if (st->cancel) return 1;
     if (c && c->nrec && (c->blen + len + 1 > st->chunk_bytes || c->nrec >= (1u << 22))) { builder_finish_chunk(b); c = NULL; }
-    if (!c) c = b->cur = (sd_chunk *)calloc(1, sizeof *c);
+    if (!c) c = b->cur = chunk_new();
     if (c->nrec == c->rcap) {
         c->rcap = c->rcap ? c->rcap * 2 : 1u << 16;
         c->len = (uint64_t *)realloc(c->len, (size_t)c->rcap * sizeof *c->len);
@@ -237,6 +262,7 @@ static int sd_on_record(void *user, char *seq, size_t len)
             c->pinned = 1;                                 /* the usual case: a whole chunk's worth, page-locked */
             c->bcap = st->chunk_bytes;
         }
+        if (!c->buf) __atomic_add_fetch(&n_unpinned_chunks, 1, __ATOMIC_RELAXED);     /* (SK_SD_TIMING: the pool was empty or the record too long) */
         if (c->blen + len + 1 > c->bcap) {                 /* a record never straddles chunks: grow instead */
             uint64_t cap = c->bcap ? c->bcap : 1u << 20;
             while (cap < c->blen + len + 1) cap *= 2;
@@ -273,7 +299,11 @@ static void *sd_parse_worker(void *arg)
         double w0 = now_s(), w1, w2, w3;
         pthread_mutex_lock(&st->pmu);
         while (st->segn == 0 && !st->seg_done) pthread_cond_wait(&st->pcv, &st->pmu);
-        if (st->segn == 0) { pthread_mutex_unlock(&st->pmu); return NULL; }
+        if (st->segn == 0) {
+            pthread_mutex_unlock(&st->pmu);
+            pthread_mutex_lock(&t_pw_mu); cpu_parsers += thread_cpu_s(); pthread_mutex_unlock(&t_pw_mu);
+            return NULL;
+        }
         sg = st->segq[0];
         for (i = 1; i < st->segn; i++) st->segq[i - 1] = st->segq[i];
         st->segn--;
@@ -303,7 +333,7 @@ static void *sd_parse_worker(void *arg)
             else if (ps.end_kind == SKP_END_STALE) end_len = st->carry_last_len;       /* "the previous record" lies in an earlier segment */
             if (!st->cancel_segments && (sg->is_last || ps.end_kind == SKP_END_TRUNC || st->split_failed)) {  /* the file ends here (a truncated record ends it for the reference too) */
                 sd_chunk *c;
-                if (b.ndone == 0) { b.cur = (sd_chunk *)calloc(1, sizeof *b.cur); builder_finish_chunk(&b); }
+                if (b.ndone == 0) { b.cur = chunk_new(); builder_finish_chunk(&b); }
                 c = b.done[b.ndone - 1];
                 c->last = 1;
                 c->end_kind = ps.end_kind;
@@ -450,7 +480,7 @@ static void *sd_decode_thread(void *arg)
         pthread_mutex_unlock(&st->pmu);
         for (i = 0; i < nw; i++) pthread_join(wk[i], NULL);
         if (nw == 0) {                                     /* no thread could be started: an empty, failed file rather than a hang */
-            sd_chunk *c = (sd_chunk *)calloc(1, sizeof *c);
+            sd_chunk *c = chunk_new();
             c->last = 1; c->end_kind = SKP_END_RESET;
             st->split_failed = 1;
             stream_push(st, c);
@@ -480,7 +510,7 @@ static void *sd_decode_thread(void *arg)
                 while (ps.state != P_STOP && !st->cancel && (got = gzread(st->g, blk, BLK)) > 0) parser_feed(&ps, blk, (size_t)got);
         }
         parser_eof(&ps);
-        c = b.cur ? b.cur : (sd_chunk *)calloc(1, sizeof *c);
+        c = b.cur ? b.cur : chunk_new();
         b.cur = NULL;
         c->last = 1;
         c->end_kind = ps.end_kind;
@@ -491,6 +521,7 @@ static void *sd_decode_thread(void *arg)
     if (own) skzp_close(&zp);
     if (map) sd_unmap_later((void *)map, mlen);
     free(blk);
+    pthread_mutex_lock(&t_pw_mu); cpu_readers += thread_cpu_s(); pthread_mutex_unlock(&t_pw_mu);
     return NULL;
 }
 
@@ -727,41 +758,23 @@ static int hit_cmp(const void *a, const void *b)
     return x->pos < y->pos ? -1 : x->pos > y->pos;
 }
 
-/* tally one chunk against every strain: one upload, one launch per strain (they overlap on the device),
- * then -- strain by strain on the pool -- the per-record tallies and per-record lists of informative rows, in
- * window order */
-typedef struct { sd_prog *p; sk_batch **batches; sd_chunk *c; int from_union; } sd_tally_job;
-
-static void tally_one(void *arg, uint32_t s)
+/* One strain's share of a chunk's scan results (c->res_*: collected and dealt out by the main thread) -> the per-record tallies
+ * and per-record lists of informative rows, in window order (c->sp[s]). */
+static void tally_one(sd_prog *p, sd_chunk *c, uint32_t s)
 {
-    sd_tally_job *j = (sd_tally_job *)arg;
-    sd_prog *p = &j->p[s];
-    sd_chunk *c = j->c;
     uint64_t nh = 0, h = 0;
     uint32_t n = 0, k;
     sd_sp *sp = &c->sp[s];
-    int rc;
-    p->job_rc = SK_OK;
     memset(sp, 0, sizeof *sp);
-    if (c->np == 0) return;
-    /* only the pieces that hit this strain at all come back (compacted on the device): with many strains against one
+    if (c->np == 0 || !c->res_off) return;
+    /* only the pieces that hit this strain at all came back (compacted on the device): with many strains against one
      * metagenome nearly every (read, strain) pair is a blank */
-    if (!j->from_union && p->tallycap < c->np) {
-        p->tallycap = c->np + c->np / 4 + 1024;
-        p->tallybuf = (uint32_t *)realloc(p->tallybuf, (size_t)p->tallycap * sizeof(sk_tally_rec));
-    }
-    sk_tally_rec *sparse = (sk_tally_rec *)p->tallybuf;
-    uint64_t nsp = 0, e;
-    if (j->from_union) { nsp = p->u_nsp; nh = p->u_nh; }  /* (dealt out by sd_tally_chunk: tallybuf and hitbuf hold this strain's share) */
-    else {
-    if ((rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
-    if (nh > p->hitcap) {                                 /* the log overflowed: once more with room */
-        p->hitcap = nh + nh / 4;
-        p->hitbuf = (sk_hit *)realloc(p->hitbuf, (size_t)p->hitcap * sizeof(sk_hit));
-        if ((rc = sk_tally_launch(p->ctx, j->batches[sd_dev_of_strain(s)], SD_TYPE, SD_INFORMATIVE, p->hitcap)) != SK_OK ||
-            (rc = sk_tally_collect_sparse(p->ctx, sparse, c->np, &nsp, p->hitbuf, &nh)) != SK_OK) { p->job_rc = rc; return; }
-    }
-    }
+    sk_tally_rec *sparse = c->res_recs + c->res_off[s];
+    sk_hit *hits = c->res_hits + c->res_hoff[s];
+    const uint64_t nsp = c->res_off[s + 1] - c->res_off[s];
+    uint64_t e;
+    nh = c->res_hoff[s + 1] - c->res_hoff[s];
+    (void)p;
     /* in the order of the pieces (they come back unordered): a sort when they are few, a sweep over a piece-indexed
      * array when most pieces hit (one strain, reads from that strain) */
     if (nsp * 8 > c->np) {
@@ -771,7 +784,7 @@ static void tally_one(void *arg, uint32_t s)
         for (k = 0; k < c->np; k++) if (by[2 * (size_t)k]) { sparse[w].rec = k; sparse[w].all = by[2 * (size_t)k]; sparse[w].inf = by[2 * (size_t)k + 1]; w++; }
         free(by);
     } else qsort(sparse, (size_t)nsp, sizeof *sparse, tally_rec_cmp);
-    qsort(p->hitbuf, (size_t)nh, sizeof(sk_hit), hit_cmp);
+    qsort(hits, (size_t)nh, sizeof(sk_hit), hit_cmp);
     sp->rec = (uint32_t *)malloc(((size_t)nsp * 4 + 2) * sizeof(uint32_t));
     sp->all = sp->rec + nsp; sp->inf = sp->all + nsp; sp->hbeg = sp->inf + nsp;
     sp->rows = (uint32_t *)malloc(((size_t)nh + 1) * sizeof(uint32_t));
@@ -782,10 +795,205 @@ static void tally_one(void *arg, uint32_t s)
         while (last + 1 < c->np && c->prec[last + 1] == rec) last++;              /* the record's last piece: its rows end where the next record begins */
         end = last + 1 < c->np ? c->pstart[last + 1] : 0xFFFFFFFFu;
         sp->rec[sp->n] = rec; sp->all[sp->n] = all; sp->inf[sp->n] = inf; sp->hbeg[sp->n] = n;
-        while (h < nh && p->hitbuf[h].pos < end) sp->rows[n++] = p->hitbuf[h++].row;
+        while (h < nh && hits[h].pos < end) sp->rows[n++] = hits[h++].row;
         sp->n++;
     }
     sp->hbeg[sp->n] = n;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Lanes (round 4): the per-strain work behind a chunk's scan, off the main thread.
+ *
+ * Round 3's main thread did, chunk after chunk and one thing after the other: upload, launch, collect, then WAIT for the pool to
+ * sort and spread the chunk's results strain by strain, then walk the read lengths, then WAIT for the pool to replay the
+ * reference's read-after-read bookkeeping (and compress 32 outputs) -- 3.5-4.3 s of a 7-8 s pass over 100 Gbase x 32 strains,
+ * beside 2.7-3.3 s of waiting for the decode side, which in turn waited for it (profiles/r03_cfg5_share.json).  The
+ * reference's bookkeeping (src/strain_detect.c:443-626) is sequential per STRAIN, not across strains: strain s owns its carried
+ * tallies, its copy of the last PE1 read's rows, its output.  So: L lane threads, strain s belongs to lane s mod L, and the main
+ * thread only POSTS jobs -- "spread chunk c" (tally_one), "replay this run of read pairs" -- which every lane works off in the
+ * order posted, for its own strains.  A lane's strains see the chunks and runs in file order, which is all the bookkeeping needs;
+ * the main thread goes on to the next chunk's collection at once.  Chunks are reference-counted: a job holds the chunks it names.
+ * Back-pressure: a lane's ring holds SD_RING jobs; the main thread waits when the slowest lane is that far behind.  At the end of
+ * a file the main thread waits for the lanes to run dry (the trailer lines follow the last hit line), and reads the strains'
+ * error states there.
+ * ------------------------------------------------------------------------------------------- */
+#define SD_LANES_MAX 16
+#define SD_RING 8
+enum { SD_JOB_TALLY, SD_JOB_REPLAY, SD_JOB_SYNC };
+typedef struct sd_job {
+    int kind;
+    sd_chunk *ca, *cb;                         /* TALLY: ca; REPLAY: the run's chunks (cb may be NULL) */
+    const char *f1;
+    uint32_t a0, b0, astep, n, first_valid;
+    int have_copy;
+    int pending;                               /* lanes that still have it (atomic) */
+} sd_job;
+struct sd_lanes;
+typedef struct sd_lane {
+    pthread_t th; int started;
+    pthread_mutex_t mu; pthread_cond_t cv_in, cv_out;
+    sd_job *ring[SD_RING]; uint32_t head, count; int quit;
+    struct sd_lanes *all; uint32_t id;
+    double busy;                               /* (SK_SD_TIMING) */
+} sd_lane;
+typedef struct sd_lanes {
+    sd_lane lane[SD_LANES_MAX]; uint32_t n, ns;
+    sd_prog *p;
+    pthread_mutex_t smu; pthread_cond_t scv; uint64_t syncs_done;     /* SYNC jobs completed */
+} sd_lanes;
+static sd_lanes sd_ln;
+/* device calls of the main thread (uploads, launches, collections) and the one a lane can make (a hit line's k-mer fetched on the
+ * spot, emit_rows) never run at the same time: a context takes one caller at a time */
+static pthread_mutex_t sd_dev_mu = PTHREAD_MUTEX_INITIALIZER;
+static double t_lane_busy, t_lane_backpressure, t_lane_drain;
+
+static void sd_replay_run(sd_prog *p, uint32_t s, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb, uint32_t b0,
+                          uint32_t astep, uint32_t n, int have_copy_in, uint32_t first_valid);
+
+static void lane_job_done(sd_lanes *L, sd_job *j)
+{
+    if (__atomic_sub_fetch(&j->pending, 1, __ATOMIC_ACQ_REL) > 0) return;
+    if (j->kind == SD_JOB_SYNC) {
+        pthread_mutex_lock(&L->smu);
+        L->syncs_done++;
+        pthread_cond_broadcast(&L->scv);
+        pthread_mutex_unlock(&L->smu);
+    }
+    chunk_free(j->ca);
+    chunk_free(j->cb);
+    free(j);
+}
+
+static void *lane_main(void *arg)
+{
+    sd_lane *ln = (sd_lane *)arg;
+    sd_lanes *L = ln->all;
+    for (;;) {
+        sd_job *j;
+        uint32_t s;
+        pthread_mutex_lock(&ln->mu);
+        while (ln->count == 0 && !ln->quit) pthread_cond_wait(&ln->cv_in, &ln->mu);
+        if (ln->count == 0) {
+            pthread_mutex_unlock(&ln->mu);
+            pthread_mutex_lock(&t_pw_mu); cpu_lanes += thread_cpu_s(); pthread_mutex_unlock(&t_pw_mu);
+            return NULL;
+        }
+        j = ln->ring[ln->head];
+        pthread_mutex_unlock(&ln->mu);
+        {
+            const double t0 = now_s();
+            for (s = ln->id; s < L->ns; s += L->n) {
+                sd_prog *p = &L->p[s];
+                if (j->kind == SD_JOB_TALLY) tally_one(p, j->ca, s);
+                else if (j->kind == SD_JOB_REPLAY && p->job_rc == SK_OK)
+                    sd_replay_run(p, s, j->f1, j->ca, j->a0, j->cb, j->b0, j->astep, j->n, j->have_copy, j->first_valid);
+            }
+            ln->busy += now_s() - t0;
+        }
+        pthread_mutex_lock(&ln->mu);                  /* (the job leaves the ring only now: "ring empty" means "nothing in work") */
+        ln->head = (ln->head + 1u) % SD_RING;
+        ln->count--;
+        pthread_cond_signal(&ln->cv_out);
+        pthread_mutex_unlock(&ln->mu);
+        lane_job_done(L, j);
+    }
+}
+
+static void lanes_start(sd_prog *p, uint32_t ns)
+{
+    sd_lanes *L = &sd_ln;
+    uint32_t want = getenv("SK_SD_LANES") ? (uint32_t)atoi(getenv("SK_SD_LANES")) : getenv("SK_THREADS") ? (uint32_t)atoi(getenv("SK_THREADS")) : 8u, i;
+    memset(L, 0, sizeof *L);
+    if (want < 1) want = 1;
+    if (want > SD_LANES_MAX) want = SD_LANES_MAX;
+    if (want > ns) want = ns;
+    L->n = want; L->ns = ns; L->p = p;
+    pthread_mutex_init(&L->smu, NULL);
+    pthread_cond_init(&L->scv, NULL);
+    for (i = 0; i < L->n; i++) {
+        sd_lane *ln = &L->lane[i];
+        ln->all = L; ln->id = i;
+        pthread_mutex_init(&ln->mu, NULL);
+        pthread_cond_init(&ln->cv_in, NULL);
+        pthread_cond_init(&ln->cv_out, NULL);
+        ln->started = pthread_create(&ln->th, NULL, lane_main, ln) == 0;
+    }
+}
+
+/* hand a job to every lane (it takes over the caller's claims on ca and cb: pass chunks already chunk_ref'ed) */
+static void lanes_post(sd_job *j)
+{
+    sd_lanes *L = &sd_ln;
+    uint32_t i;
+    j->pending = (int)L->n;
+    for (i = 0; i < L->n; i++) {
+        sd_lane *ln = &L->lane[i];
+        if (!ln->started) {                               /* (no thread could be made for this lane: its strains are done here) */
+            uint32_t s;
+            for (s = ln->id; s < L->ns; s += L->n) {
+                if (j->kind == SD_JOB_TALLY) tally_one(&L->p[s], j->ca, s);
+                else if (j->kind == SD_JOB_REPLAY && L->p[s].job_rc == SK_OK)
+                    sd_replay_run(&L->p[s], s, j->f1, j->ca, j->a0, j->cb, j->b0, j->astep, j->n, j->have_copy, j->first_valid);
+            }
+            lane_job_done(L, j);
+            continue;
+        }
+        pthread_mutex_lock(&ln->mu);
+        if (ln->count == SD_RING) {
+            const double t0 = now_s();
+            while (ln->count == SD_RING) pthread_cond_wait(&ln->cv_out, &ln->mu);
+            t_lane_backpressure += now_s() - t0;
+        }
+        ln->ring[(ln->head + ln->count) % SD_RING] = j;
+        ln->count++;
+        pthread_cond_signal(&ln->cv_in);
+        pthread_mutex_unlock(&ln->mu);
+    }
+}
+
+static sd_job *job_new(int kind, sd_chunk *ca, sd_chunk *cb)
+{
+    sd_job *j = (sd_job *)calloc(1, sizeof *j);
+    j->kind = kind; j->ca = ca; j->cb = cb;
+    chunk_ref(ca); chunk_ref(cb);
+    return j;
+}
+
+/* wait until every lane has worked off everything posted so far */
+static void lanes_drain(void)
+{
+    sd_lanes *L = &sd_ln;
+    uint64_t want;
+    if (!L->n) return;
+    pthread_mutex_lock(&L->smu);
+    want = L->syncs_done + 1;
+    pthread_mutex_unlock(&L->smu);
+    lanes_post(job_new(SD_JOB_SYNC, NULL, NULL));
+    pthread_mutex_lock(&L->smu);
+    while (L->syncs_done < want) pthread_cond_wait(&L->scv, &L->smu);
+    pthread_mutex_unlock(&L->smu);
+}
+
+static void lanes_stop(void)
+{
+    sd_lanes *L = &sd_ln;
+    uint32_t i;
+    for (i = 0; i < L->n; i++) {
+        sd_lane *ln = &L->lane[i];
+        if (ln->started) {
+            pthread_mutex_lock(&ln->mu);
+            ln->quit = 1;
+            pthread_cond_signal(&ln->cv_in);
+            pthread_mutex_unlock(&ln->mu);
+            pthread_join(ln->th, NULL);
+        }
+        t_lane_busy += ln->busy;
+        pthread_mutex_destroy(&ln->mu);
+        pthread_cond_destroy(&ln->cv_in);
+        pthread_cond_destroy(&ln->cv_out);
+    }
+    if (L->n) { pthread_mutex_destroy(&L->smu); pthread_cond_destroy(&L->scv); }
+    L->n = 0;
 }
 
 /* Many strains on one device: one union table per group of up to SK_UNION_MAX strains (sk_union_*), so that a batch is
@@ -876,17 +1084,59 @@ static int sd_launch(sd_prog *p, uint32_t ns, sk_batch **batches)
     return SK_OK;
 }
 
-/* the unions' results of the chunk whose scans are in flight, dealt to the strains' tallybuf/hitbuf (u_nsp, u_nh entries) */
-static int sd_collect_unions(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chunk *c)
+/* room for n more records and m more log entries in the chunk's own result arrays */
+static int chunk_res_reserve(sd_chunk *c, uint64_t *rcap, uint64_t *hcap, uint64_t nrec_total, uint64_t nhit_total)
+{
+    if (nrec_total > *rcap || !c->res_recs) {
+        *rcap = nrec_total + nrec_total / 2 + 256;
+        c->res_recs = (sk_tally_rec *)realloc(c->res_recs, (size_t)*rcap * sizeof(sk_tally_rec));
+    }
+    if (nhit_total > *hcap || !c->res_hits) {
+        *hcap = nhit_total + nhit_total / 2 + 256;
+        c->res_hits = (sk_hit *)realloc(c->res_hits, (size_t)*hcap * sizeof(sk_hit));
+    }
+    return c->res_recs && c->res_hits ? SK_OK : SK_E_NOMEM;
+}
+
+/* The results of the chunk whose scans are in flight, collected and laid out strain by strain IN THE CHUNK (res_recs/res_off,
+ * res_hits/res_hoff) -- from the union tables (every group's results dealt to its members by a counting sort), or member by
+ * member.  After this the device side may be overwritten by the next launch, and the lanes take it from here. */
+static int sd_collect(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chunk *c)
 {
     uint32_t g, s;
     int rc;
-    for (s = 0; s < ns; s++) p[s].u_nsp = p[s].u_nh = 0;
+    uint64_t rcap = 0, hcap = 0, nr = 0, nhit = 0;
+    c->res_off = (uint64_t *)calloc(2 * ((size_t)ns + 1), sizeof(uint64_t));
+    if (!c->res_off) return SK_E_NOMEM;
+    c->res_hoff = c->res_off + ns + 1;
+    if (!sd_un.n) {
+        for (s = 0; s < ns; s++) {
+            uint64_t nsp = 0, nh = 0;
+            if (p[s].tallycap < c->np || !p[s].tallybuf) {
+                p[s].tallycap = c->np + c->np / 4 + 1024;
+                p[s].tallybuf = (uint32_t *)realloc(p[s].tallybuf, (size_t)p[s].tallycap * sizeof(sk_tally_rec));
+            }
+            if ((rc = sk_tally_collect_sparse(p[s].ctx, (sk_tally_rec *)p[s].tallybuf, c->np, &nsp, p[s].hitbuf, &nh)) != SK_OK) return rc;
+            if (nh > p[s].hitcap) {                           /* the log overflowed: once more with room */
+                p[s].hitcap = nh + nh / 4;
+                p[s].hitbuf = (sk_hit *)realloc(p[s].hitbuf, (size_t)p[s].hitcap * sizeof(sk_hit));
+                if ((rc = sk_tally_launch(p[s].ctx, batches[sd_dev_of_strain(s)], SD_TYPE, SD_INFORMATIVE, p[s].hitcap)) != SK_OK ||
+                    (rc = sk_tally_collect_sparse(p[s].ctx, (sk_tally_rec *)p[s].tallybuf, c->np, &nsp, p[s].hitbuf, &nh)) != SK_OK) return rc;
+            }
+            if ((rc = chunk_res_reserve(c, &rcap, &hcap, nr + nsp, nhit + nh)) != SK_OK) return rc;
+            memcpy(c->res_recs + nr, p[s].tallybuf, (size_t)nsp * sizeof(sk_tally_rec));
+            memcpy(c->res_hits + nhit, p[s].hitbuf, (size_t)nh * sizeof(sk_hit));
+            c->res_off[s] = nr; c->res_hoff[s] = nhit;
+            nr += nsp; nhit += nh;
+        }
+        c->res_off[ns] = nr; c->res_hoff[ns] = nhit;
+        return SK_OK;
+    }
     for (g = 0; g < sd_un.n; g++) {
         const uint32_t a = g * sd_group, n = sk_union_members(sd_un.u[g]);
         const uint64_t worst = (uint64_t)c->np * n;
         uint64_t nsp = 0, nh = 0, e;
-        uint64_t cnt[SK_UNION_MAX], hcnt[SK_UNION_MAX];
+        uint64_t cnt[SK_UNION_MAX + 1], hcnt[SK_UNION_MAX + 1];
         if (worst > sd_un.recs_cap) {                       /* (address space only: pages are touched as far as results come back) */
             free(sd_un.recs);
             sd_un.recs_cap = worst + worst / 4 + 1024;
@@ -899,31 +1149,25 @@ static int sd_collect_unions(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chu
             sd_un.hcap[g] = nh + nh / 4;                    /* the log overflowed: once more with room */
             if ((rc = sk_union_tally_launch(sd_un.u[g], batches[sd_dev_of_strain(a)], sd_un.hcap[g])) != SK_OK) return rc;
         }
+        if ((rc = chunk_res_reserve(c, &rcap, &hcap, nr + nsp, nhit + nh)) != SK_OK) return rc;
         memset(cnt, 0, sizeof cnt); memset(hcnt, 0, sizeof hcnt);
         for (e = 0; e < nsp; e++) cnt[sd_un.recs[e].rec % n]++;
         for (e = 0; e < nh; e++) hcnt[sd_un.hits[e].row >> SK_UNION_ROW_BITS]++;
-        for (s = 0; s < n; s++) {
-            sd_prog *q = &p[a + s];
-            if (q->tallycap < cnt[s] || !q->tallybuf) {
-                q->tallycap = (uint32_t)(cnt[s] + cnt[s] / 4 + 1024);
-                q->tallybuf = (uint32_t *)realloc(q->tallybuf, (size_t)q->tallycap * sizeof(sk_tally_rec));
-            }
-            if (q->hitcap < hcnt[s] || !q->hitbuf) {
-                q->hitcap = hcnt[s] + hcnt[s] / 4 + 1024;
-                q->hitbuf = (sk_hit *)realloc(q->hitbuf, (size_t)q->hitcap * sizeof(sk_hit));
-            }
+        for (s = 0; s < n; s++) {                           /* the members' shares, one behind the other */
+            c->res_off[a + s] = nr; c->res_hoff[a + s] = nhit;
+            nr += cnt[s]; nhit += hcnt[s];
+            cnt[s] = c->res_off[a + s]; hcnt[s] = c->res_hoff[a + s];      /* (now: where the member's next entry goes) */
         }
         for (e = 0; e < nsp; e++) {
-            sd_prog *q = &p[a + sd_un.recs[e].rec % n];
-            sk_tally_rec *out = (sk_tally_rec *)q->tallybuf + q->u_nsp++;
+            sk_tally_rec *out = c->res_recs + cnt[sd_un.recs[e].rec % n]++;
             out->rec = sd_un.recs[e].rec / n; out->all = sd_un.recs[e].all; out->inf = sd_un.recs[e].inf;
         }
         for (e = 0; e < nh; e++) {
-            sd_prog *q = &p[a + (sd_un.hits[e].row >> SK_UNION_ROW_BITS)];
-            sk_hit *out = q->hitbuf + q->u_nh++;
+            sk_hit *out = c->res_hits + hcnt[sd_un.hits[e].row >> SK_UNION_ROW_BITS]++;
             out->pos = sd_un.hits[e].pos; out->row = sd_un.hits[e].row & ((1u << SK_UNION_ROW_BITS) - 1u);
         }
     }
+    c->res_off[ns] = nr; c->res_hoff[ns] = nhit;
     return SK_OK;
 }
 
@@ -931,27 +1175,29 @@ static int sd_collect_unions(sd_prog *p, uint32_t ns, sk_batch **batches, sd_chu
  * launched: its scans are in flight as well (started while the chunk before it was being replayed: sd_launch_ahead). */
 static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch **batches, sd_pool *pool, sd_chunk *c, int uploaded, int launched, sd_stream *st)
 {
-    sd_tally_job job;
-    uint32_t s;
     int rc;
     double t0 = now_s(), t1;
-    const int use_union = sd_un.n != 0;
+    (void)pool;
     c->nstrains = ns;
     c->sp = (sd_sp *)calloc(ns, sizeof *c->sp);
     if (c->np) {
         int d;
-        for (d = 0; d < sd_dev.n && !uploaded; d++)              /* (asynchronous copies from page-locked memory: the devices' uploads overlap) */
-            if ((rc = sk_batch_fill(batches[d], c->buf, c->blen, c->pstart, c->np)) != SK_OK) return rc;
+        pthread_mutex_lock(&sd_dev_mu);
+        rc = SK_OK;
+        for (d = 0; d < sd_dev.n && !uploaded && rc == SK_OK; d++)  /* (asynchronous copies from page-locked memory: the devices' uploads overlap) */
+            rc = sk_batch_fill(batches[d], c->buf, c->blen, c->pstart, c->np);
         t1 = now_s(); t_fill += t1 - t0; t0 = t1;
-        if (!launched && (rc = sd_launch(p, ns, batches)) != SK_OK) return rc;
-        sd_prefetch(st);                                         /* the next chunk goes up while this one is scanned */
-        if (use_union && (rc = sd_collect_unions(p, ns, batches, c)) != SK_OK) return rc;
+        if (rc == SK_OK && !launched) rc = sd_launch(p, ns, batches);
+        if (rc == SK_OK) {
+            sd_prefetch(st);                                     /* the next chunk goes up while this one is scanned */
+            rc = sd_collect(p, ns, batches, c);
+        }
+        pthread_mutex_unlock(&sd_dev_mu);
+        if (rc != SK_OK) return rc;
         t1 = now_s(); t_launch += t1 - t0; t0 = t1;
     }
-    job.p = p; job.batches = batches; job.c = c; job.from_union = use_union;
-    pool_run(pool, ns, tally_one, &job);
+    lanes_post(job_new(SD_JOB_TALLY, c, NULL));                  /* sort + spread, strain by strain, behind the main thread's back */
     t_post += now_s() - t0;
-    for (s = 0; s < ns; s++) if (p[s].job_rc != SK_OK) return p[s].job_rc;
     return SK_OK;
 }
 
@@ -963,8 +1209,10 @@ static void sd_launch_ahead(sd_stream *st, sd_prog *p, uint32_t ns)
 {
     const double t0 = now_s();
     if (!st->solo || !st->pre || st->ahead || getenv("SK_SD_NO_AHEAD")) return;
+    pthread_mutex_lock(&sd_dev_mu);
     if (sd_launch(p, ns, st->bat[st->bcur ^ 1]) == SK_OK) st->ahead = st->pre;
     else sd_drain_scans();
+    pthread_mutex_unlock(&sd_dev_mu);
     /* (a failed launch is not an error here: the chunk is launched again, and the error reported, when its turn comes -- but
      * the launches that DID start before the one that failed are waited for first: a context takes one launch at a time, and
      * their results are not collected -- ADVICE r03) */
@@ -1047,9 +1295,15 @@ static void emit_rows(sd_prog *p, const uint32_t *rows, uint32_t n, const char *
     uint32_t j;
     char key[32];
     for (j = 0; j < n; j++) {
-        if (p->table_on_device && p->ks.packed[rows[j]] == 0 && skh_keyset_fetch_keys(&p->ks, p->ctx, &rows[j], 1) != SK_OK) {
-            p->job_rc = SK_E_HIP;                            /* (a row whose key was not fetched with the informative ones: one at a time) */
-            return;                                          /* never print a line without its k-mer (a key of 0 would decode to thirty-one A's): the run fails */
+        if (p->table_on_device && p->ks.packed[rows[j]] == 0) {       /* (a row whose key was not fetched with the informative ones: one at a time) */
+            int frc;
+            pthread_mutex_lock(&sd_dev_mu);
+            frc = skh_keyset_fetch_keys(&p->ks, p->ctx, &rows[j], 1);
+            pthread_mutex_unlock(&sd_dev_mu);
+            if (frc != SK_OK) {
+                p->job_rc = SK_E_HIP;
+                return;                                      /* never print a line without its k-mer (a key of 0 would decode to thirty-one A's): the run fails */
+            }
         }
         skh_keyset_key(&p->ks, rows[j], key);
         if (nl <= 3800) {
@@ -1145,22 +1399,16 @@ static void sd_replay_run(sd_prog *p, uint32_t s, const char *f1, const sd_chunk
     }
 }
 
-/* replay one run for every strain; returns the (strain-independent) have_copy afterwards */
-typedef struct { sd_prog *p; const char *f1; const sd_chunk *ca, *cb; uint32_t a0, b0, astep, n, first_valid; int have_copy; } sd_replay_job;
-static void replay_one(void *arg, uint32_t s)
+/* Post one run to the lanes (they replay it strain by strain, behind the runs posted before); returns the (strain-independent)
+ * have_copy afterwards.  The job holds the two chunks until every lane is through with it. */
+static int post_replay(const char *f1, sd_chunk *ca, uint32_t a0, sd_chunk *cb, uint32_t b0, uint32_t astep, uint32_t n, int have_copy)
 {
-    sd_replay_job *j = (sd_replay_job *)arg;
-    sd_replay_run(&j->p[s], s, j->f1, j->ca, j->a0, j->cb, j->b0, j->astep, j->n, j->have_copy, j->first_valid);
-}
-static int pool_replay(sd_pool *pl, sd_prog *p, uint32_t ns, const char *f1, const sd_chunk *ca, uint32_t a0, const sd_chunk *cb,
-                       uint32_t b0, uint32_t astep, uint32_t n, int have_copy)
-{
-    sd_replay_job j;
+    sd_job *j = job_new(SD_JOB_REPLAY, ca, cb);
     uint32_t k;
-    j.p = p; j.f1 = f1; j.ca = ca; j.cb = cb; j.a0 = a0; j.b0 = b0; j.astep = astep; j.n = n; j.have_copy = have_copy;
+    j->f1 = f1; j->a0 = a0; j->b0 = b0; j->astep = astep; j->n = n; j->have_copy = have_copy;
     for (k = 0; k < n && ca->len[a0 + k * astep] < SK_K; k++) { }
-    j.first_valid = k;
-    pool_run(n < 2 ? NULL : pl, ns, replay_one, &j);
+    j->first_valid = k;
+    lanes_post(j);
     return have_copy || k < n;
 }
 
@@ -1230,13 +1478,20 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
             goto done;
         }
         t_lens += now_s() - t_mark; t_mark = now_s();
-        have_copy = pool_replay(pool, p, ns, f1, ca, a0, cb, b0, astep, n, have_copy);
+        have_copy = post_replay(f1, ca, a0, cb, b0, astep, n, have_copy);
         t_replay += now_s() - t_mark;
         if (held) { chunk_free(held); if (cb) A.ci++; }  /* PEI across a chunk boundary: the mate was A's next record */
         else {
             A.ci += n * astep;
             if (mode == SD_PE && cb) B.ci += n;
         }
+    }
+    {   /* the lanes run dry before anything is said about the file: the trailer lines follow the last hit line, and a strain's error
+         * state is read only here */
+        const double t0 = now_s();
+        lanes_drain();
+        t_lane_drain += now_s() - t0;
+        for (s = 0; s < ns && got >= 0; s++) if (p[s].job_rc != SK_OK) got = p[s].job_rc;
     }
     if (got == SK_E_SPLIT) {
         fprintf(err, "strain_detect: %s could not be cut at record boundaries for parsing on several threads: nothing from it is reported; "
@@ -1261,6 +1516,7 @@ static int sd_quantify(sd_prog *p, uint32_t ns, sk_batch *batch, sd_pool *pool, 
     }
     status = 0;
 done:
+    lanes_drain();                                       /* (every way out: nothing of this file is in work when its streams go) */
     t_mark = now_s();
     stream_close(&A);
     stream_close(&B);
@@ -1610,11 +1866,12 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
     sd_all_p = p; sd_all_ns = ns;
     sd_unions_open(p, ns);
     pool_start(&pool, ns);
+    lanes_start(p, ns);
     if (B) {
         FILE *fp = fopen(B, "r");
         char *line = NULL, *nl, *tok, *f1, *f2;
         size_t cap = 0;
-        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); pool_stop(&pool); sd_unions_close(); return 1; }
+        if (!fp) { fprintf(err, "could not read file file_of_filenames %s in quantify_hits_all_files()\n", B); lanes_stop(); pool_stop(&pool); sd_unions_close(); return 1; }
         while (!bad && getline(&line, &cap, fp) != -1) {
             int m;
             if ((nl = strchr(line, '\n')) != NULL) *nl = '\0';
@@ -1633,6 +1890,7 @@ static int sd_run(sd_prog *p, uint32_t ns, const char *B, const char *b, const c
         free(line);
         fclose(fp);
     } else bad = sd_quantify(p, ns, batch, &pool, b, b2, mode);
+    lanes_stop();
     pool_stop(&pool);
     sd_unmap_wait();
     sd_batch_cache_close();
@@ -1849,9 +2107,54 @@ done:
         fprintf(err, "strain_detect timing: opening the strains, thread time summed: context %.2f s, table load %.2f s, -a/-g flags + outfile %.2f s\n",
                 t_open_ctx, t_open_load, t_open_flags);
     if (getenv("SK_SD_TIMING"))
-        fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (upload %.2f, launch %.2f, "
-                     "collect+sort+spread per strain on the pool %.2f), read lengths %.2f s, replay on the pool %.2f s, chunks freed %.2f s, files opened %.2f s and closed %.2f s, union tables freed %.2f s, total before close %.2f s\n", t_setup, t_wait, t_tally, t_fill,
-                t_launch, t_post, t_lens, t_replay, t_cfree, t_sopen, t_sclose, t_uclose, now_s() - t_begin);
+        fprintf(err, "strain_detect timing: setup %.2f s, waiting for the decode thread %.2f s, tally %.2f s (upload %.2f, launch + collect %.2f, "
+                     "posting to the lanes %.2f), read lengths %.2f s, posting the runs %.2f s, waiting for the lanes at the files' ends %.2f s "
+                     "(and %.2f s for room in a lane's ring), chunks freed %.2f s, files opened %.2f s and closed %.2f s, union tables freed %.2f s, "
+                     "total before close %.2f s; lanes' busy time, summed: %.2f s (sort + spread + replay + compression hand-over)\n",
+                t_setup, t_wait, t_tally, t_fill, t_launch, t_post, t_lens, t_replay, t_lane_drain, t_lane_backpressure, t_cfree, t_sopen, t_sclose,
+                t_uclose, now_s() - t_begin, t_lane_busy);
+    if (getenv("SK_SD_TIMING")) {                        /* who used the CPUs: the process as a whole against the threads this file starts */
+        struct rusage ru;
+        if (getrusage(RUSAGE_SELF, &ru) == 0)
+            fprintf(err, "strain_detect timing: CPU time of the process: user %.1f s + system %.1f s; of it parser threads %.1f s, reader threads %.1f s, "
+                         "lanes %.1f s, this (main) thread %.1f s -- the rest is the output compressors, the HIP runtime's own threads and the strains' opening\n",
+                    (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec, (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec,
+                    cpu_parsers, cpu_readers, cpu_lanes, thread_cpu_s());
+    }
+    if (getenv("SK_SD_TIMING")) {                        /* ... and the threads that are still there (the runtime's, the compressors', the lanes'), by name */
+        DIR *td = opendir("/proc/self/task");
+        struct dirent *de;
+        const double tick = 1.0 / (double)sysconf(_SC_CLK_TCK);
+        while (td && (de = readdir(td)) != NULL) {
+            char path[300], buf[1024], *rp;
+            FILE *tf;
+            unsigned long ut = 0, stt = 0;
+            if (de->d_name[0] == '.') continue;
+            snprintf(path, sizeof path, "/proc/self/task/%s/stat", de->d_name);
+            if (!(tf = fopen(path, "r"))) continue;
+            if (fgets(buf, sizeof buf, tf) && (rp = strrchr(buf, ')')) != NULL &&
+                sscanf(rp + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &stt) == 2 && (double)(ut + stt) * tick >= 0.5) {
+                *rp = 0;
+                fprintf(err, "strain_detect timing: thread %s (%s: user %.1f s, system %.1f s\n", de->d_name, strchr(buf, '(') ? strchr(buf, '(') + 1 : "?",
+                        (double)ut * tick, (double)stt * tick);
+            }
+            fclose(tf);
+        }
+        if (td) closedir(td);
+    }
+    if (getenv("SK_SD_TIMING")) {                        /* was the process held back by its CPU quota?  (cgroup v2: cpu.stat of the job's group) */
+        FILE *cs = fopen("/sys/fs/cgroup/cpu.stat", "r");
+        char ln[128];
+        while (cs && fgets(ln, sizeof ln, cs))
+            if (!strncmp(ln, "nr_throttled", 12) || !strncmp(ln, "throttled_usec", 14) || !strncmp(ln, "usage_usec", 10)) {
+                ln[strcspn(ln, "\n")] = 0;
+                fprintf(err, "strain_detect timing: cgroup cpu.stat %s (since the group began)\n", ln);
+            }
+        if (cs) fclose(cs);
+    }
+    if (getenv("SK_SD_TIMING"))
+        fprintf(err, "strain_detect timing: page-locked chunk buffers: %d of at most %d made (%zu bytes each), %lu chunks had to do without one\n",
+                sd_pin.total, SD_PIN_MAX, sd_pin.bytes, n_unpinned_chunks);
     if (getenv("SK_SD_TIMING") && t_pw_parse > 0)
         fprintf(err, "strain_detect timing: parser threads, summed: parsing %.2f s, waiting for a segment %.2f s, for their turn to hand chunks on %.2f s, for room in the queue %.2f s\n",
                 t_pw_parse, t_pw_seg, t_pw_turn, t_pw_push);
