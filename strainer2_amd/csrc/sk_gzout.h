@@ -84,6 +84,7 @@ static void skzo_deliver(skzo_job *j)
 static void *skzo_worker(void *arg)
 {
     skzo_pool *p = (skzo_pool *)arg;
+    pthread_setname_np(pthread_self(), "sk-gzout");
     for (;;) {
         skzo_job *j;
         pthread_mutex_lock(&p->mu);

@@ -42,6 +42,8 @@
 enum { SD_TYPE = 0, SD_BACKGROUND = 5, SD_INFORMATIVE = 2, SD_PLAIN = 1, SD_NCOLS = 6 };
 enum { SD_SE = 0, SD_PE = 1, SD_PEI = 2, SD_UNKNOWN = -1 };
 #define SD_BATCH_BYTES (32u << 20)
+#define SD_PARSERS_MAX 16                 /* parser threads on one file, at most (SK_PARSE_THREADS) */
+#define SD_PARSERS_MAPPED 12              /* ... on a mapped plain file with the whole thread budget behind it, by default (8 until round 4: the main thread was what the pass waited for) */
 /* ONE process, ONE decode pipeline, several devices (strain_detect -S with SK_DEVICES=n; BASELINE configs[4]: 256 strains on the 8
  * GPUs of a node).  The strains are dealt to the devices in groups of SK_UNION_MAX (one union table per group: group g lives on
  * logical device g mod n); a decoded chunk of the metagenome is uploaded ONCE PER DEVICE from the same page-locked buffer (every
@@ -125,7 +127,7 @@ typedef struct {
      * every segment is parsed on its own and CHECKED to end between two records, chunks are queued in segment order */
     int         par;                         /* parser threads (0/1 = the decode thread parses itself) */
     pthread_mutex_t pmu; pthread_cond_t pcv;
-    struct sd_seg *segq[12]; int segn, seg_done;   /* segments waiting for a parser thread; no more will come */
+    struct sd_seg *segq[20]; int segn, seg_done;   /* segments waiting for a parser thread; no more will come */
     uint64_t    next_push;                   /* sequence number of the segment whose chunks go to q next */
     size_t      carry_last_len;              /* length of the last record handed out so far (for an END_STALE ending) */
     int         split_failed;                /* a segment did not end between two records */
@@ -144,7 +146,7 @@ typedef struct {
 /* Page-locked chunk buffers, recycled.  The upload of a chunk from ordinary memory goes through the runtime's
  * staging path, which collapses (measured: 17 -> 1.7 GB/s) as soon as other threads of the process fault pages
  * in at a high rate -- which is what the decode threads do when one .gz file is inflated by eight of them. */
-#define SD_PIN_MAX 16
+#define SD_PIN_MAX 32                    /* (1 GiB at the default chunk size: every parser thread holds one, the queue three, the device pair two) */
 static struct {
     pthread_mutex_t mu;
     sk_ctx *ctx; size_t bytes;
@@ -291,6 +293,7 @@ static int sd_on_record(void *user, char *seq, size_t len)
 static void *sd_parse_worker(void *arg)
 {
     sd_stream *st = (sd_stream *)arg;
+    pthread_setname_np(pthread_self(), "sk-parse");
     for (;;) {
         sd_seg *sg;
         sd_builder b;
@@ -400,7 +403,7 @@ static void *sd_decode_thread(void *arg)
          * plain file when many strains wait for it (32 strains x 10 Gbase of FASTA: the one parser thread, 3 GB/s, was what the
          * whole pass waited for).  Cut the text into segments for the parser threads -- copied out of the inflate stream, or
          * simply pointing into the map: */
-        pthread_t wk[8];
+        pthread_t wk[SD_PARSERS_MAX];
         int nw = 0, i;
         uint64_t seq = 0;
         size_t scan_from;
@@ -408,8 +411,8 @@ static void *sd_decode_thread(void *arg)
         sd_seg *sg = NULL;
         {   /* a mapped file costs nothing to read: with a whole thread budget behind one file, eight parsers (an inflating
              * file keeps its four: the inflate threads need the CPUs) */
-            const int npar = map && !getenv("SK_PARSE_THREADS") && st->gz_threads >= 16 ? 8 : st->par;
-            for (i = 0; i < npar && i < 8; i++) if (pthread_create(&wk[nw], NULL, sd_parse_worker, st) == 0) nw++;
+            const int npar = map && !getenv("SK_PARSE_THREADS") && st->gz_threads >= 16 ? SD_PARSERS_MAPPED : st->par;
+            for (i = 0; i < npar && i < SD_PARSERS_MAX; i++) if (pthread_create(&wk[nw], NULL, sd_parse_worker, st) == 0) nw++;
         }
         if (map) {
             size_t at = 0;
@@ -549,7 +552,7 @@ static int stream_open(sd_stream *st, const char *path, int gz_threads)
         const char *e = getenv("SK_PARSE_THREADS");
         st->par = e ? atoi(e) : (gz_threads >= 8 ? 4 : gz_threads >= 3 ? 2 : 1);
         if (getenv("SK_NO_SPLIT") || st->par < 2) st->par = 1;
-        if (st->par > 8) st->par = 8;
+        if (st->par > SD_PARSERS_MAX) st->par = SD_PARSERS_MAX;
     }
     pthread_mutex_init(&st->pmu, NULL);
     pthread_cond_init(&st->pcv, NULL);
@@ -683,6 +686,7 @@ static void *pool_worker_sd(void *arg)
 {
     sd_pool *pl = (sd_pool *)arg;
     unsigned long seen = 0;
+    pthread_setname_np(pthread_self(), "sk-pool");
     for (;;) {
         pthread_mutex_lock(&pl->mu);
         while (pl->gen == seen && !pl->quit) pthread_cond_wait(&pl->cv_work, &pl->mu);
@@ -868,6 +872,7 @@ static void *lane_main(void *arg)
 {
     sd_lane *ln = (sd_lane *)arg;
     sd_lanes *L = ln->all;
+    pthread_setname_np(pthread_self(), "sk-lane");
     for (;;) {
         sd_job *j;
         uint32_t s;
