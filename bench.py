@@ -641,10 +641,11 @@ def main():
             ctx.zero_counts(1)
             t1 = time.perf_counter()
             fb = 0
+            FILE_PASSES = 3                                  # (one pass of this small list is 60 ms: three make a steadier number)
             try:
-                if ok:
-                    fb = scan_list_sharded(ctx, os.path.join(root, "list.txt"), 1, rank, world)
-                    ctx.sync()
+                for _ in range(FILE_PASSES if ok else 0):
+                    fb += scan_list_sharded(ctx, os.path.join(root, "list.txt"), 1, rank, world)
+                ctx.sync()
             except (OSError, ValueError) as e:
                 ok, why = False, f"scan_list failed: {e}"
             if world > 1:
@@ -664,8 +665,8 @@ def main():
                             "first_pass_seconds_rank0": cold,
                             "what": "plain FASTQ under %s: 2 files x %d reads per rank + one file of %d reads, ONE list scanned by "
                                     "all ranks through skh_scan_list (items dealt by size, the big file cut at checked record "
-                                    "boundaries), counts all-reduced; decode threads per rank = SK_THREADS or the CPU budget / ranks; the second of two "
-                                    "passes (the first one page-locks the threads' buffers, kept by the context)"
+                                    "boundaries), counts all-reduced; decode threads per rank = SK_THREADS or the CPU budget / ranks; three timed "
+                                    "passes behind an untimed first one (which page-locks the threads' buffers, kept by the context)"
                                     % (root, n_small, 4 * n_small)}
         barrier()
         if rank == 0:
@@ -724,7 +725,12 @@ def main():
                                                  "measured TCC_REQ in profiles/)",
                                          "achieved_per_s": (nbytes / 16.0 + nbytes / 128.0) / (avg_ms * 1e-3), "ceiling_per_s": L2_REQ_CEILING,
                                          "frac": (nbytes / 16.0 + nbytes / 128.0) / (avg_ms * 1e-3) / L2_REQ_CEILING,
-                                         "ceiling_source": "random 8-byte loads from a <= 4 MiB table, profiles/r01_gather_microbench.txt"},
+                                         "ceiling_source": "random 8-byte loads from a <= 4 MiB table, profiles/r01_gather_microbench.txt",
+                                         # round 4 (tools/probes/overlap_probe.hip, profiles/r04_overlap_probe.txt; NOT measured in this run): the
+                                         # kernel's two access patterns bare -- the stream's nt loads + one hashed 8-byte lookup per 16 bytes, no
+                                         # arithmetic, same grid -- take 0.511 ms for this batch: what the memory system gives the single-kernel design
+                                         "bare_access_pattern_ms": 0.511 * nbytes / 1.51e9,
+                                         "frac_of_bare_access_pattern": (0.511 * nbytes / 1.51e9) / avg_ms if avg_ms > 0 else None},
                          # ... and the third: the SIMDs' issue slots (the kernel is integer SWAR work, 13 vector instructions per base)
                          "vector_issue": measured_vector_issue()},
             "cpu_baseline": cpu,
