@@ -91,20 +91,32 @@ static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords
     } else zrc = skz_decode_file(path, parse_feed_sink, &ps);
     if (zrc == SKZ_OPEN) { parser_free(&ps); return SK_E_OPEN; }
     if (zrc == SKZ_NOT_GZIP && !getenv("SK_ZLIB")) {
-        /* plain text: parsed straight out of the mapped file (round 4; zlib's pass-through copies every byte once more, and the
-         * whole-record shortcuts of the parser want their records inside ONE block, not cut every MiB).  Anything that cannot be
-         * mapped -- a pipe, an empty file -- goes through gzread below, which hands the same bytes on */
+        /* plain text: read() in 4 MiB blocks (round 4).  zlib's pass-through does the same copy behind more layers and cuts
+         * the text every MiB (the parser's whole-record shortcuts want their records inside ONE block).  Parsing out of a
+         * mapping of the file was measured and LOSES with 16 decode threads (BASELINE configs[2], 1,670 files in /dev/shm,
+         * gpurun_out/r04/cfg3_where.txt -> profiles/r04_cfg3_where.txt: the threads spend 31 s on a core and 37 s asleep in
+         * page faults behind the address space's lock, which every mmap/munmap of the other threads takes for writing --
+         * scans 4.6 s; read(): 42 s on a core, next to none asleep -- scans 3.4 s).  What is not a regular file goes
+         * through gzread below, which hands the same bytes on */
         const int fd = open(path, O_RDONLY);
         struct stat sb;
-        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
-            const size_t n = (size_t)sb.st_size;
-            const unsigned char *t = (const unsigned char *)mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (t != MAP_FAILED) {
-                size_t at;
-                madvise((void *)t, n, MADV_SEQUENTIAL);
-                for (at = 0; at < n && ps.state != P_STOP; at += (size_t)4 << 20) parser_feed(&ps, t + at, n - at < ((size_t)4 << 20) ? n - at : (size_t)4 << 20);
-                munmap((void *)t, n);
-                zrc = SKZ_OK;                           /* (done) */
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            enum { RBLK = 4 << 20 };
+            unsigned char *rb = (unsigned char *)malloc(RBLK);
+            if (rb) {
+                (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+                while (ps.state != P_STOP) {
+                    size_t have = 0;
+                    ssize_t r = 1;
+                    while (have < RBLK && (r = read(fd, rb + have, RBLK - have)) != 0) {
+                        if (r < 0) { if (errno == EINTR) continue; break; }
+                        have += (size_t)r;
+                    }
+                    if (have) parser_feed(&ps, rb, have);
+                    if (r <= 0) break;                  /* (end of file, or an error: what was read counts, as with gzread) */
+                }
+                free(rb);
+                zrc = SKZ_OK;
             }
         }
         if (fd >= 0) close(fd);
@@ -788,6 +800,9 @@ typedef struct {
     FILE           *progress;          /* rank 0's progress file (or NULL) ...                      */
     list_line      *ll;                /* ... the list's lines ...                                  */
     uint32_t        nll, ll_next;      /* ... and the first one not yet written there               */
+    int             timing;            /* SK_TIMING: where the decode threads' time goes (seconds summed over threads, under queue_mu) */
+    double          t_item, t_submit_wait, t_submit, t_ticket, t_cpu;
+    uint64_t        nchunks;
 } scan_pool;
 
 /* The progress file gets a list line when a decode thread TAKES the line's (first) item, and every line before it that is
@@ -812,6 +827,8 @@ typedef struct {
     sk_inflater *inf;                  /* SK_GPU_INFLATE=1: this worker's device-side gzip decoder ... */
     int          dev_ok;               /* ... which only the pool's first dev_workers threads use (the others inflate on the host) */
     uint8_t   *text; uint64_t text_cap;/* ... and the page-locked buffer its text lands in */
+    double     t_submit_wait, t_submit, t_ticket;      /* SK_TIMING */
+    uint64_t   nchunks;
 } scan_worker;
 
 /* size of a worker's chunk buffer: SK_CHUNK_BYTES (4096 .. 63 MiB; tests use small ones: many flushes per file), default 32 MiB */
@@ -827,9 +844,13 @@ static int worker_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
 {
     scan_worker *w = (scan_worker *)user;
     int rc;
+    const double t0 = w->pool->timing ? now_s() : 0.0;
+    double t1;
     pthread_mutex_lock(&w->pool->submit_mu);
+    t1 = w->pool->timing ? now_s() : 0.0;
     rc = sk_scan_pinned(w->pool->ctx, chunk, nbytes, w->pool->col, &w->ticket[w->cur]);
     pthread_mutex_unlock(&w->pool->submit_mu);
+    if (w->pool->timing) { w->t_submit_wait += t1 - t0; w->t_submit += now_s() - t1; w->nchunks++; }
     w->used[w->cur] = 1;
     return rc;
 }
@@ -846,7 +867,11 @@ static uint8_t *worker_next_buf(void *user)
 {
     scan_worker *w = (scan_worker *)user;
     w->cur ^= 1;
-    if (w->used[w->cur]) sk_ticket_wait(w->pool->ctx, w->ticket[w->cur]);
+    if (w->used[w->cur]) {
+        const double t0 = w->pool->timing ? now_s() : 0.0;
+        sk_ticket_wait(w->pool->ctx, w->ticket[w->cur]);
+        if (w->pool->timing) w->t_ticket += now_s() - t0;
+    }
     return worker_buf(w, w->cur);
 }
 
@@ -887,13 +912,29 @@ static int parse_range(const scan_item *it, rec_fn fn, void *user, int64_t *nrec
     if (fd < 0) return SK_E_OPEN;
     if (fstat(fd, &st) != 0 || (uint64_t)st.st_size != it->size) { close(fd); return SK_E_SPLIT; }     /* (changed since the plan) */
     t = (const unsigned char *)mmap(NULL, (size_t)it->size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (t == MAP_FAILED) return SK_E_OPEN;
-    madvise((void *)t, (size_t)it->size, MADV_SEQUENTIAL);
+    if (t == MAP_FAILED) { close(fd); return SK_E_OPEN; }
+    /* the mapping serves the two guesses and the look at the byte behind the piece (a few pages); the piece's text is read()
+     * into a block of this thread's -- sixteen threads faulting mapped pages in wait for each other (parse_file above) */
     sa = parser_guess_start(t, it->size, it->a, 1);
     sb = it->b >= it->size ? it->size : parser_guess_start(t, it->size, it->b, 1);
     parser_init(&ps, fn, user);
-    for (i = sa; i < sb && ps.state != P_STOP; i += BLK) parser_feed(&ps, t + i, (size_t)(sb - i < BLK ? sb - i : BLK));
+    {
+        unsigned char *rb = (unsigned char *)malloc(BLK);
+        for (i = sa; i < sb && ps.state != P_STOP; ) {
+            const size_t want = (size_t)(sb - i < BLK ? sb - i : BLK);
+            size_t have = 0;
+            while (rb && have < want) {
+                const ssize_t r = pread(fd, rb + have, want - have, (off_t)(i + have));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) break;
+                have += (size_t)r;
+            }
+            if (rb && have == want) parser_feed(&ps, rb, want); else parser_feed(&ps, t + i, want);       /* (a failed read: out of the mapping) */
+            i += want;
+        }
+        free(rb);
+    }
+    close(fd);
     if (ps.state != P_STOP && sb < it->size && sb > sa)
         ok = parser_between_records(&ps) && (t[sb] == 0x3e || t[sb] == 0x40);
     /* a FASTQ record whose quality does not match its sequence ends the FILE for the reference (src/kseq.h:205-209 returns -2,
@@ -1177,10 +1218,21 @@ static void *pool_worker(void *arg)
         p->next++;
         progress_upto(p, p->item[i].line);
         pthread_mutex_unlock(&p->queue_mu);
-        rc = wrc != SK_OK ? wrc : worker_item(&w, &p->item[i], &bases);
-        pthread_mutex_lock(&p->queue_mu);
+        {
+            const double t0 = p->timing ? now_s() : 0.0;
+            rc = wrc != SK_OK ? wrc : worker_item(&w, &p->item[i], &bases);
+            pthread_mutex_lock(&p->queue_mu);
+            if (p->timing) p->t_item += now_s() - t0;
+        }
         p->bases += bases;
         if (rc < 0 && (p->rc == SK_OK || i < p->rc_index)) { p->rc = (int)rc; p->rc_index = i; }
+        pthread_mutex_unlock(&p->queue_mu);
+    }
+    if (p->timing) {
+        struct timespec ts;
+        pthread_mutex_lock(&p->queue_mu);
+        p->t_submit_wait += w.t_submit_wait; p->t_submit += w.t_submit; p->t_ticket += w.t_ticket; p->nchunks += w.nchunks;
+        if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0) p->t_cpu += (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
         pthread_mutex_unlock(&p->queue_mu);
     }
     worker_done(&w);
@@ -1292,6 +1344,7 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
     }
     if (no_split == 2) local_fail |= LIST_FAIL_GUARD;       /* (second scan after a failed cut: this rank could not put its column back) */
     memset(&pool, 0, sizeof pool);
+    pool.timing = getenv("SK_TIMING") != NULL;
     pool.ctx = ctx;
     pool.col = col;
     pthread_mutex_init(&pool.submit_mu, NULL);
@@ -1471,6 +1524,11 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
         for (i = 0; i < (uint32_t)nthreads; i++) pthread_create(&th[i], NULL, pool_worker, &pool);
         for (i = 0; i < (uint32_t)nthreads; i++) pthread_join(th[i], NULL);
         free(th);
+        if (pool.timing && err)
+            fprintf(err, "kmer_scrub_count timing: %s: %d decode threads, %u items, %llu chunks; summed over the threads: in items %.2f s, "
+                         "of it on a core %.2f s, waiting for the submit lock %.2f s, inside the submit %.2f s, waiting for a buffer's copy %.2f s\n",
+                    list_path, nthreads, pool.nitem, (unsigned long long)pool.nchunks, pool.t_item, pool.t_cpu, pool.t_submit_wait,
+                    pool.t_submit, pool.t_ticket);
     }
     if (!plan_only && ctx) {
         /* The agreement after the scan: what went wrong, anywhere.  The first list line whose file could not be opened (the

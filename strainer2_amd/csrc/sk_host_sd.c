@@ -222,7 +222,7 @@ static void stream_push(sd_stream *st, sd_chunk *c)
 }
 
 /* chunk builder of one parser: where finished chunks go depends on who parses */
-typedef struct sd_seg { unsigned char *buf; size_t n, cap; uint64_t seq; int is_last, borrowed; } sd_seg;   /* borrowed: buf points into the mapped file */
+typedef struct sd_seg { unsigned char *buf; size_t n, cap; uint64_t seq; int is_last, borrowed; int fd; uint64_t off; } sd_seg;   /* borrowed: buf points into the mapped file */
 typedef struct {
     sd_stream *st;
     sd_chunk  *cur;                          /* chunk under construction */
@@ -293,6 +293,8 @@ static int sd_on_record(void *user, char *seq, size_t len)
 static void *sd_parse_worker(void *arg)
 {
     sd_stream *st = (sd_stream *)arg;
+    unsigned char *rbuf = NULL;
+    size_t rcap = 0;
     pthread_setname_np(pthread_self(), "sk-parse");
     for (;;) {
         sd_seg *sg;
@@ -305,6 +307,7 @@ static void *sd_parse_worker(void *arg)
         if (st->segn == 0) {
             pthread_mutex_unlock(&st->pmu);
             pthread_mutex_lock(&t_pw_mu); cpu_parsers += thread_cpu_s(); pthread_mutex_unlock(&t_pw_mu);
+            free(rbuf);
             return NULL;
         }
         sg = st->segq[0];
@@ -317,6 +320,22 @@ static void *sd_parse_worker(void *arg)
         memset(&b, 0, sizeof b);
         b.st = st;
         parser_init(&ps, sd_on_record, &b);
+        if (sg->borrowed && sg->fd >= 0 && !st->cancel) {
+            /* a segment of a plain file: read into this thread's own buffer rather than parsed out of the mapping (round 4).
+             * Twelve threads faulting the mapping's pages in wait for each other behind the address space's lock (every large
+             * malloc/free of the lanes takes it for writing): BASELINE configs[4]'s share pass, same box, 6.65 / 6.47 s out of the
+             * mapping against 5.61 / 5.06 s with pread -- "waiting for the decode thread" 2.5-2.9 s against 1.6-2.0 s
+             * (profiles/r04_cfg5_pread.json; SK_SD_MAPPED=1 is the old way).  The copy costs about 0.05 s per GB and thread. */
+            size_t have = 0;
+            if (rcap < sg->n) { free(rbuf); rcap = sg->n + (sg->n >> 3); rbuf = (unsigned char *)malloc(rcap); }
+            while (rbuf && have < sg->n) {
+                const ssize_t r = pread(sg->fd, rbuf + have, sg->n - have, (off_t)(sg->off + have));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) break;
+                have += (size_t)r;
+            }
+            if (rbuf && have == sg->n) parser_feed(&ps, rbuf, sg->n); else parser_feed(&ps, sg->buf, sg->n);
+        } else
         if (!st->cancel) parser_feed(&ps, sg->buf, sg->n);
         if (!sg->is_last && ps.state != P_STOP && !parser_between_records(&ps)) ok = 0;
         if (ps.state != P_STOP || ps.end_kind != SKP_END_NONE) { /* (stopped by cancel or by a truncated record: the ending stands) */ }
@@ -387,6 +406,7 @@ static void *sd_decode_thread(void *arg)
      * FASTA against what the parser itself does); anything that cannot be mapped, or SK_ZLIB=1: gzread */
     const unsigned char *map = NULL;
     size_t mlen = 0;
+    int map_fd = -1;
     if (!own && !getenv("SK_ZLIB")) {
         const int fd = open(st->path, O_RDONLY);
         struct stat sb;
@@ -394,7 +414,7 @@ static void *sd_decode_thread(void *arg)
             void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) { map = (const unsigned char *)m; mlen = (size_t)sb.st_size; madvise(m, mlen, MADV_SEQUENTIAL); }
         }
-        if (fd >= 0) close(fd);
+        if (fd >= 0 && map && !getenv("SK_SD_MAPPED")) map_fd = fd; else if (fd >= 0) close(fd);       /* (the map stays: the cutting below looks at a few of its pages) */
         if (map && mlen >= 2 && map[0] == 0x1f && map[1] == 0x8b) { munmap((void *)map, mlen); map = NULL; }   /* (gzip after all: zlib) */
     }
     if (st->par > 1 && (own || map)) {
@@ -428,6 +448,8 @@ static void *sd_decode_thread(void *arg)
                 sg->buf = (unsigned char *)map + at;
                 sg->n = cut - at;
                 sg->borrowed = 1;
+                sg->fd = map_fd;
+                sg->off = at;
                 sg->seq = seq++;
                 sg->is_last = cut == mlen;
                 sd_seg_dispatch(st, sg);
@@ -523,6 +545,7 @@ static void *sd_decode_thread(void *arg)
     }
     if (own) skzp_close(&zp);
     if (map) sd_unmap_later((void *)map, mlen);
+    if (map_fd >= 0) close(map_fd);
     free(blk);
     pthread_mutex_lock(&t_pw_mu); cpu_readers += thread_cpu_s(); pthread_mutex_unlock(&t_pw_mu);
     return NULL;
