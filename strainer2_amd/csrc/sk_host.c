@@ -101,7 +101,9 @@ static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords
         const int fd = open(path, O_RDONLY);
         struct stat sb;
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
-            enum { RBLK = 4 << 20 };
+            const char *e = getenv("SK_READ_BLOCK");                /* (64 bytes -- tests -- .. 32 MiB; default 4 MiB) */
+            const long long ev = e ? atoll(e) : 0;
+            const size_t RBLK = ev >= 64 && ev <= (32 << 20) ? (size_t)ev : (size_t)4 << 20;
             unsigned char *rb = (unsigned char *)malloc(RBLK);
             if (rb) {
                 (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);

@@ -290,6 +290,14 @@ static int sd_on_record(void *user, char *seq, size_t len)
  * (src/kseq.h:171-211 reads from the top; nothing here changes what a record is).  A failed check fails the run with
  * a message (SK_NO_SPLIT=1 turns the cutting off) -- it is never papered over.  Chunks reach the queue in segment
  * order: the replay of the reference's read-after-read bookkeeping (src/strain_detect.c:443-626) sees the file's order. */
+/* bytes per pread of a parser thread: SK_READ_BLOCK (64 bytes -- tests -- .. 32 MiB), default 2 MiB */
+static size_t sd_read_block(void)
+{
+    const char *e = getenv("SK_READ_BLOCK");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 64 && v <= (32 << 20) ? (size_t)v : (size_t)2 << 20;
+}
+
 static void *sd_parse_worker(void *arg)
 {
     sd_stream *st = (sd_stream *)arg;
@@ -326,15 +334,22 @@ static void *sd_parse_worker(void *arg)
              * malloc/free of the lanes takes it for writing): BASELINE configs[4]'s share pass, same box, 6.65 / 6.47 s out of the
              * mapping against 5.61 / 5.06 s with pread -- "waiting for the decode thread" 2.5-2.9 s against 1.6-2.0 s
              * (profiles/r04_cfg5_pread.json; SK_SD_MAPPED=1 is the old way).  The copy costs about 0.05 s per GB and thread. */
-            size_t have = 0;
-            if (rcap < sg->n) { free(rbuf); rcap = sg->n + (sg->n >> 3); rbuf = (unsigned char *)malloc(rcap); }
-            while (rbuf && have < sg->n) {
-                const ssize_t r = pread(sg->fd, rbuf + have, sg->n - have, (off_t)(sg->off + have));
-                if (r < 0 && errno == EINTR) continue;
-                if (r <= 0) break;
-                have += (size_t)r;
+            /* ... in blocks that stay in the core's cache between the copy and the parse (the parser takes its text in any
+             * pieces; a whole segment at a time was measured too: the copy then goes out to memory and comes back) */
+            size_t done = 0;
+            if (!rbuf) { rcap = sd_read_block(); rbuf = (unsigned char *)malloc(rcap); }
+            while (done < sg->n && ps.state != P_STOP && !st->cancel) {
+                const size_t want = sg->n - done < rcap ? sg->n - done : rcap;
+                size_t have = 0;
+                while (rbuf && have < want) {
+                    const ssize_t r = pread(sg->fd, rbuf + have, want - have, (off_t)(sg->off + done + have));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) break;
+                    have += (size_t)r;
+                }
+                if (rbuf && have == want) parser_feed(&ps, rbuf, want); else parser_feed(&ps, sg->buf + done, want);    /* (a failed read: out of the mapping) */
+                done += want;
             }
-            if (rbuf && have == sg->n) parser_feed(&ps, rbuf, sg->n); else parser_feed(&ps, sg->buf, sg->n);
         } else
         if (!st->cancel) parser_feed(&ps, sg->buf, sg->n);
         if (!sg->is_last && ps.state != P_STOP && !parser_between_records(&ps)) ok = 0;

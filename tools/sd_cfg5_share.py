@@ -106,6 +106,8 @@ def main():
                               ("parse_threads_8", {"SK_PARSE_THREADS": "8"}),
                               ("parse_threads_8_chunks_of_128_mib", {"SK_PARSE_THREADS": "8", "SK_SD_CHUNK_BYTES": str(128 << 20)}),
                               ("mapped_segments", {"SK_SD_MAPPED": "1"}), ("default_again", {}),
+                              ("read_block_512k", {"SK_READ_BLOCK": str(512 << 10)}), ("read_block_1m", {"SK_READ_BLOCK": str(1 << 20)}),
+                              ("read_block_4m", {"SK_READ_BLOCK": str(4 << 20)}), ("read_block_32m", {"SK_READ_BLOCK": str(32 << 20)}),
                               ("two_logical_devices_one_card", {"SK_DEVICES": "0,0", "SK_SD_GROUP": "16"})):
                 if os.environ.get("VARIANTS") not in ("1", "all") and name not in os.environ["VARIANTS"].split(","):
                     continue
