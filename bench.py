@@ -21,7 +21,7 @@ frac = achieved / 8 TB/s.  SURVEY 8(d)'s model figure (7.4 B/base: one 8-byte pr
 beside it as `survey_model_*`: this kernel answers 16 windows with one filter block and never moves those
 bytes, so that figure is not a fraction of anything.  traffic = measured HBM bytes per launch from the PMC
 passes of tools/profile.sh, taken from profiles/traffic.json ONLY if that file was measured on this very
-sk_device.hip (sha256 stamp), else null.
+sk_device.hip + sk_dev_*.hip.h (sha256 stamp), else null.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu]
   N > 1, either way:
@@ -206,8 +206,14 @@ def load_cfg2_facts(args):
 
 
 def device_source_sha():
-    with open(os.path.join(REPO, "strainer2_amd", "csrc", "sk_device.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+    """sha256 over the device translation unit: sk_device.hip and the sk_dev_*.hip.h parts it includes (names and bytes, in name order)"""
+    d = os.path.join(REPO, "strainer2_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ["sk_device.hip"] + sorted(n for n in os.listdir(d) if n.startswith("sk_dev_") and n.endswith(".hip.h")):
+        h.update(name.encode() + b"\0")
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def measured_traffic(args, kernel_name):
@@ -223,7 +229,7 @@ def measured_traffic(args, kernel_name):
     if tj.get("reads") != args.reads or tj.get("kernel") != kernel_name:
         return None, "profiles/traffic.json is for another workload/kernel"
     if tj.get("sk_device_hip_sha256") != device_source_sha():
-        return None, "profiles/traffic.json was measured on another version of sk_device.hip (stale): re-run tools/profile.sh"
+        return None, "profiles/traffic.json was measured on another version of sk_device.hip / sk_dev_*.hip.h (stale): re-run tools/profile.sh"
     return tj.get("hbm_bytes_per_launch"), tj.get("correction")
 
 

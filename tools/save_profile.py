@@ -9,6 +9,18 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+
+
+def device_source_sha():
+    """the same stamp as bench.py's device_source_sha(): sk_device.hip and its sk_dev_*.hip.h parts, names and bytes, in name order"""
+    d = os.path.join("strainer2_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ["sk_device.hip"] + sorted(n for n in os.listdir(d) if n.startswith("sk_dev_") and n.endswith(".hip.h")):
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 # the NEWEST run of the tag (tools/profile.sh writes every run into gpurun_out/prof_TAG_<time>; gpurun merges them all into this
 # directory, so "the" run must be chosen, never globbed): by the directory's own time stamp in its name
 runs = sorted(d for d in glob.glob(os.path.join("gpurun_out", "prof_" + tag + "_*")) if os.path.isfile(os.path.join(d, "summary.json")))
@@ -47,7 +59,7 @@ t = {"kernel": [n for n in s["kernels"] if "sk_scan_grid" in n][0].split("<")[0]
      "streaming_share_bytes": stream_bytes,
      "vector_instructions_per_launch": c.get("SQ_INSTS_VALU"), "gpu_cycles_per_launch_per_xcd": (c.get("GRBM_GUI_ACTIVE") or 0) / 8 or None,
      "tcc_requests_per_launch": c.get("TCC_REQ_sum"),
-     "sk_device_hip_sha256": hashlib.sha256(open("strainer2_amd/csrc/sk_device.hip", "rb").read()).hexdigest(),
+     "sk_device_hip_sha256": device_source_sha(),
      "correction": "FETCH_SIZE raw + half of the record stream's bytes (gfx950: 128-B streaming requests are tallied at 64 B; "
                    "applied to the streaming share only, random lookups as counted) + WRITE_SIZE (exact). Separate --pmc passes (tools/profile.sh).",
      "source": f"profiles/{tag}_summary.txt", "run": src}
