@@ -33,8 +33,9 @@ FACTS = os.path.join(REPO, "tests", "golden", "cfg5_share_facts.json")
 
 
 def run(exe, argv, **env):
+    prefix = env.pop("_PREFIX", "").split()                  # (a variant may put a launcher in front: "taskset -c 0-63,128-191")
     t = time.time()
-    p = subprocess.run([exe] + argv, cwd=WORK, capture_output=True, env=dict(os.environ, SK_SD_TIMING="1", **env))
+    p = subprocess.run(prefix + [exe] + argv, cwd=WORK, capture_output=True, env=dict(os.environ, SK_SD_TIMING="1", **env))
     return p, time.time() - t
 
 
@@ -106,6 +107,8 @@ def main():
                               ("parse_threads_8", {"SK_PARSE_THREADS": "8"}),
                               ("parse_threads_8_chunks_of_128_mib", {"SK_PARSE_THREADS": "8", "SK_SD_CHUNK_BYTES": str(128 << 20)}),
                               ("mapped_segments", {"SK_SD_MAPPED": "1"}), ("default_again", {}),
+                              ("cpus_of_node_0", {"_PREFIX": "taskset -c 0-63,128-191"}), ("cpus_of_node_1", {"_PREFIX": "taskset -c 64-127,192-255"}),
+                              ("cpus_of_node_0_again", {"_PREFIX": "taskset -c 0-63,128-191"}), ("cpus_of_node_1_again", {"_PREFIX": "taskset -c 64-127,192-255"}),
                               ("read_block_512k", {"SK_READ_BLOCK": str(512 << 10)}), ("read_block_1m", {"SK_READ_BLOCK": str(1 << 20)}),
                               ("read_block_4m", {"SK_READ_BLOCK": str(4 << 20)}), ("read_block_32m", {"SK_READ_BLOCK": str(32 << 20)}),
                               ("two_logical_devices_one_card", {"SK_DEVICES": "0,0", "SK_SD_GROUP": "16"})):
