@@ -95,6 +95,7 @@ struct sk_ctx {
     uint8_t     *d_stage[SK_NSTAGE];
     hipEvent_t   stage_done[SK_NSTAGE];
     int          stage_next;
+    hipStream_t  copy_stream;          // sk_scan_pinned's uploads: the next chunk's copy runs while this chunk is scanned
     hipEvent_t   copied[64];           // ring of "host buffer of ticket t has been read" events
     uint64_t     tickets;              // tickets issued so far
     // flags: [0] wide windows seen in the current batch, [1] table build errors
@@ -249,6 +250,7 @@ extern "C" void sk_ctx_destroy(sk_ctx *c)
         if (c->d_stage[i]) hipFree(c->d_stage[i]);
         if (c->stage_done[i]) hipEventDestroy(c->stage_done[i]);
     }
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_free) hipEventDestroy(e);
     for (int i = 0; i < 64; i++) if (c->copied[i]) hipEventDestroy(c->copied[i]);
@@ -1260,6 +1262,7 @@ static int sk_stage_init(sk_ctx *c)
         SK_HIP(c, hipMalloc((void **)&c->d_stage[i], SK_STAGE_BYTES));
         SK_HIP(c, hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming));
     }
+    SK_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     return SK_OK;
 }
 
@@ -1352,9 +1355,14 @@ extern "C" int sk_scan_pinned(sk_ctx *c, const uint8_t *pinned, uint64_t nbytes,
     else SK_HIP(c, hipEventSynchronize(ev));                     // ring slot of ticket t-64
     const int b = c->stage_next;
     c->stage_next = (b + 1) % SK_NSTAGE;
-    SK_HIP(c, hipEventSynchronize(c->stage_done[b]));
-    if (nbytes) SK_HIP(c, hipMemcpyAsync(c->d_stage[b], pinned, nbytes, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(c, hipEventRecord(ev, c->stream));
+    // The copy goes on a stream of its own and waits THERE for the scan that read this device buffer last; the scan waits for the
+    // copy.  So chunk n+1 is on the link while chunk n is scanned, and the caller (a decode thread holding the submit lock) does
+    // not wait for the device at all -- its back-pressure is the ticket of its own two buffers.  (Round 4: copy and scan took
+    // turns on one stream, 0.65 + 0.05 ms a chunk, and the submit waited on the host for the buffer two chunks back.)
+    SK_HIP(c, hipStreamWaitEvent(c->copy_stream, c->stage_done[b], 0));       // (never recorded yet = done)
+    if (nbytes) SK_HIP(c, hipMemcpyAsync(c->d_stage[b], pinned, nbytes, hipMemcpyHostToDevice, c->copy_stream));
+    SK_HIP(c, hipEventRecord(ev, c->copy_stream));
+    SK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));                          // (before anything else: sk_sync / sk_pinned_free wait on c->stream alone)
     rc = sk_launch_scan(c, c->d_stage[b], nbytes, 0, col);
     if (rc) return rc;
     SK_HIP(c, hipEventRecord(c->stage_done[b], c->stream));
