@@ -422,6 +422,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed passes (1000 x 0.8 ms: long enough for an outside GPU-busy sampler to see)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed launches of the same scan before the W warmup steps, for this long: the card's clocks ramp over the first ~100 "
+                         "launches (20 timed steps straight after start: 0.648 ms a launch; after 0.3 s of launches: 0.610) -- reported as preheat_* in the line; 0 = none")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (cfg 2: 10 M)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--strain-bp", type=int, default=5_000_000, help="size of the synthetic strain (cfg 2: 5 Mbp); other sizes are for sweeps, not for `value`")
@@ -503,6 +506,14 @@ def main():
 
     from strainer2_amd.dist import allreduce_counts
 
+    preheat_launches = 0
+    if args.preheat_ms > 0:                 # bring the card to its running clocks (untimed; the counters are zeroed below)
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+            for _ in range(20):
+                ctx.scan_device(dev, nbytes, 2)
+            ctx.sync()
+            preheat_launches += 20
     for _ in range(args.warmup):
         ctx.scan_device(dev, nbytes, 2)
     if world > 1:
@@ -699,7 +710,7 @@ def main():
         traffic, traffic_note = measured_traffic(args, kernel_name)
         line = {
             "metric": "metagenome bases/sec scanned at k=31", "value": value, "unit": "bases/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_ms": args.preheat_ms, "preheat_launches": preheat_launches,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[1]: 5 Mbp synthetic strain (-r) vs %d x %d bp synthetic reads (-B) per GPU, k=31, "
