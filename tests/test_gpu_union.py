@@ -139,3 +139,50 @@ def test_union_refuses_what_it_cannot_hold():
         a.set_option("text_stage", 0)
         with pytest.raises(sk.SKError):
             sk.KmerUnion([a])
+
+
+def test_union_a_million_short_records_against_the_members():
+    """more than 16 x 65,536 records in one batch, most of them hitting: the compaction's workgroups take sixteen sets of 64 records
+    each (sk_union_post), the pairs and log entries outnumber what travels home with the counters (SK_UNION_EAGER: the rest is
+    fetched behind them) -- member by member the tallies and the log must be the member's own"""
+    rng = np.random.default_rng(20260405)
+    prng = random.Random(7)
+    base = _synth.rand_dna(prng, 60000)
+    strains = [base, _mutate(prng, base, 0.01), _synth.rand_dna(prng, 30000), _synth.revcomp(base[20000:]) + _synth.rand_dna(prng, 500)]
+    nrec, L = 1_050_000, 48
+    arrs = [np.frombuffer(g, dtype=np.uint8) for g in strains]
+    reads = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(nrec, L + 1))].copy()
+    which = rng.integers(0, len(strains) + 2, size=nrec)                  # (a third of the reads are random)
+    for s, a in enumerate(arrs):
+        rows = np.nonzero(which == s)[0]
+        st = rng.integers(0, len(a) - L, size=len(rows))
+        reads[rows, :L] = a[st[:, None] + np.arange(L)[None, :]]
+    reads[:, L] = ord("\n")
+    stream = reads.tobytes()
+    starts = (np.arange(nrec, dtype=np.uint64) * (L + 1)).astype(np.uint32)
+    ctxs, sets, want = [], [], []
+    try:
+        for g in strains:
+            ks = sk.Keyset.from_stream(g + b"\n", default_val=1, incr=0)
+            c = sk.KmerContext(0)
+            c.load_keyset(ks, 6)
+            typ = np.ones(ks.nrows, dtype=np.uint32)
+            typ[::37] = 2
+            c.set_counts(0, typ)
+            ctxs.append(c)
+            sets.append(ks)
+            want.append(c.tally_batch(stream, starts, 0, 2))
+        with sk.KmerUnion(ctxs, 0, 2) as u:
+            tally, hits = u.tally_batch(stream, starts, hits_cap=8_000_000)
+        assert int((tally[:, :, 0] > 0).sum()) > 16384 * 8 and len(hits) > 16384 * 4       # (far beyond what comes back with the counters)
+        for s in range(len(strains)):
+            wt, wh = want[s]
+            assert np.array_equal(tally[:, s, :], wt), s
+            mine = hits[hits[:, 0] == s][:, 1:]
+            wh = wh[np.lexsort((wh[:, 1], wh[:, 0]))]
+            assert np.array_equal(mine, wh), (s, len(mine), len(wh))
+    finally:
+        for c in ctxs:
+            c.close()
+        for k in sets:
+            k.close()
