@@ -1,4 +1,6 @@
 """Small deterministic input generators shared by the tests."""
+import json
+import os
 import random
 
 COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
@@ -35,3 +37,20 @@ def fuzz_stream(rng: random.Random, strain: bytes, nreads: int, junk=b"NnRYKMUu-
                 r[i] = r[i] | 0x20
         out.append(bytes(r))
     return b"\n".join(out) + b"\n"
+
+
+
+def two_expansions_strain(golden, tmp_path):
+    """the 9.2 Mbp strain of tests/golden/make_two_expansions_facts.py, written again by that script's own function; None if this
+    numpy draws another sequence than the one the reference saw (the facts carry the file's md5)"""
+    import hashlib
+    import importlib.util
+    facts = json.load(open(os.path.join(golden, "two_expansions_facts.json")))
+    spec = importlib.util.spec_from_file_location("make_two_expansions_facts", os.path.join(golden, "make_two_expansions_facts.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = str(tmp_path / "strain.fa")
+    mod.write_strain(path)
+    if hashlib.md5(open(path, "rb").read()).hexdigest() != facts["strain"]["md5"]:
+        return None, facts
+    return path, facts

@@ -102,6 +102,28 @@ def test_program_bundled_example_md5(golden, tmp_path):
     assert h.hexdigest() == facts["stdout_md5"] == "75989a9bc31ef0b6f53a5112a60920bd"
 
 
+def test_program_table_after_two_expansions_md5(golden, tmp_path):
+    """a 9.2 Mbp strain: the reference's hash table grows twice (8 M -> 16 M -> 32 M slots, src/BIO_hash.c:129-139), and the row
+    order of its TSV is what that leaves.  The program's whole stdout (350 MB) against the md5 of the UNMODIFIED reference's
+    (tests/golden/two_expansions_facts.json, made by tests/golden/make_two_expansions_facts.py)."""
+    path, facts = _synth.two_expansions_strain(golden, tmp_path)
+    if path is None:
+        pytest.skip("this numpy's generator draws another strain than the one the facts were made from")
+    for n in ("A.txt", "B.txt"):
+        (tmp_path / n).write_text("")
+    out = tmp_path / "table.tsv"
+    with open(out, "wb") as f:
+        p = subprocess.run([sk.cli_path(), "-r", path, "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")], stdout=f, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stderr == b""
+    h = hashlib.md5()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert os.path.getsize(out) == facts["stdout_bytes"]
+    assert h.hexdigest() == facts["stdout_md5"]
+    os.unlink(out)
+
+
 @pytest.mark.parametrize("seed,junk", [(1, 0.0), (2, 0.01), (3, 0.05)])
 def test_scan_stream_fuzz_vs_oracle(ctx, seed, junk):
     """Random streams with junk bytes / case / N / U / IUPAC, strain with IUPAC letters too."""

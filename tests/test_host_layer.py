@@ -66,6 +66,35 @@ def test_keyset_bundled_strain_order_and_doubling(golden):
     assert np.array_equal(ocounts[:, 0], ks.first_count())
 
 
+def test_keyset_order_after_two_expansions_is_the_references(golden, tmp_path):
+    """9.2 M keys: the reference's table grows at its 4,000,001st AND its 8,000,001st distinct k-mer (src/BIO_hash.c:129-139,39-61),
+    every earlier case grows once at most at the real initial size.  Row order (the keys packed to 62 bits, md5) and the
+    reference_count column of the host's replay and of the oracle against the UNMODIFIED reference's table
+    (tests/golden/two_expansions_facts.json)."""
+    import hashlib
+    path, facts = _synth.two_expansions_strain(golden, tmp_path)
+    if path is None:
+        pytest.skip("this numpy's generator draws another strain than the one the facts were made from")
+    ks = sk.Keyset.from_file(path)
+    assert ks.nrows == facts["rows"] and ks.final_slots == 32000000 and ks.nwide == 0
+    assert hashlib.md5(ks.packed().astype("<u8").tobytes()).hexdigest() == facts["packed_keys_md5_u64_le"]
+    assert hashlib.md5(ks.first_count().astype("<u4").tobytes()).hexdigest() == facts["reference_count_md5_u32_le"]
+    # the oracle restatement at the same size
+    t = _oracle.OracleTable()
+    assert t.build_file(path) == 0 and t.size == facts["rows"] and t.capacity == 32000000
+    okeys, ocounts = t.rows()
+    code = np.zeros(256, dtype=np.uint64)
+    code[list(b"ACGT")] = np.arange(4, dtype=np.uint64)
+    kb = np.frombuffer(b"".join(okeys), dtype=np.uint8).reshape(-1, 31)
+    packed = np.zeros(len(okeys), dtype=np.uint64)
+    for i in range(31):
+        packed = (packed << np.uint64(2)) | code[kb[:, i]]
+    assert np.array_equal(packed, ks.packed())
+    assert np.array_equal(ocounts[:, 0], ks.first_count())
+    t.close()
+    ks.close()
+
+
 def test_keyset_short_record_policy(golden):
     d = os.path.join(golden, "cases", "short_contig")
     ks = sk.Keyset.from_file(os.path.join(d, "strain.fa"))
