@@ -132,6 +132,7 @@ typedef struct {
     size_t      carry_last_len;              /* length of the last record handed out so far (for an END_STALE ending) */
     int         split_failed;                /* a segment did not end between two records */
     int         cancel_segments;             /* the file is over for the reader (truncated record): later segments are dropped */
+    int         in_mode;                     /* SD_IN_*: how the parser threads get at the bytes of a mapped plain file's segments */
     /* consumer */
     sd_chunk   *c; uint32_t ci;
     int         eof, end_kind; size_t end_len;
@@ -222,6 +223,7 @@ static void stream_push(sd_stream *st, sd_chunk *c)
 }
 
 /* chunk builder of one parser: where finished chunks go depends on who parses */
+enum { SD_IN_POPULATE = 0, SD_IN_PREAD = 1, SD_IN_MAPPED = 2 };
 typedef struct sd_seg { unsigned char *buf; size_t n, cap; uint64_t seq; int is_last, borrowed; int fd; uint64_t off; } sd_seg;   /* borrowed: buf points into the mapped file */
 typedef struct {
     sd_stream *st;
@@ -328,27 +330,47 @@ static void *sd_parse_worker(void *arg)
         memset(&b, 0, sizeof b);
         b.st = st;
         parser_init(&ps, sd_on_record, &b);
-        if (sg->borrowed && sg->fd >= 0 && !st->cancel) {
-            /* a segment of a plain file: read into this thread's own buffer rather than parsed out of the mapping (round 4).
-             * Twelve threads faulting the mapping's pages in wait for each other behind the address space's lock (every large
-             * malloc/free of the lanes takes it for writing): BASELINE configs[4]'s share pass, same box, 6.65 / 6.47 s out of the
-             * mapping against 5.61 / 5.06 s with pread -- "waiting for the decode thread" 2.5-2.9 s against 1.6-2.0 s
-             * (profiles/r04_cfg5_pread.json; SK_SD_MAPPED=1 is the old way).  The copy costs about 0.05 s per GB and thread. */
-            /* ... in blocks that stay in the core's cache between the copy and the parse (the parser takes its text in any
-             * pieces; a whole segment at a time was measured too: the copy then goes out to memory and comes back) */
-            size_t done = 0;
-            if (!rbuf) { rcap = sd_read_block(); rbuf = (unsigned char *)malloc(rcap); }
-            while (done < sg->n && ps.state != P_STOP && !st->cancel) {
-                const size_t want = sg->n - done < rcap ? sg->n - done : rcap;
-                size_t have = 0;
-                while (rbuf && have < want) {
-                    const ssize_t r = pread(sg->fd, rbuf + have, want - have, (off_t)(sg->off + done + have));
-                    if (r < 0 && errno == EINTR) continue;
-                    if (r <= 0) break;
-                    have += (size_t)r;
+        if (sg->borrowed && !st->cancel) {
+            /* A segment of a plain file: it points into the mapping of the whole file.  Three ways to get at its bytes (round 4):
+             *   SD_IN_POPULATE (default)  the segment's pages are put into the address space by ONE call, parsed where they lie, and
+             *       taken out again by one call: no copy, no trap per 64 KiB of text, and the address space's lock is only ever
+             *       taken for READING -- BASELINE configs[4]'s share pass 3.5-3.6 s, 40 CPU-seconds;
+             *   SD_IN_PREAD               read into a buffer of this thread's, in blocks that stay in the core's cache between the
+             *       copy and the parse: 3.9-4.1 s on the same box, 48 CPU-seconds -- a sampling of the program counter says 59 % of
+             *       a parser thread's time is the kernel's copy (tools/probes/sigprof_preload.c); also where the kernel has no
+             *       MADV_POPULATE_READ (before 5.14);
+             *   SD_IN_MAPPED              parsed out of the mapping, every page faulted in where it is first touched: 5.1-6.7 s.  Not
+             *       the faults themselves: the file's munmap at its end tears 2.7 M page-table entries down under the lock for
+             *       WRITING, and the next file's faults wait a third of a second for it, file after file.
+             * (profiles/r04_cfg5_pread.json, r04_cfg5_read_blocks.json, r04_cfg5_populate.json; SK_SD_INPUT=populate|pread|mapped) */
+            int mode = st->in_mode;
+            const uintptr_t pa = (uintptr_t)sg->buf & ~(uintptr_t)4095u, pe = ((uintptr_t)sg->buf + sg->n + 4095u) & ~(uintptr_t)4095u;
+            if (mode == SD_IN_POPULATE) {
+#ifdef MADV_POPULATE_READ
+                if (madvise((void *)pa, (size_t)(pe - pa), MADV_POPULATE_READ) != 0 && errno == EINVAL) st->in_mode = mode = SD_IN_PREAD;   /* (an older kernel: from now on the copy) */
+#else
+                st->in_mode = mode = SD_IN_PREAD;
+#endif
+            }
+            if (mode == SD_IN_PREAD && sg->fd >= 0) {
+                size_t done = 0;
+                if (!rbuf) { rcap = sd_read_block(); rbuf = (unsigned char *)malloc(rcap); }
+                while (done < sg->n && ps.state != P_STOP && !st->cancel) {
+                    const size_t want = sg->n - done < rcap ? sg->n - done : rcap;
+                    size_t have = 0;
+                    while (rbuf && have < want) {
+                        const ssize_t r = pread(sg->fd, rbuf + have, want - have, (off_t)(sg->off + done + have));
+                        if (r < 0 && errno == EINTR) continue;
+                        if (r <= 0) break;
+                        have += (size_t)r;
+                    }
+                    if (rbuf && have == want) parser_feed(&ps, rbuf, want); else parser_feed(&ps, sg->buf + done, want);    /* (a failed read: out of the mapping) */
+                    done += want;
                 }
-                if (rbuf && have == want) parser_feed(&ps, rbuf, want); else parser_feed(&ps, sg->buf + done, want);    /* (a failed read: out of the mapping) */
-                done += want;
+            } else parser_feed(&ps, sg->buf, sg->n);
+            if (mode == SD_IN_POPULATE) {               /* (whole pages inside the segment only: a neighbour may still be reading the ones at its ends) */
+                const uintptr_t da = ((uintptr_t)sg->buf + 4095u) & ~(uintptr_t)4095u, de = ((uintptr_t)sg->buf + sg->n) & ~(uintptr_t)4095u;
+                if (de > da) (void)madvise((void *)da, (size_t)(de - da), MADV_DONTNEED);
             }
         } else
         if (!st->cancel) parser_feed(&ps, sg->buf, sg->n);
@@ -429,7 +451,7 @@ static void *sd_decode_thread(void *arg)
             void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) { map = (const unsigned char *)m; mlen = (size_t)sb.st_size; madvise(m, mlen, MADV_SEQUENTIAL); }
         }
-        if (fd >= 0 && map && !getenv("SK_SD_MAPPED")) map_fd = fd; else if (fd >= 0) close(fd);       /* (the map stays: the cutting below looks at a few of its pages) */
+        if (fd >= 0 && map) map_fd = fd; else if (fd >= 0) close(fd);       /* (kept open for the parser threads' pread, should they go that way) */
         if (map && mlen >= 2 && map[0] == 0x1f && map[1] == 0x8b) { munmap((void *)map, mlen); map = NULL; }   /* (gzip after all: zlib) */
     }
     if (st->par > 1 && (own || map)) {
@@ -585,6 +607,10 @@ static int stream_open(sd_stream *st, const char *path, int gz_threads)
     st->path = path;
     st->gz_threads = gz_threads;
     st->chunk_bytes = sd_chunk_bytes();
+    {   /* SK_SD_INPUT=populate|pread|mapped (SK_SD_MAPPED=1: the round-3 way, kept for the A/B) */
+        const char *e = getenv("SK_SD_INPUT");
+        st->in_mode = e && !strcmp(e, "pread") ? SD_IN_PREAD : (e && !strcmp(e, "mapped")) || getenv("SK_SD_MAPPED") ? SD_IN_MAPPED : SD_IN_POPULATE;
+    }
     {   /* parser threads for this file: when the budget leaves several threads per file (the case of one or two big
          * metagenomes), a quarter of them parse; SK_PARSE_THREADS sets the number, SK_NO_SPLIT=1 means one */
         const char *e = getenv("SK_PARSE_THREADS");

@@ -375,6 +375,7 @@ def test_strain_detect_parser_threads_give_the_serial_result(sd_host_exe, tmp_pa
     _sd_inputs(tmp_path, 77)
     base = ["-r", str(tmp_path / "s.fa"), "-a", str(tmp_path / "s.inf.gz"), "-B", str(tmp_path / "B.txt")]
     env = dict(ENV, TSAN_OPTIONS="halt_on_error=1", SK_THREADS="4", SK_SD_CHUNK_BYTES=chunk, SK_PARSE_THREADS="3", SK_READ_BLOCK="257")      # (257: a segment is pread in many pieces, cut anywhere)
+    env["SK_SD_INPUT"] = {"700": "pread", "5000": "mapped"}.get(chunk, "populate")      # the three ways a parser thread gets at a mapped file's segment
     par = subprocess.run([sd_host_exe] + base + ["-o", str(tmp_path / "par.gz")], env=env, capture_output=True)
     for bad in (b"runtime error", b"AddressSanitizer", b"ThreadSanitizer"):
         assert bad not in par.stderr, par.stderr.decode()[-3000:]

@@ -1,7 +1,7 @@
 /* tools/probes/parse_probe.c -- what ONE parser thread delivers: a plain FASTA/FASTQ file, mapped, fed to the product's record
  * parser (strainer2_amd/csrc/sk_parser.h) in blocks, every record of k bases or more copied behind the others with a '\n' as the
  * chunk builders do.  Prints GB/s of file and Gbase/s.   gcc -O2 -o tools/probes/parse_probe tools/probes/parse_probe.c
- *   tools/probes/parse_probe FILE [block bytes, default 4 MiB] [HEADER=path of another sk_parser.h to compare: compile time only] */
+ *   [OUT_MB=640] tools/probes/parse_probe FILE [block bytes, default 4 MiB] [HEADER=path of another sk_parser.h to compare: compile time only] */
 #include <fcntl.h>
 #include <stdio.h>
 #include <sys/mman.h>
@@ -35,7 +35,7 @@ int main(int argc, char **argv)
     if (fd < 0 || fstat(fd, &sb)) { perror(argv[1]); return 1; }
     m = (const unsigned char *)mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (m == MAP_FAILED) { perror("mmap"); return 1; }
-    out_cap = 32u << 20; out = (unsigned char *)malloc(out_cap);
+    out_cap = (size_t)(getenv("OUT_MB") ? atol(getenv("OUT_MB")) : 32) << 20; out = (unsigned char *)malloc(out_cap);     /* (OUT_MB: the chunk builders cycle through 20 x 32 MiB) */
     for (rep = 0; rep < 3; rep++) {
         parser ps;
         double t0 = now(), dt;

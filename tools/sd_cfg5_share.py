@@ -106,11 +106,14 @@ def main():
                               ("parse_threads_2", {"SK_PARSE_THREADS": "2"}), ("parse_threads_6", {"SK_PARSE_THREADS": "6"}),
                               ("parse_threads_8", {"SK_PARSE_THREADS": "8"}),
                               ("parse_threads_8_chunks_of_128_mib", {"SK_PARSE_THREADS": "8", "SK_SD_CHUNK_BYTES": str(128 << 20)}),
-                              ("mapped_segments", {"SK_SD_MAPPED": "1"}), ("default_again", {}),
+                              ("default_again", {}), ("input_pread", {"SK_SD_INPUT": "pread"}), ("input_mapped", {"SK_SD_INPUT": "mapped"}),
+                              ("default_once_more", {}), ("input_pread_again", {"SK_SD_INPUT": "pread"}),
+                              # (sampled: gcc -O2 -shared -fPIC -o /tmp/sigprof.so tools/probes/sigprof_preload.c -ldl first; tools/sigprof_report.py reads the samples)
+                              ("sigprof", {"LD_PRELOAD": "/tmp/sigprof.so", "SK_LEAK_AT_EXIT": "0", "SK_PROF_OUT": os.path.join(REPO, "gpurun_out", "sigprof_sd.txt")}),
                               ("cpus_of_node_0", {"_PREFIX": "taskset -c 0-63,128-191"}), ("cpus_of_node_1", {"_PREFIX": "taskset -c 64-127,192-255"}),
                               ("cpus_of_node_0_again", {"_PREFIX": "taskset -c 0-63,128-191"}), ("cpus_of_node_1_again", {"_PREFIX": "taskset -c 64-127,192-255"}),
-                              ("read_block_512k", {"SK_READ_BLOCK": str(512 << 10)}), ("read_block_1m", {"SK_READ_BLOCK": str(1 << 20)}),
-                              ("read_block_4m", {"SK_READ_BLOCK": str(4 << 20)}), ("read_block_32m", {"SK_READ_BLOCK": str(32 << 20)}),
+                              ("read_block_512k", {"SK_SD_INPUT": "pread", "SK_READ_BLOCK": str(512 << 10)}), ("read_block_1m", {"SK_SD_INPUT": "pread", "SK_READ_BLOCK": str(1 << 20)}),
+                              ("read_block_4m", {"SK_SD_INPUT": "pread", "SK_READ_BLOCK": str(4 << 20)}), ("read_block_32m", {"SK_SD_INPUT": "pread", "SK_READ_BLOCK": str(32 << 20)}),
                               ("two_logical_devices_one_card", {"SK_DEVICES": "0,0", "SK_SD_GROUP": "16"})):
                 if os.environ.get("VARIANTS") not in ("1", "all") and name not in os.environ["VARIANTS"].split(","):
                     continue
