@@ -139,6 +139,18 @@ int sk_pinned_free(sk_ctx *ctx, void *p);
 int sk_scan_pinned(sk_ctx *ctx, const uint8_t *pinned, uint64_t nbytes, uint32_t col, uint64_t *ticket);
 int sk_ticket_wait(sk_ctx *ctx, uint64_t ticket);
 
+/* The host-side 2-bit pre-pack of a record stream (new; the reference moves bytes through memory only,
+ * src/kseq.h:90-141).  sk_pack_stream makes, for every 16-byte chunk of `stream`, what the scan kernel's own first phase would
+ * make of it -- a 32-bit word of sixteen 2-bit codes (A 0, C 1, G 2, T 3 in either case, first byte highest; 0 for any other byte)
+ * and a 16-bit mask of the bytes that are no A/C/G/T -- into `packed` (sk_packed_bytes(nbytes) bytes: the code words, then the
+ * masks): 6 bytes per 16 bases cross the PCIe link instead of 16.  *odd is set when the stream holds a byte that is neither
+ * A/C/G/T, N/n nor '\n' (an IUPAC letter, U, '\r': only the exact byte-string kernel can judge its windows, a6 of SURVEY 8):
+ * such a batch must go to sk_scan_pinned as bytes.  sk_scan_pinned_packed is sk_scan_pinned for a packed batch (`packed` in
+ * memory from sk_pinned_alloc; nbytes = the length of the byte stream it was packed from); counts are the same, bit for bit. */
+uint64_t sk_packed_bytes(uint64_t nbytes);
+int sk_pack_stream(const uint8_t *stream, uint64_t nbytes, void *packed, int *odd);
+int sk_scan_pinned_packed(sk_ctx *ctx, const void *packed, uint64_t nbytes, uint32_t col, uint64_t *ticket);
+
 /* Same, for a batch already resident in HBM (device pointer). */
 int sk_scan_device(sk_ctx *ctx, const void *dev_stream, uint64_t nbytes, uint32_t col);
 

@@ -6,6 +6,7 @@ program.  This Python package is only a thin ctypes binding over that C-ABI, use
 tests and by ``bench.py``.  There is no Python or CPU compute path: if the shared library is
 missing, importing :mod:`strainer2_amd.native` raises.
 """
+from .native import pack_stream  # noqa: F401
 from .native import (  # noqa: F401
     SKError,
     KmerContext,

@@ -563,7 +563,7 @@ __device__ __forceinline__ sk_u4 sk_load_chunk(const uint8_t *__restrict__ strea
 // around them) are read and looked at.
 // Scalar registers decide how many workgroups a CU admits: <= 80 -> 8 of these 256-thread groups, 81..96 -> 7, 97..112 -> 6
 // (MI355X_MICROARCH.md, "Residency").  The COUNT kernel is held at 80, the TALLY kernels at 96 (round 3: 100 and 94 = 6 and 7 groups).
-template <bool TALLY, int ABLATE, bool CAND, bool UNION = false>
+template <bool TALLY, int ABLATE, bool CAND, bool UNION = false, bool PACKED = false>
 #if defined(SK_NO_SGPR_CAP)                                       // (A/B builds: round 3's register budget -- TALLY 100 scalar registers = 6 groups per CU, UNION 94 = 7)
 __global__ __launch_bounds__(SK_THREADS)
 #else
@@ -634,10 +634,37 @@ void sk_scan_grid(const uint8_t *__restrict__ stream, uint64_t nbytes, uint64_t 
         __builtin_amdgcn_s_setprio(SK_PRIO_BASE);
 #endif
     };
-    if (!CAND) issue_loads(tile0);
+    if (!CAND && !PACKED) issue_loads(tile0);
 
     // ================= phase 1: bytes -> packed codes + invalid masks ==========================
     uint32_t candm = 0xFFu;                                        // this thread's chunks that are candidates (CAND)
+    if (PACKED) {
+        // The batch came PACKED by the host (sk_pack_stream: what sk_decode16 makes of a 16-byte chunk, made there -- 6 bytes a chunk
+        // over the PCIe link instead of 16): `stream` holds the chunks' code words, `cand` their masks of bytes that are no A/C/G/T.
+        // A packed batch holds no byte the byte-string kernel would have to judge (the host sends such a batch as bytes).  Chunks
+        // outside the batch read as separators, as in the byte form.
+        const uint32_t *__restrict__ codes = (const uint32_t *)stream;
+        const uint16_t *__restrict__ invs = (const uint16_t *)cand;
+        const int64_t g0 = (int64_t)(tile0 >> 4) - (int64_t)SK_SPAN_CH;
+        const int64_t nch = (int64_t)((nbytes + 15u) >> 4);
+        uint32_t pc[NIT], pi[NIT];
+    #pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+            const int64_t g = g0 + (int64_t)c;
+            pc[it] = 0u; pi[it] = 0xFFFFu;
+            if (c < SK_NCHUNK_GRID && g >= 0 && g < nch) { pc[it] = __builtin_nontemporal_load(codes + g); pi[it] = __builtin_nontemporal_load(invs + g); }
+        }
+    #pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t c = tid + (uint32_t)it * SK_THREADS;
+            if (c < SK_NCHUNK_GRID) {
+                const uint32_t r = c >> 3, sl = c & 7u;
+                rec[r * SK_REC_DW + sl] = pc[it];
+                ((uint16_t *)rec)[r * (2 * SK_REC_DW) + 16 + sl] = (uint16_t)pi[it];
+            }
+        }
+    } else
     if (!CAND) {
         SK_PHASE(0);                                                 // start -> the tile's loads issued
     #pragma unroll

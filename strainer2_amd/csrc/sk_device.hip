@@ -176,6 +176,11 @@ extern "C" int sk_ctx_create(sk_ctx **out, int device)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SK_E_NODEVICE;
     if (device < 0 || device >= ndev) return SK_E_ARG;
     if (hipSetDevice(device) != hipSuccess) return SK_E_NODEVICE;
+    {   // (experiment) SK_SYNC=blocking: waits for the device sleep instead of spinning -- the hosts here are short of CPUs, not of latency
+        const char *e = getenv("SK_SYNC");
+        if (e && !strcmp(e, "blocking")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        else if (e && !strcmp(e, "yield")) (void)hipSetDeviceFlags(hipDeviceScheduleYield);
+    }
     sk_ctx *c = new (std::nothrow) sk_ctx();
     if (!c) return SK_E_NOMEM;
     c->device = device;
@@ -621,8 +626,9 @@ static int sk_diff_flush(sk_ctx *c)
 static int sk_scratch(sk_ctx *c, void **p, size_t *cap, size_t need);
 
 // launch main + wide kernels over one device-resident batch
+// packed_inv: the batch is in the host-packed form (sk_pack_stream) -- d_stream points at its code words, packed_inv at its masks
 static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, uint64_t emit_begin, uint32_t col,
-                          const sk_sink *tally_sink = NULL)
+                          const sk_sink *tally_sink = NULL, const void *packed_inv = NULL)
 {
     if (nbytes <= emit_begin || c->nrows == 0) return SK_OK;        // (an empty key set: nothing can be counted)
     const uint64_t ntiles = (nbytes + SK_TILE - 1) / SK_TILE;
@@ -690,7 +696,7 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     // 2 % strain reads; profiles/r02_lds_pipeline.txt) -- its one full pass over the stream plus the
     // bin write already costs half of the single kernel's time, and the re-read of the candidates' neighbourhoods pays
     // the fabric's random-line rate.  The default is the single kernel for every batch size.
-    const bool piped = (!c->ablate || c->ablate >= 7) && c->pipeline == 2;        // (ablations 7-9 exist for both forms)
+    const bool piped = !packed_inv && (!c->ablate || c->ablate >= 7) && c->pipeline == 2;        // (ablations 7-9 exist for both forms)
     const uint8_t *d_cand = NULL;
     if (piped && !c->d_grid3) {
         // the partitioned pipeline's filter slices, built from the resident table the first time they are wanted:
@@ -723,7 +729,12 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
     }
 #define SK_LAUNCH_GRID(T, A, C) hipLaunchKernelGGL((sk_scan_grid<T, A, C>), grid, block, 0, c->stream, \
                                                    d_stream, nbytes, emit_begin, tv, sink, d_fl, d_cand)
-    if (tally_sink && tally_sink->ns)
+    if (packed_inv) {
+        if (tally_sink || c->ablate) return sk_fail(c, SK_E_UNSUPPORTED, "packed batches are scanned in COUNT mode only");
+        hipLaunchKernelGGL((sk_scan_grid<false, 0, false, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl,
+                           (const uint8_t *)packed_inv);
+    }
+    else if (tally_sink && tally_sink->ns)
         hipLaunchKernelGGL((sk_scan_grid<true, 0, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl, d_cand);
     else if (piped && tally_sink) SK_LAUNCH_GRID(true, 0, true);
 #ifdef SK_EXPERIMENTS
@@ -1351,7 +1362,7 @@ extern "C" int sk_scan_pinned(sk_ctx *c, const uint8_t *pinned, uint64_t nbytes,
     if (rc) return rc;
     const uint64_t t = c->tickets++;
     hipEvent_t &ev = c->copied[t & 63u];
-    if (!ev) SK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!ev) SK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming | (getenv("SK_SYNC") ? hipEventBlockingSync : 0u)));
     else SK_HIP(c, hipEventSynchronize(ev));                     // ring slot of ticket t-64
     const int b = c->stage_next;
     c->stage_next = (b + 1) % SK_NSTAGE;
@@ -1364,6 +1375,38 @@ extern "C" int sk_scan_pinned(sk_ctx *c, const uint8_t *pinned, uint64_t nbytes,
     SK_HIP(c, hipEventRecord(ev, c->copy_stream));
     SK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));                          // (before anything else: sk_sync / sk_pinned_free wait on c->stream alone)
     rc = sk_launch_scan(c, c->d_stage[b], nbytes, 0, col);
+    if (rc) return rc;
+    SK_HIP(c, hipEventRecord(c->stage_done[b], c->stream));
+    *ticket = t;
+    return SK_OK;
+}
+
+// The same for a batch the host has PACKED (sk_pack_stream, sk_host.c: per 16-byte chunk of the byte stream the 32-bit code word and
+// the 16-bit mask the scan kernel's own decode would make of it -- `packed` holds the (nbytes + 15) / 16 code words, then the masks):
+// 6 bytes per 16 bases cross the PCIe link instead of 16, and the kernel's phase 1 only copies them into place.  nbytes is the
+// length of the BYTE stream the batch was packed from (offsets, record ends and the batch's end mean what they mean there).  A batch
+// with a byte that only the byte-string kernel can judge (sk_pack_stream says so) must be sent as bytes.
+extern "C" int sk_scan_pinned_packed(sk_ctx *c, const void *packed, uint64_t nbytes, uint32_t col, uint64_t *ticket)
+{
+    if (!c || (!packed && nbytes) || !ticket) return SK_E_ARG;
+    if (!c->d_keys) return sk_fail(c, SK_E_STATE, "no table loaded");
+    if (col >= c->ncols) return sk_fail(c, SK_E_ARG, "column %u out of range", col);
+    const uint64_t nch = (nbytes + 15u) >> 4;
+    if (nch * 6u > SK_STAGE_BYTES) return sk_fail(c, SK_E_ARG, "packed batch larger than the staging buffer");
+    SK_HIP(c, hipSetDevice(c->device));
+    int rc = sk_stage_init(c);
+    if (rc) return rc;
+    const uint64_t t = c->tickets++;
+    hipEvent_t &ev = c->copied[t & 63u];
+    if (!ev) SK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming | (getenv("SK_SYNC") ? hipEventBlockingSync : 0u)));
+    else SK_HIP(c, hipEventSynchronize(ev));                     // ring slot of ticket t-64
+    const int b = c->stage_next;
+    c->stage_next = (b + 1) % SK_NSTAGE;
+    SK_HIP(c, hipStreamWaitEvent(c->copy_stream, c->stage_done[b], 0));
+    if (nch) SK_HIP(c, hipMemcpyAsync(c->d_stage[b], packed, nch * 6u, hipMemcpyHostToDevice, c->copy_stream));
+    SK_HIP(c, hipEventRecord(ev, c->copy_stream));
+    SK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+    rc = sk_launch_scan(c, c->d_stage[b], nbytes, 0, col, NULL, c->d_stage[b] + nch * 4u);
     if (rc) return rc;
     SK_HIP(c, hipEventRecord(c->stage_done[b], c->stream));
     *ticket = t;

@@ -32,6 +32,7 @@
 #include "sk_common.h"
 
 #include "sk_parser.h"
+#include "sk_pack.h"
 #include "sk_ctxjob.h"
 #include "sk_gzpipe.h"
 #include "sk_cpus.h"
@@ -64,6 +65,22 @@ static int parse_feed_sink(void *user, const unsigned char *data, size_t n)
     parser *ps = (parser *)user;
     parser_feed(ps, data, n);
     return ps->state == P_STOP;
+}
+
+/* ---- the host-side pre-pack (sk_pack.h) behind the C-ABI ---- */
+uint64_t sk_packed_bytes(uint64_t nbytes) { return ((nbytes + 15u) >> 4) * 6u; }
+
+int sk_pack_stream(const uint8_t *stream, uint64_t nbytes, void *packed, int *odd)
+{
+    static skp_pack_fn picked = NULL;
+    skp_pack_fn fn = __atomic_load_n(&picked, __ATOMIC_RELAXED);
+    const uint64_t nch = (nbytes + 15u) >> 4;
+    int o = 0;
+    if ((!stream && nbytes) || (!packed && nbytes) || !odd) return SK_E_ARG;
+    if (!fn) { fn = skp_pack_pick(); __atomic_store_n(&picked, fn, __ATOMIC_RELAXED); }       /* (idempotent: two threads store the same pointer) */
+    fn(stream, nbytes, (uint32_t *)packed, (uint16_t *)((uint8_t *)packed + nch * 4u), &o);
+    *odd = o;
+    return SK_OK;
 }
 
 /* pipe: inflate on a helper thread while this one parses (worth it when there are fewer files than cores);
@@ -803,8 +820,9 @@ typedef struct {
     list_line      *ll;                /* ... the list's lines ...                                  */
     uint32_t        nll, ll_next;      /* ... and the first one not yet written there               */
     int             timing;            /* SK_TIMING: where the decode threads' time goes (seconds summed over threads, under queue_mu) */
-    double          t_item, t_submit_wait, t_submit, t_ticket, t_cpu;
-    uint64_t        nchunks;
+    double          t_item, t_submit_wait, t_submit, t_ticket, t_cpu, t_pack;
+    uint64_t        nchunks, npacked;
+    int             pack;              /* chunks go up packed (6 bytes per 16 bases; SK_LIST_PACK=0: as bytes) */
 } scan_pool;
 
 /* The progress file gets a list line when a decode thread TAKES the line's (first) item, and every line before it that is
@@ -829,8 +847,11 @@ typedef struct {
     sk_inflater *inf;                  /* SK_GPU_INFLATE=1: this worker's device-side gzip decoder ... */
     int          dev_ok;               /* ... which only the pool's first dev_workers threads use (the others inflate on the host) */
     uint8_t   *text; uint64_t text_cap;/* ... and the page-locked buffer its text lands in */
-    double     t_submit_wait, t_submit, t_ticket;      /* SK_TIMING */
-    uint64_t   nchunks;
+    double     t_submit_wait, t_submit, t_ticket, t_pack;      /* SK_TIMING */
+    uint64_t   nchunks, npacked;
+    uint8_t   *pk[2];                  /* the chunks' packed form (sk_pack_stream), two page-locked buffers taking turns ... */
+    uint64_t   pk_ticket[2];           /* ... each rewritten only after the upload that read it */
+    int        pk_used[2], pk_cur;
 } scan_worker;
 
 /* size of a worker's chunk buffer: SK_CHUNK_BYTES (4096 .. 63 MiB; tests use small ones: many flushes per file), default 32 MiB */
@@ -846,8 +867,32 @@ static int worker_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
 {
     scan_worker *w = (scan_worker *)user;
     int rc;
-    const double t0 = w->pool->timing ? now_s() : 0.0;
+    double t0 = w->pool->timing ? now_s() : 0.0;
     double t1;
+    if (w->pool->pack) {
+        /* The chunk goes up PACKED: what the scan kernel's first phase would make of its bytes is made here (sk_pack.h), 6 bytes per
+         * 16 bases over the link instead of 16 -- the list scan of plain text was bound by the link, not by these threads.  A chunk
+         * with a byte for the byte-string kernel (IUPAC, U, CR ...) goes up as bytes, below. */
+        const int i = w->pk_cur ^= 1;
+        if (!w->pk[i] && sk_pinned_alloc(w->pool->ctx, (void **)&w->pk[i], sk_packed_bytes(POOL_CHUNK)) != SK_OK) w->pk[i] = NULL;
+        if (w->pk[i]) {
+            int odd = 0;
+            if (w->pk_used[i]) { sk_ticket_wait(w->pool->ctx, w->pk_ticket[i]); w->pk_used[i] = 0; }
+            if (w->pool->timing) { t1 = now_s(); w->t_ticket += t1 - t0; t0 = t1; }
+            sk_pack_stream(chunk, nbytes, w->pk[i], &odd);
+            if (w->pool->timing) { t1 = now_s(); w->t_pack += t1 - t0; t0 = t1; }
+            if (!odd) {
+                pthread_mutex_lock(&w->pool->submit_mu);
+                t1 = w->pool->timing ? now_s() : 0.0;
+                rc = sk_scan_pinned_packed(w->pool->ctx, w->pk[i], nbytes, w->pool->col, &w->pk_ticket[i]);
+                pthread_mutex_unlock(&w->pool->submit_mu);
+                if (w->pool->timing) { w->t_submit_wait += t1 - t0; w->t_submit += now_s() - t1; w->nchunks++; w->npacked++; }
+                w->pk_used[i] = rc == SK_OK;
+                w->used[w->cur] = 0;                    /* (the bytes were read by this thread alone: their buffer is free at once) */
+                return rc;
+            }
+        }
+    }
     pthread_mutex_lock(&w->pool->submit_mu);
     t1 = w->pool->timing ? now_s() : 0.0;
     rc = sk_scan_pinned(w->pool->ctx, chunk, nbytes, w->pool->col, &w->ticket[w->cur]);
@@ -893,6 +938,8 @@ static void worker_done(scan_worker *w)
     pthread_mutex_lock(&w->pool->submit_mu);
     if (w->pinned[0]) sk_pinned_free(w->pool->ctx, w->pinned[0]);      /* (synchronises the stream first) */
     if (w->pinned[1]) sk_pinned_free(w->pool->ctx, w->pinned[1]);
+    if (w->pk[0]) sk_pinned_free(w->pool->ctx, w->pk[0]);
+    if (w->pk[1]) sk_pinned_free(w->pool->ctx, w->pk[1]);
     pthread_mutex_unlock(&w->pool->submit_mu);
 }
 
@@ -1234,6 +1281,7 @@ static void *pool_worker(void *arg)
         struct timespec ts;
         pthread_mutex_lock(&p->queue_mu);
         p->t_submit_wait += w.t_submit_wait; p->t_submit += w.t_submit; p->t_ticket += w.t_ticket; p->nchunks += w.nchunks;
+        p->t_pack += w.t_pack; p->npacked += w.npacked;
         if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0) p->t_cpu += (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
         pthread_mutex_unlock(&p->queue_mu);
     }
@@ -1347,6 +1395,7 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
     if (no_split == 2) local_fail |= LIST_FAIL_GUARD;       /* (second scan after a failed cut: this rank could not put its column back) */
     memset(&pool, 0, sizeof pool);
     pool.timing = getenv("SK_TIMING") != NULL;
+    { const char *e = getenv("SK_LIST_PACK"); pool.pack = !(e && e[0] == '0'); }
     pool.ctx = ctx;
     pool.col = col;
     pthread_mutex_init(&pool.submit_mu, NULL);
@@ -1528,9 +1577,10 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
         free(th);
         if (pool.timing && err)
             fprintf(err, "kmer_scrub_count timing: %s: %d decode threads, %u items, %llu chunks; summed over the threads: in items %.2f s, "
-                         "of it on a core %.2f s, waiting for the submit lock %.2f s, inside the submit %.2f s, waiting for a buffer's copy %.2f s\n",
+                         "of it on a core %.2f s, waiting for the submit lock %.2f s, inside the submit %.2f s, waiting for a buffer's copy %.2f s, "
+                         "packing %.2f s (%llu chunks went up packed)\n",
                     list_path, nthreads, pool.nitem, (unsigned long long)pool.nchunks, pool.t_item, pool.t_cpu, pool.t_submit_wait,
-                    pool.t_submit, pool.t_ticket);
+                    pool.t_submit, pool.t_ticket, pool.t_pack, (unsigned long long)pool.npacked);
     }
     if (!plan_only && ctx) {
         /* The agreement after the scan: what went wrong, anywhere.  The first list line whose file could not be opened (the

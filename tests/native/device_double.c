@@ -263,6 +263,27 @@ int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t n) { (void)c; *p = malloc(n); 
 int sk_pinned_free(sk_ctx *c, void *p) { (void)c; free(p); return SK_OK; }
 int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64_t *t) { if (t) *t = 1; return sk_scan_stream(c, s, n, col); }
 int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return SK_OK; }
+/* a packed batch (sk_pack_stream): its bytes made again -- a base for a code, a separator for every byte that was none (which of N,
+ * n or '\n' it was makes no difference to a window count: either ends the windows that hold it) -- and scanned as bytes */
+int sk_scan_pinned_packed(sk_ctx *c, const void *packed, uint64_t n, uint32_t col, uint64_t *t)
+{
+    const uint64_t nch = (n + 15u) >> 4;
+    const uint32_t *codes = (const uint32_t *)packed;
+    const uint16_t *inv = (const uint16_t *)((const uint8_t *)packed + nch * 4u);
+    uint8_t *b = (uint8_t *)malloc(n ? n : 1);
+    uint64_t i;
+    int rc;
+    if (!b) return SK_E_NOMEM;
+    for (i = 0; i < n; i++) {
+        const uint64_t g = i >> 4;
+        const unsigned k = (unsigned)(i & 15u);
+        b[i] = (inv[g] >> k) & 1u ? (uint8_t)'\n' : (uint8_t)"ACGT"[(codes[g] >> (30u - 2u * k)) & 3u];
+    }
+    if (t) *t = 1;
+    rc = sk_scan_stream(c, b, n, col);
+    free(b);
+    return rc;
+}
 int sk_sync(sk_ctx *c) { (void)c; return SK_OK; }
 /* ---- a communicator for the multi-PROCESS CPU tests (tests/test_multirank_protocol.py).  DOUBLE_COMM_DIR names a fresh
  * directory all ranks see.  Collective number k of rank r is the file c<k>.r<r> = {kind, element count, payload}; a rank

@@ -37,6 +37,7 @@ int sk_pinned_alloc(sk_ctx *c, void **p, uint64_t n) { (void)c; (void)p; (void)n
 int sk_pinned_free(sk_ctx *c, void *p) { (void)c; (void)p; return unreachable("sk_pinned_free"); }
 int sk_scan_pinned(sk_ctx *c, const uint8_t *s, uint64_t n, uint32_t col, uint64_t *t) { (void)c; (void)s; (void)n; (void)col; (void)t; return unreachable("sk_scan_pinned"); }
 int sk_ticket_wait(sk_ctx *c, uint64_t t) { (void)c; (void)t; return unreachable("sk_ticket_wait"); }
+int sk_scan_pinned_packed(sk_ctx *c, const void *s, uint64_t n, uint32_t col, uint64_t *t) { (void)c; (void)s; (void)n; (void)col; (void)t; return unreachable("sk_scan_pinned_packed"); }
 int skh_scrub_filter_resident(sk_ctx *c, const skh_keyset *k, int d, double m, int i, FILE *o, FILE *e) { (void)c; (void)k; (void)d; (void)m; (void)i; (void)o; (void)e; return unreachable("skh_scrub_filter_resident"); }
 const char *sk_strerror(int c) { (void)c; return "stub"; }
 const char *sk_last_error(const sk_ctx *c) { (void)c; return "stub"; }

@@ -454,6 +454,55 @@ def test_scan_pinned_equals_scan_stream(ctx):
     ctx.pinned_free(buf)
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_packed_batches_count_what_the_byte_batches_count(ctx, seed):
+    """the host-side 2-bit pre-pack (sk_pack_stream -> sk_scan_pinned_packed): chunks of whole records, packed on the host -- 6 bytes
+    per 16 bases -- must give, count for count, what the same chunks give as bytes and what the oracle counts: strain reads on both
+    strands with substitutions, N and n, lower case, reads around k and around the 16-byte grid, ragged chunk ends, a chunk of one
+    byte.  A chunk with a byte for the byte-string kernel says so (`odd`) and goes up as bytes."""
+    rng = random.Random(seed)
+    strain = _synth.rand_dna(rng, rng.choice([20000, 60000]))
+    ks = sk.Keyset.from_stream(strain + b"\n")
+    ctx.load_keyset(ks, 4)
+    data = _synth.fuzz_stream(rng, strain, 4000, junk=b"NnNnacgt", p_junk=0.004, min_len=rng.choice([1, 31]), max_len=rng.choice([64, 200, 700]))
+    ctx.scan_stream(data, 1)
+    recs = data.split(b"\n")[:-1]
+    cap = rng.choice([1 << 12, 1 << 16, 1 << 20])
+    raw = ctx.pinned_alloc(cap)
+    pk = [ctx.pinned_alloc(6 * ((cap + 15) // 16)) for _ in range(2)]
+    tickets = [None, None]
+    i = k = 0
+    npacked = 0
+    while i < len(recs):
+        n, j = 0, i
+        while j < len(recs) and n + len(recs[j]) + 1 <= raw.size:
+            n += len(recs[j]) + 1
+            j += 1
+        assert j > i
+        raw[:n] = np.frombuffer(b"\n".join(recs[i:j]) + b"\n", dtype=np.uint8)
+        if tickets[k] is not None:
+            ctx.ticket_wait(tickets[k])
+        _, odd = sk.pack_stream(raw[:n], out=pk[k])
+        assert not odd
+        tickets[k] = ctx.scan_pinned_packed(pk[k], n, 2)
+        npacked += 1
+        k ^= 1
+        i = j
+    ctx.sync()
+    assert npacked >= 1
+    assert np.array_equal(ctx.counts(1), ctx.counts(2)) and int(ctx.counts(1).sum()) > 5000
+    t = _oracle.OracleTable(ncols=4)
+    assert t.build_stream(strain + b"\n") == 0
+    t.scan_stream(data, 1)
+    okeys, ocounts = t.rows()
+    assert okeys == ks.keys() and np.array_equal(ocounts[:, 1], ctx.counts(2))
+    t.close()
+    assert sk.pack_stream(b"ACGTRACGT\n")[1] and sk.pack_stream(b"ACGU\n")[1] and sk.pack_stream(b"ACGT\r\n")[1] and not sk.pack_stream(b"ACGTNn\n")[1]
+    ctx.pinned_free(raw)
+    for a in pk:
+        ctx.pinned_free(a)
+
+
 def test_rccl_allreduce_on_the_counter_block_single_rank(repo):
     """torch.distributed (backend nccl = RCCL) all-reduce running directly on the library's device counters,
     as bench.py --gpus N does: world of one, counts unchanged (tools/nccl_single_rank_check.py)"""

@@ -95,6 +95,49 @@ def test_keyset_order_after_two_expansions_is_the_references(golden, tmp_path):
     ks.close()
 
 
+@pytest.mark.parametrize("simd", ["1", "0"])
+def test_host_pre_pack_is_the_scan_kernels_decode(simd, monkeypatch):
+    """sk_pack_stream (the host-side 2-bit pre-pack, sk_pack.h) against the definition it shares with the scan kernel's first phase
+    (sk_decode16): per 16-byte chunk a code word -- A 0, C 1, G 2, T 3 in either case, first byte highest, 0 for any other byte --
+    and a mask of the bytes that are no A/C/G/T; `odd` iff some byte is neither A/C/G/T, N/n nor a newline.  Every byte value, ragged
+    ends, the vector path and the table path."""
+    monkeypatch.setenv("SK_PACK_SIMD", simd)
+    import subprocess
+    import sys
+    code = r"""
+import sys, random
+import numpy as np
+sys.path.insert(0, %r)
+import strainer2_amd as sk
+rng = random.Random(5)
+lut = {ord(c): i for i, c in enumerate("ACGT")}
+lut.update({ord(c): i for i, c in enumerate("acgt")})
+fine = set(b"ACGTacgtNn\n")
+for rep in range(300):
+    n = rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 1000, 4099])
+    kind = rep %% 3
+    b = bytes(rng.randrange(256) if kind == 0 else rng.choice(b"ACGTacgtNn\n") if kind == 1 else (rng.choice(b"ACGT") if rng.random() < 0.97 else rng.randrange(256)) for _ in range(n))
+    packed, odd = sk.pack_stream(b)
+    nch = (n + 15) // 16
+    assert len(packed) == 6 * nch
+    codes = np.frombuffer(packed[:4 * nch].tobytes(), dtype="<u4")
+    inv = np.frombuffer(packed[4 * nch:].tobytes(), dtype="<u2")
+    for g in range(nch):
+        c = m = 0
+        for i in range(16):
+            at = 16 * g + i
+            v = lut.get(b[at]) if at < n else None
+            c = (c << 2) | (v or 0)
+            if v is None:
+                m |= 1 << i
+        assert (int(codes[g]), int(inv[g])) == (c, m), (rep, g)
+    assert odd == any(x not in fine for x in b), rep
+print("ok")
+""" % REPO
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SK_PACK_SIMD=simd))
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-800:]
+
+
 def test_keyset_short_record_policy(golden):
     d = os.path.join(golden, "cases", "short_contig")
     ks = sk.Keyset.from_file(os.path.join(d, "strain.fa"))
