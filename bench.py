@@ -572,7 +572,7 @@ def main():
 
     # PCIe-inclusive rate (host buffer -> pinned staging -> H2D -> scan), reported beside `value`,
     # never as it: 2 passes of sk_scan_stream over the same record stream
-    host_rate = pinned_rate = None
+    host_rate = pinned_rate = packed_resident = None
     if world == 1 and not args.ablate and not args.no_host_rate:
         ctx.scan_stream(reads[: 64 << 20], 3)
         ctx.sync()
@@ -594,6 +594,27 @@ def main():
         ctx.sync()
         pinned_rate = 2 * nbases / (time.perf_counter() - t1)
         ctx.pinned_free(pin)
+        # the same stream in the host-PACKED form (sk_pack_stream: 6 bytes per 16 bases; what the list scans upload): resident on the
+        # device, the kernel's first phase only copies -- another input form than `value`'s, reported beside it, counts checked
+        if args.hit_frac == 0.02:
+            pk, odd = sk.pack_stream(reads)
+            if not odd:
+                dpk = ctx.dev_alloc(pk.size)
+                ctx.dev_upload(dpk, pk)
+                ctx.zero_counts(3)
+                ctx.scan_device_packed(dpk, nbytes, 3)
+                ctx.sync()
+                assert np.array_equal(ctx.counts(3) * args.steps, counts), "the packed form counts something else"
+                ctx.scan_timing(reset=True)
+                for _ in range(50):
+                    ctx.scan_device_packed(dpk, nbytes, 3)
+                ctx.sync()
+                pms, pn = ctx.scan_timing(reset=True)
+                packed_resident = {"kernel": "sk_scan_grid<PACKED>", "avg_launch_ms": pms / max(pn, 1), "launches": int(pn),
+                                   "bases_per_s": nbases / (pms / max(pn, 1) * 1e-3), "input_bytes_per_launch": int(pk.size),
+                                   "what": "the same reads resident in the host-packed form (a code word and a mask per 16-byte chunk, 6 bytes instead of 16): "
+                                           "the kernel's phase 1 copies instead of decoding; counts == the byte form's, checked.  NOT the input `value` is quoted on"}
+                ctx.dev_free(dpk)
 
     # File-fed, rank-sharded side measurement (never `value`): every rank writes 2 FASTQ files of its own reads under
     # /dev/shm (or TMPDIR), ONE list names them all plus one file four times the size, and every rank scans its share of
@@ -720,6 +741,7 @@ def main():
                        "bases_per_step_per_gpu": nbases, "hits_per_pass_rank0_or_sum": hits_per_pass,
                        "pcie_inclusive_bases_per_s_host_buffers": host_rate,
                        "pcie_inclusive_bases_per_s_pinned_buffers": pinned_rate,
+                       "packed_input_resident": packed_resident,
                        "file_fed_rank_sharded": file_fed,
                        "sharding": "reads sharded by rank, table replicated, one RCCL all-reduce of counts" if world > 1 else "single GPU"},
             "parity": parity,

@@ -150,6 +150,7 @@ int sk_ticket_wait(sk_ctx *ctx, uint64_t ticket);
 uint64_t sk_packed_bytes(uint64_t nbytes);
 int sk_pack_stream(const uint8_t *stream, uint64_t nbytes, void *packed, int *odd);
 int sk_scan_pinned_packed(sk_ctx *ctx, const void *packed, uint64_t nbytes, uint32_t col, uint64_t *ticket);
+int sk_scan_device_packed(sk_ctx *ctx, const void *dev_packed, uint64_t nbytes, uint32_t col);   /* the packed batch already in device memory (4-byte aligned) */
 
 /* Same, for a batch already resident in HBM (device pointer). */
 int sk_scan_device(sk_ctx *ctx, const void *dev_stream, uint64_t nbytes, uint32_t col);

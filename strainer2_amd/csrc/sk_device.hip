@@ -1265,6 +1265,19 @@ extern "C" int sk_scan_device(sk_ctx *c, const void *dev_stream, uint64_t nbytes
     return sk_launch_scan(c, (const uint8_t *)dev_stream, nbytes, 0, col);
 }
 
+// sk_scan_device for a batch that lies in device memory in the PACKED form (sk_pack_stream's layout: the code words, then the masks;
+// 4-byte aligned): how fast the kernel is when its first phase only copies -- a side measurement of bench.py, not the headline's input.
+extern "C" int sk_scan_device_packed(sk_ctx *c, const void *dev_packed, uint64_t nbytes, uint32_t col)
+{
+    if (!c || (!dev_packed && nbytes)) return SK_E_ARG;
+    if (!c->d_keys) return sk_fail(c, SK_E_STATE, "no table loaded");
+    if (col >= c->ncols) return sk_fail(c, SK_E_ARG, "column %u out of range", col);
+    if (((uintptr_t)dev_packed & 3u) != 0) return sk_fail(c, SK_E_ARG, "device batch must be 4-byte aligned");
+    SK_HIP(c, hipSetDevice(c->device));
+    const uint64_t nch = (nbytes + 15u) >> 4;
+    return sk_launch_scan(c, (const uint8_t *)dev_packed, nbytes, 0, col, NULL, (const uint8_t *)dev_packed + nch * 4u);
+}
+
 static int sk_stage_init(sk_ctx *c)
 {
     if (c->h_stage[0]) return SK_OK;

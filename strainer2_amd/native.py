@@ -42,7 +42,7 @@ SK_E_PLAN = -10
 # every symbol include/strainer_kmer.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "sk_ctx_create", "sk_ctx_destroy", "sk_last_error", "sk_strerror", "sk_table_load", "sk_table_load_ex",
-    "sk_table_load_wide", "sk_table_load_text", "sk_table_build_from_text", "sk_table_export_keys", "sk_table_export_keys_of", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned", "sk_scan_pinned_packed", "sk_pack_stream", "sk_packed_bytes",
+    "sk_table_load_wide", "sk_table_load_text", "sk_table_build_from_text", "sk_table_export_keys", "sk_table_export_keys_of", "sk_scan_stream", "sk_scan_device", "sk_pinned_alloc", "sk_pinned_free", "sk_scan_pinned", "sk_scan_pinned_packed", "sk_scan_device_packed", "sk_pack_stream", "sk_packed_bytes",
     "sk_ticket_wait", "sk_tally_batch", "sk_sync", "sk_counts_fetch",
     "sk_counts_set", "sk_counts_set_rows", "sk_counts_zero", "sk_counts_device_ptr", "sk_table_rows", "sk_table_cols",
     "sk_counts_allreduce", "sk_comm_init", "sk_comm_init_ex", "sk_rendezvous_exchange", "sk_comm_destroy", "sk_comm_sum_u32", "sk_comm_agree_u64", "sk_comm_max_u64", "sk_comm_world", "sk_scan_timing", "sk_set_option", "sk_dev_alloc", "sk_dev_free",
@@ -88,6 +88,7 @@ lib.sk_pinned_free.argtypes = [C.c_void_p, C.c_void_p]
 lib.sk_scan_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
 lib.sk_ticket_wait.argtypes = [C.c_void_p, C.c_uint64]
 lib.sk_scan_pinned_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.sk_scan_device_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.sk_pack_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_int)]
 lib.sk_packed_bytes.argtypes = [C.c_uint64]
 lib.sk_packed_bytes.restype = C.c_uint64
@@ -303,6 +304,9 @@ class KmerContext:
         t = C.c_uint64(0)
         self._ck(lib.sk_scan_pinned(self._h, arr.ctypes.data + offset, nbytes, col, C.byref(t)))
         return t.value
+
+    def scan_device_packed(self, dev_ptr, nbytes, col):
+        self._ck(lib.sk_scan_device_packed(self._h, dev_ptr, nbytes, col))
 
     def scan_pinned_packed(self, packed_arr, nbytes, col):
         """a batch packed by pack_stream() into page-locked memory (pinned_alloc): returns the ticket"""

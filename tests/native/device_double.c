@@ -403,3 +403,4 @@ int sk_inflater_create(int device, struct sk_inflater **out) { (void)device; *ou
 void sk_inflater_destroy(struct sk_inflater *f) { (void)f; }
 uint64_t sk_inflate_gz_size(const uint8_t *gz, uint64_t n) { (void)gz; (void)n; return 0; }
 int sk_inflate_gz(struct sk_inflater *f, const uint8_t *gz, uint64_t n, uint8_t *t, uint64_t cap, uint64_t *len, uint32_t *crc) { (void)f; (void)gz; (void)n; (void)t; (void)cap; (void)len; (void)crc; return -100; }
+int sk_scan_device_packed(sk_ctx *c, const void *p, uint64_t n, uint32_t col) { uint64_t t; return sk_scan_pinned_packed(c, p, n, col, &t); }
