@@ -85,6 +85,10 @@ int sk_pack_stream(const uint8_t *stream, uint64_t nbytes, void *packed, int *od
 
 /* pipe: inflate on a helper thread while this one parses (worth it when there are fewer files than cores);
  * pipe > 1: the helper inflates each gzip member with that many threads (sk_gzpar.h) */
+/* this thread is parsing PLAIN text (set by parse_file / parse_range, read by the list scan's sink): only then are its chunks packed
+ * before they go up -- a .gz item is bound by its inflate on these same CPUs, the link idles, and packing would cost it 7 % */
+static __thread int tl_plain_text;
+
 static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords, int *sink_rc, int pipe)
 {
     enum { BLK = 1 << 20 };
@@ -93,6 +97,7 @@ static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords
     parser ps;
     int got, zrc;
     parser_init(&ps, fn, user);
+    tl_plain_text = 0;
     /* gzip files go through the library's own inflate (sk_gzfast.h, about twice zlib's rate); anything else
      * -- plain text, which gzread passes through, or SK_ZLIB=1 -- through zlib */
     if (getenv("SK_ZLIB")) zrc = SKZ_NOT_GZIP;
@@ -117,6 +122,7 @@ static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords
          * through gzread below, which hands the same bytes on */
         const int fd = open(path, O_RDONLY);
         struct stat sb;
+        tl_plain_text = 1;
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
             const char *e = getenv("SK_READ_BLOCK");                /* (64 bytes -- tests -- .. 32 MiB; default 4 MiB) */
             const long long ev = e ? atoll(e) : 0;
@@ -822,7 +828,7 @@ typedef struct {
     int             timing;            /* SK_TIMING: where the decode threads' time goes (seconds summed over threads, under queue_mu) */
     double          t_item, t_submit_wait, t_submit, t_ticket, t_cpu, t_pack;
     uint64_t        nchunks, npacked;
-    int             pack;              /* chunks go up packed (6 bytes per 16 bases; SK_LIST_PACK=0: as bytes) */
+    int             pack;              /* chunks of plain-text items go up packed (6 bytes per 16 bases; SK_LIST_PACK=0: never, 2: .gz items' too) */
 } scan_pool;
 
 /* The progress file gets a list line when a decode thread TAKES the line's (first) item, and every line before it that is
@@ -869,7 +875,7 @@ static int worker_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
     int rc;
     double t0 = w->pool->timing ? now_s() : 0.0;
     double t1;
-    if (w->pool->pack) {
+    if (w->pool->pack > 1 || (w->pool->pack && tl_plain_text)) {
         /* The chunk goes up PACKED: what the scan kernel's first phase would make of its bytes is made here (sk_pack.h), 6 bytes per
          * 16 bases over the link instead of 16 -- the list scan of plain text was bound by the link, not by these threads.  A chunk
          * with a byte for the byte-string kernel (IUPAC, U, CR ...) goes up as bytes, below. */
@@ -967,6 +973,7 @@ static int parse_range(const scan_item *it, rec_fn fn, void *user, int64_t *nrec
     sa = parser_guess_start(t, it->size, it->a, 1);
     sb = it->b >= it->size ? it->size : parser_guess_start(t, it->size, it->b, 1);
     parser_init(&ps, fn, user);
+    tl_plain_text = 1;
     {
         unsigned char *rb = (unsigned char *)malloc(BLK);
         for (i = sa; i < sb && ps.state != P_STOP; ) {
@@ -1395,7 +1402,7 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
     if (no_split == 2) local_fail |= LIST_FAIL_GUARD;       /* (second scan after a failed cut: this rank could not put its column back) */
     memset(&pool, 0, sizeof pool);
     pool.timing = getenv("SK_TIMING") != NULL;
-    { const char *e = getenv("SK_LIST_PACK"); pool.pack = !(e && e[0] == '0'); }
+    { const char *e = getenv("SK_LIST_PACK"); pool.pack = e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }      /* (0: never, 2: always -- tests --, default: the chunks of plain-text items) */
     pool.ctx = ctx;
     pool.col = col;
     pthread_mutex_init(&pool.submit_mu, NULL);
