@@ -176,6 +176,7 @@ int  sk_batch_create(sk_ctx *ctx, sk_batch **out);          /* on ctx's device; 
 void sk_batch_destroy(sk_batch *b);
 int  sk_batch_sync(sk_batch *b);                               /* its uploads are done: the host memory it was filled from may be reused, the batch kept for the next file */
 int  sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec);
+int  sk_batch_fill_packed(sk_batch *b, const void *packed, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec);   /* the batch in sk_pack_stream's form (nbytes, rec_start: of the byte stream it was packed from) */
 int  sk_tally_launch(sk_ctx *ctx, const sk_batch *b, uint32_t type_col, uint32_t informative_value, uint64_t hits_cap);
 int  sk_tally_collect(sk_ctx *ctx, uint32_t *out_tally /* 2*nrec */, sk_hit *out_hits /* hits_cap */, uint64_t *out_nhits);
 /* The same collection, sparse: only records with at least one hit, compacted on the device, as {record, all hits,

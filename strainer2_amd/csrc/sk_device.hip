@@ -730,9 +730,13 @@ static int sk_launch_scan(sk_ctx *c, const uint8_t *d_stream, uint64_t nbytes, u
 #define SK_LAUNCH_GRID(T, A, C) hipLaunchKernelGGL((sk_scan_grid<T, A, C>), grid, block, 0, c->stream, \
                                                    d_stream, nbytes, emit_begin, tv, sink, d_fl, d_cand)
     if (packed_inv) {
-        if (tally_sink || c->ablate) return sk_fail(c, SK_E_UNSUPPORTED, "packed batches are scanned in COUNT mode only");
-        hipLaunchKernelGGL((sk_scan_grid<false, 0, false, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl,
-                           (const uint8_t *)packed_inv);
+        if (c->ablate) return sk_fail(c, SK_E_UNSUPPORTED, "no ablations on packed batches");
+        if (tally_sink && tally_sink->ns)
+            hipLaunchKernelGGL((sk_scan_grid<true, 0, false, true, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl, (const uint8_t *)packed_inv);
+        else if (tally_sink)
+            hipLaunchKernelGGL((sk_scan_grid<true, 0, false, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl, (const uint8_t *)packed_inv);
+        else
+            hipLaunchKernelGGL((sk_scan_grid<false, 0, false, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl, (const uint8_t *)packed_inv);
     }
     else if (tally_sink && tally_sink->ns)
         hipLaunchKernelGGL((sk_scan_grid<true, 0, false, true>), grid, block, 0, c->stream, d_stream, nbytes, emit_begin, tv, sink, d_fl, d_cand);
@@ -798,6 +802,7 @@ struct sk_batch {
     size_t       stream_cap, rec_cap;
     uint64_t     nbytes;
     uint32_t     nrec, ntiles;
+    bool         packed;                // d_stream holds the host-packed form (sk_pack_stream) of nbytes bytes
     std::vector<uint32_t> tile_first;
 };
 
@@ -837,7 +842,18 @@ extern "C" void sk_batch_destroy(sk_batch *b)
 }
 
 // Upload new contents.  Every tally launched on the previous contents must have been collected.
+static int sk_batch_fill_any(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec, bool packed);
 extern "C" int sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec)
+{
+    return sk_batch_fill_any(b, stream, nbytes, rec_start, nrec, false);
+}
+// the batch in the host-packed form (sk_pack_stream: 6 bytes per 16 of the byte stream; no byte for the byte-string kernel in it);
+// nbytes and rec_start are those of the BYTE stream it was packed from
+extern "C" int sk_batch_fill_packed(sk_batch *b, const void *packed, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec)
+{
+    return sk_batch_fill_any(b, (const uint8_t *)packed, nbytes, rec_start, nrec, true);
+}
+static int sk_batch_fill_any(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec, bool packed)
 {
     if (!b || !stream || !rec_start) return SK_E_ARG;
     sk_ctx *c = b->owner;
@@ -866,7 +882,8 @@ extern "C" int sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes
         while (r < nrec && rec_start[r] < edge) r++;
         b->tile_first[t] = r;
     }
-    SK_HIP(c, hipMemcpyAsync(b->d_stream, stream, nbytes, hipMemcpyHostToDevice, b->stream));
+    SK_HIP(c, hipMemcpyAsync(b->d_stream, stream, packed ? ((nbytes + 15u) >> 4) * 6u : nbytes, hipMemcpyHostToDevice, b->stream));
+    b->packed = packed;
     SK_HIP(c, hipMemcpyAsync(b->d_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, b->stream));
     SK_HIP(c, hipMemcpyAsync((uint32_t *)b->d_rec + nrec, b->tile_first.data(), (size_t)(ntiles + 2) * 4, hipMemcpyHostToDevice, b->stream));
     SK_HIP(c, hipEventRecord(b->ready, b->stream));
@@ -912,7 +929,7 @@ extern "C" int sk_tally_launch(sk_ctx *c, const sk_batch *b, uint32_t type_col, 
         c->infbits_ok = true; c->infbits_col = type_col; c->infbits_val = informative_value;
     }
     sink.infbits = c->d_infbits;
-    rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink);
+    rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink, b->packed ? (const uint8_t *)b->d_stream + ((b->nbytes + 15u) >> 4) * 4u : NULL);
     if (rc) return rc;
     // the records that were hit at all, compacted on the device (sk_tally_collect_sparse); only the two counters come
     // back now, the tallies themselves when they are asked for
@@ -1176,7 +1193,7 @@ extern "C" int sk_union_tally_launch(sk_union *u, const sk_batch *b, uint64_t hi
     sink.hits = (uint2 *)u->d_raw; sink.nhits = d_cnt; sink.hits_cap = hits_cap;
     sink.type = (const uint32_t *)u->d_umask; sink.ns = u->n;
     sink.infbits = (const uint32_t *)u->d_flag;                   // (sk_uflag: the records' touched marks)
-    rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink);
+    rc = sk_launch_scan(c, (const uint8_t *)b->d_stream, b->nbytes, 0, 0, &sink, b->packed ? (const uint8_t *)b->d_stream + ((b->nbytes + 15u) >> 4) * 4u : NULL);
     if (rc) return rc;
     {   // compact the tallies and deal the log out, in one launch
         uint32_t sets = (b->nrec + 256u * 256u - 1u) / (256u * 256u);          // (about 256 compacting workgroups)

@@ -98,6 +98,7 @@ typedef struct {
 typedef struct sd_chunk {
     uint8_t  *buf; uint64_t blen, bcap;      /* record stream: the records of length >= k, '\n' after each */
     int       pinned;                        /* buf belongs to the pool of page-locked buffers */
+    int       packed;                        /* buf holds the stream in sk_pack_stream's form (blen, pstart: of the byte stream it was packed from) */
     uint32_t *pstart, *prec; uint32_t np, pcap;   /* those records: offset in buf, index in len[] */
     uint64_t *len; uint32_t nrec, rcap;      /* every record, length as the reference sees it */
     int       last, end_kind; size_t end_len;/* last chunk of the file: how the parser ended */
@@ -232,8 +233,27 @@ typedef struct {
     int        direct;                       /* serial decode: finished chunks go straight to the stream's queue */
 } sd_builder;
 
+/* SK_SD_PACK=1: the finished chunk packed by the thread that built it -- 6 bytes per 16 bases go up instead of 16 (sk_pack.h; the scan's
+ * first phase then only copies).  Out of one pool buffer into another, the first given back at once; a chunk with a byte for the
+ * byte-string kernel, or one outside the pool, stays as it is.  OFF by default: the pass is bound by these threads' CPU time as much
+ * as by the link, and the packing is theirs to pay. */
+static int sd_pack_on(void) { const char *e = getenv("SK_SD_PACK"); return e && e[0] == '1'; }
+
+static void chunk_pack(sd_chunk *c)
+{
+    void *pk;
+    int odd = 0;
+    if (!c || !c->pinned || !c->np || c->packed || c->blen > sd_chunk_bytes() || !sd_pack_on()) return;
+    if ((pk = sd_pin_get()) == NULL) return;
+    if (sk_pack_stream(c->buf, c->blen, pk, &odd) != SK_OK || odd) { sd_pin_put(pk); return; }
+    sd_pin_put(c->buf);
+    c->buf = (uint8_t *)pk;
+    c->packed = 1;
+}
+
 static void builder_finish_chunk(sd_builder *b)
 {
+    chunk_pack(b->cur);
     if (b->direct) stream_push(b->st, b->cur);
     else {
         if (b->ndone == b->dcap) { b->dcap = b->dcap ? b->dcap * 2 : 4; b->done = (sd_chunk **)realloc(b->done, (size_t)b->dcap * sizeof *b->done); }
@@ -1130,7 +1150,7 @@ static void sd_prefetch(sd_stream *st)
     for (d = 0; d < sd_dev.n && ok; d++) {
         sk_batch **b = &st->bat[st->bcur ^ 1][d];
         if (!*b && sd_batch_get(d, b) != SK_OK) { *b = NULL; ok = 0; break; }
-        ok = sk_batch_fill(*b, n->buf, n->blen, n->pstart, n->np) == SK_OK;
+        ok = (n->packed ? sk_batch_fill_packed(*b, n->buf, n->blen, n->pstart, n->np) : sk_batch_fill(*b, n->buf, n->blen, n->pstart, n->np)) == SK_OK;
     }
     if (ok) st->pre = n;                                   /* (all devices or none: a chunk that is not everywhere goes up again) */
     t_fill += now_s() - t0;
@@ -1254,7 +1274,7 @@ static int sd_tally_chunk(sd_prog *p, uint32_t ns, sk_batch **batches, sd_pool *
         pthread_mutex_lock(&sd_dev_mu);
         rc = SK_OK;
         for (d = 0; d < sd_dev.n && !uploaded && rc == SK_OK; d++)  /* (asynchronous copies from page-locked memory: the devices' uploads overlap) */
-            rc = sk_batch_fill(batches[d], c->buf, c->blen, c->pstart, c->np);
+            rc = c->packed ? sk_batch_fill_packed(batches[d], c->buf, c->blen, c->pstart, c->np) : sk_batch_fill(batches[d], c->buf, c->blen, c->pstart, c->np);
         t1 = now_s(); t_fill += t1 - t0; t0 = t1;
         if (rc == SK_OK && !launched) rc = sd_launch(p, ns, batches);
         if (rc == SK_OK) {

@@ -123,6 +123,27 @@ static int64_t find(const sk_ctx *c, uint64_t k)
 int sk_batch_create(sk_ctx *c, sk_batch **out) { (void)c; *out = calloc(1, sizeof **out); return *out ? SK_OK : SK_E_NOMEM; }
 void sk_batch_destroy(sk_batch *b) { if (b) { free(b->bytes); free(b->start); free(b); } }
 int sk_batch_sync(sk_batch *b) { return b ? SK_OK : SK_E_ARG; }
+int sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec);
+/* a packed batch: its bytes made again (a separator for every byte that was no base: which of N, n or '\n' it was does not matter to a
+ * tally -- but a record's own end must stay a '\n', and it does: the byte behind every record was one) */
+int sk_batch_fill_packed(sk_batch *b, const void *packed, uint64_t n, const uint32_t *rec_start, uint32_t nrec)
+{
+    const uint64_t nch = (n + 15u) >> 4;
+    const uint32_t *codes = (const uint32_t *)packed;
+    const uint16_t *inv = (const uint16_t *)((const uint8_t *)packed + nch * 4u);
+    uint8_t *bytes = (uint8_t *)malloc(n ? n : 1);
+    uint64_t i;
+    int rc;
+    if (!bytes) return SK_E_NOMEM;
+    for (i = 0; i < n; i++) {
+        const uint64_t g = i >> 4;
+        const unsigned k = (unsigned)(i & 15u);
+        bytes[i] = (inv[g] >> k) & 1u ? (uint8_t)'\n' : (uint8_t)"ACGT"[(codes[g] >> (30u - 2u * k)) & 3u];
+    }
+    rc = sk_batch_fill(b, bytes, n, rec_start, nrec);
+    free(bytes);
+    return rc;
+}
 int sk_batch_fill(sk_batch *b, const uint8_t *stream, uint64_t nbytes, const uint32_t *rec_start, uint32_t nrec)
 {
     free(b->bytes); free(b->start);

@@ -80,3 +80,4 @@ void sk_inflater_destroy(struct sk_inflater *f) { (void)f; }
 uint64_t sk_inflate_gz_size(const uint8_t *gz, uint64_t n) { (void)gz; (void)n; return 0; }
 int sk_inflate_gz(struct sk_inflater *f, const uint8_t *gz, uint64_t n, uint8_t *t, uint64_t cap, uint64_t *len, uint32_t *crc) { (void)f; (void)gz; (void)n; (void)t; (void)cap; (void)len; (void)crc; return -100; }
 int sk_scan_device_packed(sk_ctx *c, const void *s, uint64_t n, uint32_t col) { (void)c; (void)s; (void)n; (void)col; return unreachable("sk_scan_device_packed"); }
+int sk_batch_fill_packed(sk_batch *b, const void *s, uint64_t n, const uint32_t *r, uint32_t nr) { (void)b; (void)s; (void)n; (void)r; (void)nr; return unreachable("sk_batch_fill_packed"); }

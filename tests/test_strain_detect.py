@@ -394,6 +394,22 @@ def test_sd_program_tiny_chunks(golden, name, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,chunk", [("batch", "500"), ("cli_pe", "3000"), ("cli_pei", "0"), ("background", "0")])
+def test_sd_program_with_packed_chunks(golden, name, chunk, tmp_path, monkeypatch):
+    """SK_SD_PACK=1: the parser threads hand their chunks on PACKED (sk_pack_stream: 6 bytes per 16 bases; sk_batch_fill_packed ->
+    sk_scan_grid<TALLY[,UNION],PACKED>) -- the goldens' result files, stdout and stderr must not change (opt-in: on a host with 16
+    CPUs per card the packing costs more than the link saves)"""
+    monkeypatch.setenv("SK_SD_PACK", "1")
+    if chunk != "0":
+        monkeypatch.setenv("SK_SD_CHUNK_BYTES", chunk)
+    d, meta, out, err, hits = _case(golden, name)
+    p, got = _run(_gpu_runner, d, meta, tmp_path)
+    assert p.returncode == meta["returncode"] == 0
+    assert p.stdout == out and p.stderr == err
+    assert got == hits
+
+
+@pytest.mark.gpu
 def test_sd_strain_list_with_background_column(golden, tmp_path):
     """-S with the optional 4th column (-g list): the background filter runs per strain on its worker thread and
     its messages come out in list order; same result as the single-strain golden"""

@@ -106,7 +106,7 @@ def main():
                               ("parse_threads_2", {"SK_PARSE_THREADS": "2"}), ("parse_threads_6", {"SK_PARSE_THREADS": "6"}),
                               ("parse_threads_8", {"SK_PARSE_THREADS": "8"}),
                               ("parse_threads_8_chunks_of_128_mib", {"SK_PARSE_THREADS": "8", "SK_SD_CHUNK_BYTES": str(128 << 20)}),
-                              ("default_again", {}), ("sync_blocking", {"SK_SYNC": "blocking"}), ("sync_yield", {"SK_SYNC": "yield"}), ("sync_blocking_again", {"SK_SYNC": "blocking"}), ("input_pread", {"SK_SD_INPUT": "pread"}), ("input_mapped", {"SK_SD_INPUT": "mapped"}),
+                              ("default_again", {}), ("chunks_packed", {"SK_SD_PACK": "1"}), ("chunks_packed_again", {"SK_SD_PACK": "1"}), ("chunks_packed_16_parsers", {"SK_SD_PACK": "1", "SK_PARSE_THREADS": "16"}), ("sync_blocking", {"SK_SYNC": "blocking"}), ("sync_yield", {"SK_SYNC": "yield"}), ("sync_blocking_again", {"SK_SYNC": "blocking"}), ("input_pread", {"SK_SD_INPUT": "pread"}), ("input_mapped", {"SK_SD_INPUT": "mapped"}),
                               ("default_once_more", {}), ("input_pread_again", {"SK_SD_INPUT": "pread"}),
                               # (sampled: gcc -O2 -shared -fPIC -o /tmp/sigprof.so tools/probes/sigprof_preload.c -ldl first; tools/sigprof_report.py reads the samples)
                               ("sigprof", {"LD_PRELOAD": "/tmp/sigprof.so", "SK_LEAK_AT_EXIT": "0", "SK_PROF_OUT": os.path.join(REPO, "gpurun_out", "sigprof_sd.txt")}),
