@@ -828,7 +828,9 @@ typedef struct {
     int             timing;            /* SK_TIMING: where the decode threads' time goes (seconds summed over threads, under queue_mu) */
     double          t_item, t_submit_wait, t_submit, t_ticket, t_cpu, t_pack;
     uint64_t        nchunks, npacked;
-    int             pack;              /* chunks of plain-text items go up packed (6 bytes per 16 bases; SK_LIST_PACK=0: never, 2: .gz items' too) */
+    int             pack;              /* SK_LIST_PACK: 1 (default) = the chunks of plain-text items go up packed (6 bytes per 16 bases) once the scan has shown
+                                        * itself bound by the link; 0 = never; 2 = always, .gz items' too (tests) */
+    int             link_bound;        /* a decode thread has spent a tenth of its time waiting for uploads (atomic) */
 } scan_pool;
 
 /* The progress file gets a list line when a decode thread TAKES the line's (first) item, and every line before it that is
@@ -858,6 +860,7 @@ typedef struct {
     uint8_t   *pk[2];                  /* the chunks' packed form (sk_pack_stream), two page-locked buffers taking turns ... */
     uint64_t   pk_ticket[2];           /* ... each rewritten only after the upload that read it */
     int        pk_used[2], pk_cur;
+    double     t_begin, t_wait_all;    /* since this worker began: time spent waiting for its buffers' uploads */
 } scan_worker;
 
 /* size of a worker's chunk buffer: SK_CHUNK_BYTES (4096 .. 63 MiB; tests use small ones: many flushes per file), default 32 MiB */
@@ -875,7 +878,7 @@ static int worker_sink(void *user, const uint8_t *chunk, uint64_t nbytes)
     int rc;
     double t0 = w->pool->timing ? now_s() : 0.0;
     double t1;
-    if (w->pool->pack > 1 || (w->pool->pack && tl_plain_text)) {
+    if (w->pool->pack > 1 || (w->pool->pack && tl_plain_text && __atomic_load_n(&w->pool->link_bound, __ATOMIC_RELAXED))) {
         /* The chunk goes up PACKED: what the scan kernel's first phase would make of its bytes is made here (sk_pack.h), 6 bytes per
          * 16 bases over the link instead of 16 -- the list scan of plain text was bound by the link, not by these threads.  A chunk
          * with a byte for the byte-string kernel (IUPAC, U, CR ...) goes up as bytes, below. */
@@ -921,9 +924,17 @@ static uint8_t *worker_next_buf(void *user)
     scan_worker *w = (scan_worker *)user;
     w->cur ^= 1;
     if (w->used[w->cur]) {
-        const double t0 = w->pool->timing ? now_s() : 0.0;
+        const double t0 = now_s();
+        double dt;
         sk_ticket_wait(w->pool->ctx, w->ticket[w->cur]);
-        if (w->pool->timing) w->t_ticket += now_s() - t0;
+        dt = now_s() - t0;
+        if (w->pool->timing) w->t_ticket += dt;
+        /* Is this list scan bound by the link?  A thread that has spent a tenth of its time waiting for its own buffers' uploads says
+         * so for all: from then on the chunks of plain-text items go up packed (worker_sink).  A scan that is short of CPUs instead
+         * -- few threads per card, .gz items -- never waits here and keeps its cycles for the decode. */
+        w->t_wait_all += dt;
+        if (!__atomic_load_n(&w->pool->link_bound, __ATOMIC_RELAXED) && w->t_wait_all > 0.002 && w->t_wait_all > 0.1 * (now_s() - w->t_begin))
+            __atomic_store_n(&w->pool->link_bound, 1, __ATOMIC_RELAXED);
     }
     return worker_buf(w, w->cur);
 }
@@ -932,6 +943,7 @@ static int worker_init(scan_worker *w, scan_pool *p)
 {
     memset(w, 0, sizeof *w);
     w->pool = p;
+    w->t_begin = now_s();
     return SK_OK;
 }
 
@@ -1402,7 +1414,7 @@ static int scan_list_once(sk_ctx *ctx, const char *list_path, const char *skip, 
     if (no_split == 2) local_fail |= LIST_FAIL_GUARD;       /* (second scan after a failed cut: this rank could not put its column back) */
     memset(&pool, 0, sizeof pool);
     pool.timing = getenv("SK_TIMING") != NULL;
-    { const char *e = getenv("SK_LIST_PACK"); pool.pack = e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }      /* (0: never, 2: always -- tests --, default: the chunks of plain-text items) */
+    { const char *e = getenv("SK_LIST_PACK"); pool.pack = e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }      /* (0: never, 2: always -- tests --, default: plain-text items' chunks once the scan is bound by the link) */
     pool.ctx = ctx;
     pool.col = col;
     pthread_mutex_init(&pool.submit_mu, NULL);

@@ -34,14 +34,16 @@ def _golden_case(golden, name):
     return d, meta, open(os.path.join(d, "expected.stdout"), "rb").read(), open(os.path.join(d, "expected.stderr"), "rb").read()
 
 
+@pytest.mark.parametrize("pack", ["1", "2"])
 @pytest.mark.parametrize("name", CASES)
-def test_program_matches_reference_golden(golden, name, tmp_path):
-    """bin/kmer_scrub_count vs the bytes the unmodified reference printed (stdout, stderr, status, progress)."""
+def test_program_matches_reference_golden(golden, name, tmp_path, pack):
+    """bin/kmer_scrub_count vs the bytes the unmodified reference printed (stdout, stderr, status, progress); SK_LIST_PACK=2: with
+    every chunk of every list uploaded in the host-packed form (chunks with IUPAC letters, U or CR fall back to bytes by themselves)"""
     d, meta, out, err = _golden_case(golden, name)
     argv = list(meta["argv"])
     if "-p" in argv:
         argv[argv.index("-p") + 1] = str(tmp_path / "progress")
-    p = subprocess.run([sk.cli_path()] + argv, cwd=d, capture_output=True)
+    p = subprocess.run([sk.cli_path()] + argv, cwd=d, capture_output=True, env=dict(os.environ, SK_LIST_PACK=pack))
     assert p.returncode == meta["returncode"]
     assert p.stdout == out
     assert p.stderr == err

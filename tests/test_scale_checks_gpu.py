@@ -46,8 +46,10 @@ def _shm_free_gb():
         return 0.0
 
 
-def test_cfg3_at_spec_as_one_job_against_the_references_facts():
-    """BASELINE configs[2] AT SPEC through bin/kmer_scrub_count as ONE job (the at-spec pins belong where the
+@pytest.mark.parametrize("pack", ["2", "0"])
+def test_cfg3_at_spec_as_one_job_against_the_references_facts(pack):
+    """(SK_LIST_PACK: every chunk uploaded packed by the decode threads / every chunk as bytes -- the default decides by the waits it sees)
+    BASELINE configs[2] AT SPEC through bin/kmer_scrub_count as ONE job (the at-spec pins belong where the
     driver runs them): the real 1000 x 5 Mbp -A list (ten strain copies at 1 % divergence), the 67 x 1 M-read FASTQ -B files listed
     once, -C with the -r path among its five genomes, -p -- all four columns (sum, non-zero rows, max, md5 of the u32 vector in the
     reference's row order), stderr and the progress file against tests/golden/cfg3_full_facts.json, which the UNMODIFIED
@@ -56,7 +58,7 @@ def test_cfg3_at_spec_as_one_job_against_the_references_facts():
     if _shm_free_gb() < 45:
         pytest.skip("needs 45 GB free under /dev/shm for the inputs and the table (%.0f GB free)" % _shm_free_gb())
     import json
-    out = _run("cfg3_full.py", LIST_REPEAT="1", WORK="/dev/shm/sk_cfg3_test")
+    out = _run("cfg3_full.py", LIST_REPEAT="1", WORK="/dev/shm/sk_cfg3_test", SK_LIST_PACK=pack)
     rep = json.loads(out[out.index("{"):])
     assert rep["identical_to_the_reference"] is True and rep["differences"] == [], rep["differences"]
     assert rep["list_repeat"] == 1 and rep["bases_scanned_total"] == 5_000_000_000 + 10_050_000_000 + 20_000_000
