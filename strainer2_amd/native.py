@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "sk_filter_create", "sk_filter_destroy", "sk_filter_load", "sk_filter_load_counts", "sk_filter_sums",
     "sk_filter_hist", "sk_filter_joint", "sk_filter_above", "skh_scrub_filter_main", "skh_scrub_filter_resident",
     "sk_distinct_count", "sk_first_seen_count", "skh_coverage_depth_main",
-    "sk_batch_create", "sk_batch_destroy", "sk_batch_sync", "sk_batch_fill", "sk_tally_launch", "sk_tally_collect", "sk_tally_collect_sparse",
+    "sk_batch_create", "sk_batch_destroy", "sk_batch_sync", "sk_batch_fill", "sk_batch_fill_packed", "sk_tally_launch", "sk_tally_collect", "sk_tally_collect_sparse",
     "sk_union_create", "sk_union_destroy", "sk_union_tally_launch", "sk_union_tally_collect", "sk_union_last_error", "sk_union_scan_timing", "sk_union_sync",
     "sk_union_members", "sk_union_rows",
 ]
@@ -152,6 +152,7 @@ lib.sk_batch_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
 lib.sk_batch_destroy.argtypes = [C.c_void_p]
 lib.sk_batch_destroy.restype = None
 lib.sk_batch_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+lib.sk_batch_fill_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
 lib.sk_tally_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
 lib.sk_tally_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
 lib.sk_tally_collect_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]
