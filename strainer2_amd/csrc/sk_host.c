@@ -85,6 +85,15 @@ int sk_pack_stream(const uint8_t *stream, uint64_t nbytes, void *packed, int *od
 
 /* pipe: inflate on a helper thread while this one parses (worth it when there are fewer files than cores);
  * pipe > 1: the helper inflates each gzip member with that many threads (sk_gzpar.h) */
+/* how a plain file's bytes are got at: 0 = its pages populated into a mapping block by block (default), 1 = read() (SK_LIST_INPUT=read,
+ * or set by the first thread that finds the kernel without MADV_POPULATE_READ) */
+static int list_input_mode = 0;
+static int list_input_read(void)
+{
+    const char *e = getenv("SK_LIST_INPUT");
+    return __atomic_load_n(&list_input_mode, __ATOMIC_RELAXED) || (e && !strcmp(e, "read"));
+}
+
 /* this thread is parsing PLAIN text (set by parse_file / parse_range, read by the list scan's sink): only then are its chunks packed
  * before they go up -- a .gz item is bound by its inflate on these same CPUs, the link idles, and packing would cost it 7 % */
 static __thread int tl_plain_text;
@@ -122,8 +131,39 @@ static int parse_file(const char *path, rec_fn fn, void *user, int64_t *nrecords
          * through gzread below, which hands the same bytes on */
         const int fd = open(path, O_RDONLY);
         struct stat sb;
+        size_t resume_at = 0;
         tl_plain_text = 1;
-        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+        /* Later in round 4: the mapping WITHOUT its two costs.  A block's pages are put into the address space by one call
+         * (MADV_POPULATE_READ: no trap per 64 KiB), parsed where they lie, and taken out again by one call (MADV_DONTNEED) -- the
+         * lock is only ever taken for reading, and munmap finds nothing to tear down (that teardown under the lock for WRITING is
+         * what the other threads' page faults waited for).  No copy: once the chunks went up packed and the scan was bound by
+         * its CPUs, a sampling of the program counter had 56 % of the decode threads' time inside read()
+         * (tools/probes/sigprof_preload.c, profiles/r04_sigprof.txt).  SK_LIST_INPUT=read is the copying way, also taken where the
+         * kernel has no MADV_POPULATE_READ (before 5.14) or the pages cannot be had (a file that shrank) */
+#ifdef MADV_POPULATE_READ
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !list_input_read()) {
+            const size_t n = (size_t)sb.st_size, PBLK = (size_t)4 << 20;
+            unsigned char *t = (unsigned char *)mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (t != MAP_FAILED) {
+                size_t at = 0;
+                while (at < n && ps.state != P_STOP) {
+                    const size_t take = n - at < PBLK ? n - at : PBLK;
+                    const size_t span = (take + 4095u) & ~(size_t)4095u;          /* (PBLK is a multiple of the page size: `at` stays page-aligned) */
+                    if (madvise(t + at, span, MADV_POPULATE_READ) != 0) {
+                        if (errno == EINVAL) __atomic_store_n(&list_input_mode, 1, __ATOMIC_RELAXED);
+                        break;
+                    }
+                    parser_feed(&ps, t + at, take);
+                    (void)madvise(t + at, span, MADV_DONTNEED);
+                    at += take;
+                }
+                munmap(t, n);
+                if (at >= n || ps.state == P_STOP) zrc = SKZ_OK;
+                else resume_at = at;
+            }
+        }
+#endif
+        if (zrc == SKZ_NOT_GZIP && fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && lseek(fd, (off_t)resume_at, SEEK_SET) == (off_t)resume_at) {
             const char *e = getenv("SK_READ_BLOCK");                /* (64 bytes -- tests -- .. 32 MiB; default 4 MiB) */
             const long long ev = e ? atoll(e) : 0;
             const size_t RBLK = ev >= 64 && ev <= (32 << 20) ? (size_t)ev : (size_t)4 << 20;
@@ -991,6 +1031,19 @@ static int parse_range(const scan_item *it, rec_fn fn, void *user, int64_t *nrec
         for (i = sa; i < sb && ps.state != P_STOP; ) {
             const size_t want = (size_t)(sb - i < BLK ? sb - i : BLK);
             size_t have = 0;
+#ifdef MADV_POPULATE_READ
+            if (!list_input_read()) {                        /* the block's pages populated, parsed in place, dropped (parse_file above) */
+                const uintptr_t pa = (uintptr_t)(t + i) & ~(uintptr_t)4095u, pe = ((uintptr_t)(t + i) + want + 4095u) & ~(uintptr_t)4095u;
+                if (madvise((void *)pa, (size_t)(pe - pa), MADV_POPULATE_READ) == 0) {
+                    const uintptr_t da = ((uintptr_t)(t + i) + 4095u) & ~(uintptr_t)4095u, de = ((uintptr_t)(t + i) + want) & ~(uintptr_t)4095u;
+                    parser_feed(&ps, t + i, want);
+                    if (de > da) (void)madvise((void *)da, (size_t)(de - da), MADV_DONTNEED);
+                    i += want;
+                    continue;
+                }
+                if (errno == EINVAL) __atomic_store_n(&list_input_mode, 1, __ATOMIC_RELAXED);
+            }
+#endif
             while (rb && have < want) {
                 const ssize_t r = pread(fd, rb + have, want - have, (off_t)(i + have));
                 if (r < 0 && errno == EINTR) continue;
@@ -1273,6 +1326,7 @@ static void *pool_worker(void *arg)
     scan_pool *p = (scan_pool *)arg;
     scan_worker w;
     int wrc = worker_init(&w, p);
+    pthread_setname_np(pthread_self(), "sk-decode");
     pthread_mutex_lock(&p->queue_mu);
     w.dev_ok = p->worker_ids++ < p->dev_workers;
     pthread_mutex_unlock(&p->queue_mu);
