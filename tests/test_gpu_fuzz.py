@@ -71,6 +71,56 @@ def test_scan_count_fuzz(seed):
             assert np.array_equal(c.counts(col), ocounts[:, col]), (seed, col)
 
 
+_CLEAN = bytes(b if b in b"ACGTacgtNn\n" else ord("N") for b in range(256))
+
+
+@pytest.mark.parametrize("seed", list(range(200, 224)) + list(range(7 * BASE + 2000, 7 * BASE + 2000 + EXTRA // 3)))
+def test_scan_count_fuzz_packed(seed):
+    """the same worlds with every byte that is neither A/C/G/T, N/n nor a newline turned into N (a packed batch holds no other), scanned
+    in the host-PACKED form (sk_pack_stream -> sk_scan_pinned_packed, chunks of whole records in pinned memory, ragged sizes) against the
+    oracle's counts of the same bytes"""
+    sstream, data = world(seed)
+    data = data.translate(_CLEAN)
+    ks = sk.Keyset.from_stream(sstream)
+    t = _oracle.OracleTable()
+    assert t.build_stream(sstream, short_policy=1) == 0
+    rng = random.Random(seed)
+    with sk.KmerContext(0) as c:
+        if seed % 5 == 0:
+            c.set_option("text_stage", 0)
+        c.load_keyset(ks, 4)
+        cap = rng.choice([1 << 13, 1 << 16, 1 << 20])
+        recs = data.split(b"\n")[:-1]
+        raw = np.empty(cap, dtype=np.uint8)
+        pk = [c.pinned_alloc(6 * ((cap + 15) // 16)) for _ in range(2)]
+        tickets = [None, None]
+        i = k = 0
+        while i < len(recs):
+            n, j = 0, i
+            while j < len(recs) and n + len(recs[j]) + 1 <= cap:
+                n += len(recs[j]) + 1
+                j += 1
+            if j == i:                                  # (a record longer than the chunk: as bytes, the way the programs cut it)
+                c.scan_stream(recs[i] + b"\n", 1)
+                i += 1
+                continue
+            raw[:n] = np.frombuffer(b"\n".join(recs[i:j]) + b"\n", dtype=np.uint8)
+            if tickets[k] is not None:
+                c.ticket_wait(tickets[k])
+            _, odd = sk.pack_stream(raw[:n], out=pk[k])
+            assert not odd
+            tickets[k] = c.scan_pinned_packed(pk[k], n, 1)
+            k ^= 1
+            i = j
+        c.sync()
+        t.scan_stream(data, 1)
+        okeys, ocounts = t.rows()
+        assert ks.keys() == okeys
+        assert np.array_equal(c.counts(1), ocounts[:, 1]), seed
+        for a in pk:
+            c.pinned_free(a)
+
+
 @pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(4 * BASE + 1000, 4 * BASE + 1000 + EXTRA // 3)))
 def test_tally_fuzz(seed):
     """per-read tallies and the log of informative hits against counts derived from the oracle's scan of each
