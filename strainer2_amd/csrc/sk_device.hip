@@ -803,7 +803,8 @@ struct sk_batch {
     uint64_t     nbytes;
     uint32_t     nrec, ntiles;
     bool         packed;                // d_stream holds the host-packed form (sk_pack_stream) of nbytes bytes
-    std::vector<uint32_t> tile_first;
+    uint32_t    *h_rec;                 // page-locked staging of rec_start[nrec] + tile_first[ntiles + 2]: ONE copy from pinned memory instead of
+    size_t       h_rec_cap;             // two from the caller's pageable arrays (which the runtime stages, chunk by chunk, on its own threads)
 };
 
 extern "C" int sk_batch_create(sk_ctx *c, sk_batch **out)
@@ -815,6 +816,7 @@ extern "C" int sk_batch_create(sk_ctx *c, sk_batch **out)
     if (!b) return SK_E_NOMEM;
     b->owner = c;
     b->d_stream = b->d_rec = NULL; b->stream_cap = b->rec_cap = 0; b->nbytes = 0; b->nrec = b->ntiles = 0;
+    b->h_rec = NULL; b->h_rec_cap = 0; b->packed = false;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; return sk_fail(c, SK_E_HIP, "stream"); }
     if (hipEventCreateWithFlags(&b->ready, hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(b->stream); delete b; return sk_fail(c, SK_E_HIP, "event"); }
     *out = b;
@@ -836,6 +838,7 @@ extern "C" void sk_batch_destroy(sk_batch *b)
     hipSetDevice(b->owner->device);
     hipStreamSynchronize(b->stream);
     hipFree(b->d_stream); hipFree(b->d_rec);
+    if (b->h_rec) hipHostFree(b->h_rec);
     hipEventDestroy(b->ready);
     hipStreamDestroy(b->stream);
     delete b;
@@ -875,17 +878,24 @@ static int sk_batch_fill_any(sk_batch *b, const uint8_t *stream, uint64_t nbytes
         SK_HIP(c, hipMalloc(&b->d_rec, want));
         b->rec_cap = want;
     }
-    SK_HIP(c, hipStreamSynchronize(b->stream));            // tile_first (host vector) of the previous upload is free again
-    b->tile_first.resize((size_t)ntiles + 2);
+    SK_HIP(c, hipStreamSynchronize(b->stream));            // the staging of the previous upload is free again
+    if (rec_need > b->h_rec_cap) {
+        if (b->h_rec) (void)hipHostFree(b->h_rec);
+        b->h_rec = NULL; b->h_rec_cap = 0;
+        const size_t want = rec_need + rec_need / 4 + 4096;
+        SK_HIP(c, hipHostMalloc((void **)&b->h_rec, want, hipHostMallocDefault));
+        b->h_rec_cap = want;
+    }
+    memcpy(b->h_rec, rec_start, (size_t)nrec * 4);
+    uint32_t *const tile_first = b->h_rec + nrec;
     for (uint32_t t = 0, r = 0; t < ntiles + 2; t++) {     // first record starting at or after the tile's first byte
         const uint64_t edge = (uint64_t)t << 15;
         while (r < nrec && rec_start[r] < edge) r++;
-        b->tile_first[t] = r;
+        tile_first[t] = r;
     }
     SK_HIP(c, hipMemcpyAsync(b->d_stream, stream, packed ? ((nbytes + 15u) >> 4) * 6u : nbytes, hipMemcpyHostToDevice, b->stream));
     b->packed = packed;
-    SK_HIP(c, hipMemcpyAsync(b->d_rec, rec_start, (size_t)nrec * 4, hipMemcpyHostToDevice, b->stream));
-    SK_HIP(c, hipMemcpyAsync((uint32_t *)b->d_rec + nrec, b->tile_first.data(), (size_t)(ntiles + 2) * 4, hipMemcpyHostToDevice, b->stream));
+    SK_HIP(c, hipMemcpyAsync(b->d_rec, b->h_rec, ((size_t)nrec + ntiles + 2) * 4, hipMemcpyHostToDevice, b->stream));
     SK_HIP(c, hipEventRecord(b->ready, b->stream));
     b->nbytes = nbytes; b->nrec = nrec; b->ntiles = ntiles;
     return SK_OK;
