@@ -52,6 +52,16 @@ def test_program_matches_reference_golden(golden, name, tmp_path, pack):
             assert [ln.split("\t")[0].rstrip("\n") for ln in f] == meta["progress_col1"]
 
 
+@pytest.mark.parametrize("sync", ["blocking", "yield"])
+def test_program_with_waits_that_sleep(golden, sync):
+    """SK_SYNC: the process's waits for the device sleep (hipDeviceScheduleBlockingSync, blocking events) or yield instead of spinning --
+    an option for hosts that are short of CPUs; the table is the same"""
+    for name in ("mixed", "drug"):
+        d, meta, out, err = _golden_case(golden, name)
+        p = subprocess.run([sk.cli_path()] + list(meta["argv"]), cwd=d, capture_output=True, env=dict(os.environ, SK_SYNC=sync, SK_THREADS="3", SK_CHUNK_BYTES="8192"))
+        assert p.returncode == meta["returncode"] and p.stdout == out and p.stderr == err
+
+
 def test_program_through_rccl_path_single_rank(golden, tmp_path):
     """SK_FORCE_COMM=1: the one-process-per-GPU code path (RCCL unique-id rendezvous, failure agreement,
     all-reduce of the counter block, rank 0 prints) with a world of one; output must not change."""
